@@ -1,0 +1,93 @@
+// common.hpp -- shared device helpers for the gfx950 kernels (wave64, CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "hevcasm_hip.h"
+
+namespace hevc {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private L2
+constexpr int kThreads = 256;      // 4 waves per workgroup, one per SIMD
+
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Loads with no alignment promise.  gfx950 runs with unaligned access enabled, so these
+// compile to one global_load_dword{,x2,x4} whatever the address.
+struct __attribute__((packed, aligned(1))) U1 { uint32_t v; };
+struct __attribute__((packed, aligned(1))) U2 { u32x2 v; };
+struct __attribute__((packed, aligned(1))) U4 { u32x4 v; };
+struct __attribute__((packed, aligned(1))) H1 { uint16_t v; };
+
+template <int BYTES> struct Chunk;
+template <> struct Chunk<4>
+{
+	uint32_t d[1];
+	__device__ __forceinline__ void load(const uint8_t *p) { d[0] = reinterpret_cast<const U1 *>(p)->v; }
+	__device__ __forceinline__ void store(uint8_t *p) const { reinterpret_cast<U1 *>(p)->v = d[0]; }
+};
+template <> struct Chunk<8>
+{
+	uint32_t d[2];
+	__device__ __forceinline__ void load(const uint8_t *p)
+	{
+		const u32x2 v = reinterpret_cast<const U2 *>(p)->v;
+		d[0] = v.x; d[1] = v.y;
+	}
+	__device__ __forceinline__ void store(uint8_t *p) const
+	{
+		u32x2 v; v.x = d[0]; v.y = d[1];
+		reinterpret_cast<U2 *>(p)->v = v;
+	}
+};
+template <> struct Chunk<16>
+{
+	uint32_t d[4];
+	__device__ __forceinline__ void load(const uint8_t *p)
+	{
+		const u32x4 v = reinterpret_cast<const U4 *>(p)->v;
+		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	}
+	__device__ __forceinline__ void store(uint8_t *p) const
+	{
+		u32x4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+		reinterpret_cast<U4 *>(p)->v = v;
+	}
+};
+
+// Workgroups are dealt round-robin over the 8 XCDs.  Give each XCD one contiguous run of the
+// block list so that neighbouring blocks (which share cache lines of the frame rows they
+// straddle) meet in the same L2.  Bijective for any grid size; speed only, never correctness.
+__device__ __forceinline__ uint32_t xcd_contiguous(uint32_t wg, uint32_t n_wg)
+{
+	const uint32_t q = n_wg / kXcds, r = n_wg % kXcds;
+	const uint32_t xcd = wg % kXcds, k = wg / kXcds;
+	// XCD x owns q (+1 if x < r) consecutive slots
+	const uint32_t start = xcd * q + (xcd < r ? xcd : r);
+	return start + k;
+}
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+
+// host side -------------------------------------------------------------------------------
+
+int set_error(int code, const char *what);     // records thread-local text, returns code
+int check_device();                            // 0 or HEVCASM_HIP_ENODEV
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define HEVC_HIP_TRY(expr) \
+	do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hevc::set_error((int)e_, hipGetErrorString(e_)); } while (0)
+
+inline int launch_status(const char *kernel)
+{
+	hipError_t e = hipGetLastError();
+	return e == hipSuccess ? 0 : set_error((int)e, kernel);
+}
+
+inline uint32_t ceil_div(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+}  // namespace hevc

@@ -1,0 +1,281 @@
+// perblock.hip -- the reference's per-block function types, served by the batched kernels.
+//
+// Behind the HEVCASM_HIP bit a hevcasm_table_* slot must hold a function with the reference's
+// per-block signature taking HOST pointers (sad.h:50, pred_inter.h:56, ...).  Each wrapper here
+// copies the block (plus filter margins) into pinned host memory that is mapped into the
+// device's address space, launches the batched kernel with n_blocks = 1 reading and writing
+// that memory directly over the host link (no separate memcpy calls), waits on the calling
+// thread's private stream, and copies the result out.  Same kernels, same arithmetic as the
+// batch API; one launch per block, so this is the verification path (hevcasm_test's HIP
+// column), not the throughput path.
+//
+// No fallback: a HIP failure here aborts with the error text, because the per-block signatures
+// cannot report errors and returning a CPU-computed value would hide a broken GPU path.
+
+#include "common.hpp"
+#include "../host/perblock.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+constexpr size_t kArenaBytes = 256 * 1024;
+
+struct Arena
+{
+	uint8_t *host = nullptr;
+	uint8_t *dev = nullptr;
+	hipStream_t stream = nullptr;
+	size_t used = 0;
+
+	void init()
+	{
+		if (host) return;
+		check(hipHostMalloc(reinterpret_cast<void **>(&host), kArenaBytes, hipHostMallocMapped), "hipHostMalloc");
+		check(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0), "hipHostGetDevicePointer");
+		check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+	}
+	static void check(hipError_t e, const char *what)
+	{
+		if (e == hipSuccess) return;
+		std::fprintf(stderr, "hevcasm HIP per-block path: %s failed: %s\n", what, hipGetErrorString(e));
+		std::abort();
+	}
+	static void check_call(int rc, const char *what)
+	{
+		if (rc == 0) return;
+		std::fprintf(stderr, "hevcasm HIP per-block path: %s failed: %s\n", what, hevcasm_hip_last_error());
+		std::abort();
+	}
+	void reset() { init(); used = 0; }
+	// returns the offset of a 64-byte aligned region
+	size_t take(size_t bytes)
+	{
+		const size_t at = (used + 63) & ~size_t(63);
+		if (at + bytes > kArenaBytes) { std::fprintf(stderr, "hevcasm HIP per-block path: staging arena exhausted\n"); std::abort(); }
+		used = at + bytes;
+		return at;
+	}
+	template <typename T> T *h(size_t off) { return reinterpret_cast<T *>(host + off); }
+	template <typename T> T *d(size_t off) { return reinterpret_cast<T *>(dev + off); }
+	void wait() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+};
+
+thread_local Arena g_arena;
+
+// copy a w x h byte rectangle whose top-left is `p` (row stride `stride`), with `margin_before`
+// rows/columns before it and `margin_after` after it, into the arena; returns the offset of the
+// staged top-left sample and the staged row stride.
+size_t stage_plane(Arena &a, const uint8_t *p, ptrdiff_t stride, int w, int h, int before, int after, ptrdiff_t *staged_stride)
+{
+	const int sw = w + before + after, sh = h + before + after;
+	const ptrdiff_t ss = (sw + 15) & ~15;
+	const size_t off = a.take((size_t)ss * sh);
+	for (int y = 0; y < sh; ++y)
+		std::memcpy(a.h<uint8_t>(off) + y * ss, p + (ptrdiff_t)(y - before) * stride - before, (size_t)sw);
+	*staged_stride = ss;
+	return off + (size_t)before * ss + before;
+}
+
+size_t stage_u32(Arena &a, uint32_t v0, uint32_t v1 = 0, uint32_t v2 = 0, uint32_t v3 = 0)
+{
+	const size_t off = a.take(16);
+	uint32_t *p = a.h<uint32_t>(off);
+	p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3;
+	return off;
+}
+
+
+void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
+{
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sr;
+	const size_t r = stage_plane(a, ref, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr);
+	const ptrdiff_t sd = (w + 15) & ~15;
+	const size_t d = a.take((size_t)sd * h);
+	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)r);
+	const size_t fr = a.take(16);
+	a.h<uint8_t>(fr)[0] = (uint8_t)(xFrac | (yFrac << 4));
+	Arena::check_call(hevcasm_hip_pred_uni_8to8_batch(a.dev, sd, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint8_t>(fr),
+			taps, w, h, 1, a.stream), "pred_uni");
+	a.wait();
+	for (int y = 0; y < h; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)w);
+}
+
+void pred_bi(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
+{
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sr, sr1;
+	const size_t r0 = stage_plane(a, ref0, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr);
+	const size_t r1 = stage_plane(a, ref1, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr1);
+	const ptrdiff_t sd = (w + 15) & ~15;
+	const size_t d = a.take((size_t)sd * h);
+	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)r0, (uint32_t)r1);
+	const size_t fr = a.take(16);
+	a.h<uint8_t>(fr)[0] = (uint8_t)(xFrac0 | (yFrac0 << 4));
+	a.h<uint8_t>(fr)[1] = (uint8_t)(xFrac1 | (yFrac1 << 4));
+	Arena::check_call(hevcasm_hip_pred_bi_8to8_batch(a.dev, sd, a.dev, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint32_t>(offs) + 2,
+			a.d<uint8_t>(fr), a.d<uint8_t>(fr) + 1, taps, w, h, 1, a.stream), "pred_bi");
+	a.wait();
+	for (int y = 0; y < h; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)w);
+}
+
+void inverse(int trType, int log2n, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *coeffs)
+{
+	const int n = 1 << log2n;
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sp;
+	const size_t p = stage_plane(a, pred, stride_pred, n, n, 0, 0, &sp);
+	const ptrdiff_t sd = (n + 15) & ~15;
+	const size_t d = a.take((size_t)sd * n);
+	const size_t c = a.take(sizeof(int16_t) * n * n);
+	std::memcpy(a.h<int16_t>(c), coeffs, sizeof(int16_t) * n * n);
+	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)p);
+	Arena::check_call(hevcasm_hip_inverse_transform_add_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(c),
+			trType, log2n, 1, a.stream), "inverse_transform_add");
+	a.wait();
+	for (int y = 0; y < n; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)n);
+}
+
+void forward(int trType, int log2n, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride)
+{
+	const int n = 1 << log2n;
+	Arena &a = g_arena;
+	a.reset();
+	const size_t s = a.take(sizeof(int16_t) * n * n);
+	for (int y = 0; y < n; ++y) std::memcpy(a.h<int16_t>(s) + y * n, src + y * src_stride, sizeof(int16_t) * n);
+	const size_t c = a.take(sizeof(int16_t) * n * n);
+	const size_t offs = stage_u32(a, 0);
+	Arena::check_call(hevcasm_hip_transform_batch(a.d<int16_t>(c), a.d<int16_t>(s), n, a.d<uint32_t>(offs), trType, log2n, 1, a.stream), "transform");
+	a.wait();
+	std::memcpy(coeffs, a.h<int16_t>(c), sizeof(int16_t) * n * n);
+}
+
+}  // namespace
+
+extern "C" {
+
+int hevcasm_hip1_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, uint32_t rect)
+{
+	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t ss, sr;
+	const size_t s = stage_plane(a, src, stride_src, w, h, 0, 0, &ss);
+	const size_t r = stage_plane(a, ref, stride_ref, w, h, 0, 0, &sr);
+	const size_t offs = stage_u32(a, (uint32_t)s, (uint32_t)r);
+	const size_t out = a.take(16);
+	Arena::check_call(hevcasm_hip_sad_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), rect, 1, a.stream), "sad");
+	a.wait();
+	return *a.h<int>(out);
+}
+
+void hevcasm_hip1_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref[], ptrdiff_t stride_ref, int sad[], uint32_t rect)
+{
+	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t ss, sr = 0;
+	const size_t s = stage_plane(a, src, stride_src, w, h, 0, 0, &ss);
+	size_t r[4];
+	for (int k = 0; k < 4; ++k) r[k] = stage_plane(a, ref[k], stride_ref, w, h, 0, 0, &sr);
+	const size_t so = stage_u32(a, (uint32_t)s);
+	const size_t ro = stage_u32(a, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
+	const size_t out = a.take(16);
+	Arena::check_call(hevcasm_hip_sad_multiref_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(so), a.d<uint32_t>(ro), a.d<int>(out), rect, 1, a.stream), "sad_multiref");
+	a.wait();
+	std::memcpy(sad, a.h<int>(out), 4 * sizeof(int));
+}
+
+int hevcasm_hip1_ssd(const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB, int w, int h)
+{
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sa, sb;
+	const size_t pa = stage_plane(a, srcA, stride_srcA, w, h, 0, 0, &sa);
+	const size_t pb = stage_plane(a, srcB, stride_srcB, w, h, 0, 0, &sb);
+	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
+	const size_t out = a.take(16);
+	Arena::check_call(hevcasm_hip_ssd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), w, h, 1, a.stream), "ssd");
+	a.wait();
+	return *a.h<int>(out);
+}
+
+void hevcasm_hip1_pred_uni_8tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref, ptrdiff_t sr, int w, int h, int xf, int yf) { pred_uni(8, dst, sd, ref, sr, w, h, xf, yf); }
+void hevcasm_hip1_pred_uni_4tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref, ptrdiff_t sr, int w, int h, int xf, int yf) { pred_uni(4, dst, sd, ref, sr, w, h, xf, yf); }
+void hevcasm_hip1_pred_bi_8tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *r0, const uint8_t *r1, ptrdiff_t sr, int w, int h, int x0, int y0, int x1, int y1) { pred_bi(8, dst, sd, r0, r1, sr, w, h, x0, y0, x1, y1); }
+void hevcasm_hip1_pred_bi_4tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *r0, const uint8_t *r1, ptrdiff_t sr, int w, int h, int x0, int y0, int x1, int y1) { pred_bi(4, dst, sd, r0, r1, sr, w, h, x0, y0, x1, y1); }
+
+void hevcasm_hip1_idst_4(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse(1, 2, d, sd, p, sp, c); }
+void hevcasm_hip1_idct_4(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse(0, 2, d, sd, p, sp, c); }
+void hevcasm_hip1_idct_8(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse(0, 3, d, sd, p, sp, c); }
+void hevcasm_hip1_idct_16(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse(0, 4, d, sd, p, sp, c); }
+void hevcasm_hip1_idct_32(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse(0, 5, d, sd, p, sp, c); }
+
+void hevcasm_hip1_dst_4(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(1, 2, c, s, st); }
+void hevcasm_hip1_dct_4(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 2, c, s, st); }
+void hevcasm_hip1_dct_8(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 3, c, s, st); }
+void hevcasm_hip1_dct_16(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 4, c, s, st); }
+void hevcasm_hip1_dct_32(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 5, c, s, st); }
+
+void hevcasm_hip1_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
+{
+	Arena &a = g_arena;
+	for (int done = 0; done < n;)
+	{
+		const int m = n - done < 32768 ? n - done : 32768;
+		a.reset();
+		const size_t s = a.take(sizeof(int16_t) * m), d = a.take(sizeof(int16_t) * m);
+		std::memcpy(a.h<int16_t>(s), src + done, sizeof(int16_t) * m);
+		Arena::check_call(hevcasm_hip_quantize_inverse(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, (size_t)m, a.stream), "quantize_inverse");
+		a.wait();
+		std::memcpy(dst + done, a.h<int16_t>(d), sizeof(int16_t) * m);
+		done += m;
+	}
+}
+
+int hevcasm_hip1_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
+{
+	// the batch kernel takes whole blocks of 16, 64, 256 or 1024 coefficients: use the largest that divides n
+	Arena &a = g_arena;
+	int cbf = 0;
+	for (int done = 0; done < n;)
+	{
+		const int left = n - done;
+		const int npb = left >= 1024 ? 1024 : left >= 256 ? 256 : left >= 64 ? 64 : 16;
+		if (left < 16) { std::fprintf(stderr, "hevcasm HIP per-block path: quantize n must be a multiple of 16\n"); std::abort(); }
+		a.reset();
+		const size_t s = a.take(sizeof(int16_t) * npb), d = a.take(sizeof(int16_t) * npb), c = a.take(16);
+		std::memcpy(a.h<int16_t>(s), src + done, sizeof(int16_t) * npb);
+		Arena::check_call(hevcasm_hip_quantize_batch(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, offset, npb, 1, a.d<int>(c), a.stream), "quantize");
+		a.wait();
+		std::memcpy(dst + done, a.h<int16_t>(d), sizeof(int16_t) * npb);
+		cbf |= *a.h<int>(c);
+		done += npb;
+	}
+	return cbf;
+}
+
+void hevcasm_hip1_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n)
+{
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sp;
+	const size_t p = stage_plane(a, pred, stride_pred, n, n, 0, 0, &sp);
+	const ptrdiff_t sd = (n + 15) & ~15;
+	const size_t d = a.take((size_t)sd * n);
+	const size_t r = a.take(sizeof(int16_t) * n * n);
+	std::memcpy(a.h<int16_t>(r), res, sizeof(int16_t) * n * n);
+	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)p);
+	Arena::check_call(hevcasm_hip_quantize_reconstruct_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(r), n, 1, a.stream), "quantize_reconstruct");
+	a.wait();
+	for (int y = 0; y < n; ++y) std::memcpy(rec + y * stride_rec, a.h<uint8_t>(d) + y * sd, (size_t)n);
+}
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+// quant.hip -- inverse quantisation, forward quantisation and reconstruction for gfx950.
+//
+// Replaces hevcasm_quantize_inverse (reference quantize.h:57, C body quantize.c:53-62),
+// hevcasm_quantize (quantize.h:78, quantize.c:160-186) and hevcasm_quantize_reconstruct
+// (quantize.h:99, quantize.c:292-302) for whole batches.
+//
+// All three are streaming kernels, HBM-bound at 4 bytes per coefficient / 4 N^2 bytes per block:
+// every lane moves 16-byte vectors (8 coefficients), consecutive lanes touch consecutive
+// addresses, nothing is staged through LDS.  The quantiser's per-block coded-block flag is an OR
+// across the lanes that share a block, done with wave shuffles.
+
+#include "common.hpp"
+
+namespace hevc {
+
+__device__ __forceinline__ int sext_lo(uint32_t d) { return (int)(short)(d & 0xffff); }
+__device__ __forceinline__ int sext_hi(uint32_t d) { return (int)d >> 16; }
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+__device__ __forceinline__ int dequant1(int v, int scale, int round, int shift)
+{
+	return clip3(-32768, 32767, (v * scale + round) >> shift);
+}
+
+// quantize.c:53-62, 8 coefficients per lane per trip, grid-stride
+__global__ __launch_bounds__(kThreads) void quantize_inverse_kernel(
+	int16_t *__restrict__ dst, const int16_t *__restrict__ src, int scale, int shift, size_t n)
+{
+	const int round = 1 << (shift - 1);
+	const size_t n8 = n / 8;
+	const size_t step = (size_t)gridDim.x * kThreads;
+	for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n8; i += step)
+	{
+		Chunk<16> c;
+		c.load(reinterpret_cast<const uint8_t *>(src + 8 * i));
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+			c.d[k] = pack16(dequant1(sext_lo(c.d[k]), scale, round, shift), dequant1(sext_hi(c.d[k]), scale, round, shift));
+		c.store(reinterpret_cast<uint8_t *>(dst + 8 * i));
+	}
+	// tail (n not a multiple of 8): the reference's C body accepts any n
+	const size_t t = 8 * n8 + (size_t)blockIdx.x * kThreads + threadIdx.x;
+	if (t < n) dst[t] = (int16_t)dequant1(src[t], scale, round, shift);
+}
+
+__device__ __forceinline__ int quant1(int v, int scale, int round, int shift)
+{
+	// quantize.c:173-180: abs() in int, so -32768 becomes 32768
+	const int mag = ((v < 0 ? -v : v) * scale + round) >> shift;
+	return clip3(-32768, 32767, v < 0 ? -mag : mag);
+}
+
+// One block of NPB coefficients is shared by NPB / 8 lanes (NPB = 16, 64, 256) or by a whole
+// wave doing two trips (NPB = 1024).
+template <int NPB>
+__global__ __launch_bounds__(kThreads) void quantize_kernel(
+	int16_t *__restrict__ dst, const int16_t *__restrict__ src, int scale, int shift, int offset,
+	int *__restrict__ cbf, uint32_t n_blocks)
+{
+	constexpr int LPB = NPB / 8 < kWave ? NPB / 8 : kWave;  // lanes per block
+	constexpr int TRIPS = NPB / (8 * LPB);
+	const int round = offset << (shift - 16);
+
+	const size_t lane_global = (size_t)blockIdx.x * kThreads + threadIdx.x;
+	size_t blk = lane_global / LPB;
+	const uint32_t part = (uint32_t)(lane_global % LPB);
+	const bool live = blk < n_blocks;
+	if (!live) blk = n_blocks - 1;
+
+	int any = 0;
+#pragma unroll
+	for (int t = 0; t < TRIPS; ++t)
+	{
+		const size_t e = blk * NPB + (size_t)(t * LPB + part) * 8;
+		Chunk<16> c;
+		c.load(reinterpret_cast<const uint8_t *>(src + e));
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const int lo = quant1(sext_lo(c.d[k]), scale, round, shift);
+			const int hi = quant1(sext_hi(c.d[k]), scale, round, shift);
+			any |= lo | hi;
+			c.d[k] = pack16(lo, hi);
+		}
+		if (live) c.store(reinterpret_cast<uint8_t *>(dst + e));
+	}
+#pragma unroll
+	for (int d = LPB / 2; d >= 1; d >>= 1) any |= __shfl_xor(any, d, kWave);
+	if (live && part == 0) cbf[blk] = any;
+}
+
+// quantize.c:292-302.  A lane owns PX = min(8, N) horizontally adjacent pixels.
+template <int N>
+__global__ __launch_bounds__(kThreads) void reconstruct_kernel(
+	uint8_t *__restrict__ rec, ptrdiff_t stride_rec, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ res, uint32_t n_blocks)
+{
+	constexpr int PX = N < 8 ? N : 8;
+	constexpr int LPR = N / PX;          // lanes per row
+	constexpr int LPB = LPR * N;         // lanes per block
+	const size_t lane_global = (size_t)xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+	const size_t blk = lane_global / LPB;
+	if (blk >= n_blocks) return;
+	const uint32_t part = (uint32_t)(lane_global % LPB);
+	const uint32_t y = part / LPR, x = (part % LPR) * PX;
+
+	Chunk<PX> p;
+	Chunk<2 * PX> r;
+	p.load(pred + pred_off[blk] + y * stride_pred + x);
+	r.load(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
+	Chunk<PX> o;
+#pragma unroll
+	for (int k = 0; k < PX / 4; ++k)
+	{
+		const uint32_t pd = p.d[k];
+		const int v0 = clip3(0, 255, (int)(pd & 0xff) + sext_lo(r.d[2 * k]));
+		const int v1 = clip3(0, 255, (int)((pd >> 8) & 0xff) + sext_hi(r.d[2 * k]));
+		const int v2 = clip3(0, 255, (int)((pd >> 16) & 0xff) + sext_lo(r.d[2 * k + 1]));
+		const int v3 = clip3(0, 255, (int)(pd >> 24) + sext_hi(r.d[2 * k + 1]));
+		o.d[k] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+	}
+	o.store(rec + rec_off[blk] + y * stride_rec + x);
+}
+
+}  // namespace hevc
+
+using namespace hevc;
+
+extern "C" int hevcasm_hip_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, size_t n, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (shift < 1 || shift > 31) return set_error(HEVCASM_HIP_EINVAL, "shift out of range");
+	if (n == 0) return 0;
+	if (!dst || !src) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	// memory-bound: cap the grid at 8 workgroups per CU and grid-stride the rest
+	size_t wgs = (n / 8 + kThreads - 1) / kThreads;
+	if (wgs < 1) wgs = 1;
+	if (wgs > 256 * 8) wgs = 256 * 8;
+	hipLaunchKernelGGL(quantize_inverse_kernel, dim3((uint32_t)wgs), dim3(kThreads), 0, as_stream(stream), dst, src, scale, shift, n);
+	return launch_status("quantize_inverse_kernel");
+}
+
+extern "C" int hevcasm_hip_quantize_batch(int16_t *dst, const int16_t *src, int scale, int shift, int offset,
+		int n_per_block, size_t n_blocks, int *cbf, void *stream)
+{
+	if (int e = check_device()) return e;
+	// the reference asserts these (quantize.c:162-168)
+	if (scale >= 0x8000 || offset >= 0x8000 || shift < 16 || shift > 27) return set_error(HEVCASM_HIP_EINVAL, "scale/offset/shift outside the reference's domain");
+	if (n_blocks == 0) return 0;
+	if (n_blocks > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
+	if (!dst || !src || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t st = as_stream(stream);
+#define LAUNCH(NPB) { \
+		constexpr int lpb = NPB / 8 < kWave ? NPB / 8 : kWave; \
+		const uint32_t grid = ceil_div(n_blocks * lpb, kThreads); \
+		hipLaunchKernelGGL((quantize_kernel<NPB>), dim3(grid), dim3(kThreads), 0, st, dst, src, scale, shift, offset, cbf, (uint32_t)n_blocks); \
+		return launch_status("quantize_kernel"); }
+	switch (n_per_block)
+	{
+	case 16: LAUNCH(16)
+	case 64: LAUNCH(64)
+	case 256: LAUNCH(256)
+	case 1024: LAUNCH(1024)
+	}
+#undef LAUNCH
+	return set_error(HEVCASM_HIP_EINVAL, "n_per_block must be 16, 64, 256 or 1024");
+}
+
+extern "C" int hevcasm_hip_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+		const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res, int nCbS, size_t n_blocks, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_blocks == 0) return 0;
+	if (n_blocks > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
+	if (!rec || !pred || !rec_off || !pred_off || !res) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t st = as_stream(stream);
+#define LAUNCH(N) { \
+		constexpr int lpb = (N / (N < 8 ? N : 8)) * N; \
+		const uint32_t grid = ceil_div(n_blocks * lpb, kThreads); \
+		hipLaunchKernelGGL((reconstruct_kernel<N>), dim3(grid), dim3(kThreads), 0, st, rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, (uint32_t)n_blocks); \
+		return launch_status("reconstruct_kernel"); }
+	switch (nCbS)
+	{
+	case 4: LAUNCH(4)
+	case 8: LAUNCH(8)
+	case 16: LAUNCH(16)
+	case 32: LAUNCH(32)
+	}
+#undef LAUNCH
+	return set_error(HEVCASM_HIP_EINVAL, "nCbS must be 4, 8, 16 or 32");
+}

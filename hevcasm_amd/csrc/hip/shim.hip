@@ -1,0 +1,124 @@
+// shim.hip -- runtime side of the C-ABI: device discovery, error text, memory/stream helpers.
+//
+// No CPU fallback lives here or anywhere in the library: when no gfx950 device is usable every
+// kernel entry point returns HEVCASM_HIP_ENODEV.
+
+#include "common.hpp"
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+namespace hevc {
+
+static thread_local char g_error[256] = "";
+
+int set_error(int code, const char *what)
+{
+	std::snprintf(g_error, sizeof(g_error), "hevcasm_hip error %d: %s", code, what ? what : "");
+	return code;
+}
+
+static bool is_gfx950(int dev)
+{
+	hipDeviceProp_t p;
+	if (hipGetDeviceProperties(&p, dev) != hipSuccess) return false;
+	return std::strncmp(p.gcnArchName, "gfx950", 6) == 0;
+}
+
+// -1 unknown, else number of gfx950 devices
+static std::atomic<int> g_count{-1};
+
+static int count_devices()
+{
+	int c = g_count.load(std::memory_order_acquire);
+	if (c >= 0) return c;
+	int n = 0, good = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+	(void)hipGetLastError();
+	for (int d = 0; d < n; ++d) good += is_gfx950(d) ? 1 : 0;
+	g_count.store(good, std::memory_order_release);
+	return good;
+}
+
+int check_device()
+{
+	if (count_devices() <= 0) return set_error(HEVCASM_HIP_ENODEV, "no usable gfx950 (MI355X) device");
+	return 0;
+}
+
+}  // namespace hevc
+
+using namespace hevc;
+
+extern "C" int hevcasm_hip_device_count(void) { return count_devices(); }
+
+extern "C" int hevcasm_hip_available(void)
+{
+	if (count_devices() <= 0) return 0;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess) return 0;
+	return is_gfx950(dev) ? 1 : 0;
+}
+
+extern "C" int hevcasm_hip_set_device(int device)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipSetDevice(device));
+	return 0;
+}
+
+extern "C" const char *hevcasm_hip_last_error(void) { return g_error; }
+
+extern "C" int hevcasm_hip_malloc(void **dev_ptr, size_t bytes)
+{
+	if (int e = check_device()) return e;
+	if (!dev_ptr) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	HEVC_HIP_TRY(hipMalloc(dev_ptr, bytes ? bytes : 1));
+	return 0;
+}
+
+extern "C" int hevcasm_hip_free(void *dev_ptr)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipFree(dev_ptr));
+	return 0;
+}
+
+extern "C" int hevcasm_hip_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+	return 0;
+}
+
+extern "C" int hevcasm_hip_download(void *host_dst, const void *dev_src, size_t bytes, void *stream)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+	return 0;
+}
+
+extern "C" int hevcasm_hip_stream_create(void **stream)
+{
+	if (int e = check_device()) return e;
+	if (!stream) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t s;
+	HEVC_HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+	*stream = (void *)s;
+	return 0;
+}
+
+extern "C" int hevcasm_hip_stream_destroy(void *stream)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipStreamDestroy(as_stream(stream)));
+	return 0;
+}
+
+extern "C" int hevcasm_hip_stream_synchronize(void *stream)
+{
+	if (int e = check_device()) return e;
+	HEVC_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+	return 0;
+}

@@ -1,0 +1,300 @@
+/*
+ * cpath.c -- portable C implementations behind HEVCASM_C_REF / HEVCASM_C_OPT (see cpath.h).
+ *
+ * Written from the HEVC specification's definitions in direct form (2-D separable filters as
+ * two explicit passes; transforms as plain matrix products with the spec's intermediate
+ * clipping), i.e. deliberately a different formulation from both the reference's butterflies
+ * and the HIP kernels, so that the three agree only if all are right.  Semantics that are the
+ * reference's own choices rather than the spec's (what is clipped, what is truncated, shifts)
+ * are cited to /root/reference/src/lib.
+ */
+#include "cpath.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : v > hi ? hi : v; }
+
+/* ------------------------------------------------------------------------------ distortion */
+
+int hevcasm_c_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, uint32_t rect)
+{
+	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
+	int total = 0;
+	for (int y = 0; y < h; ++y, src += stride_src, ref += stride_ref)
+		for (int x = 0; x < w; ++x)
+		{
+			const int d = src[x] - ref[x];
+			total += d < 0 ? -d : d;
+		}
+	return total;
+}
+
+void hevcasm_c_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref[], ptrdiff_t stride_ref, int sad[], uint32_t rect)
+{
+	for (int i = 0; i < 4; ++i) sad[i] = hevcasm_c_sad(src, stride_src, ref[i], stride_ref, rect);
+}
+
+int hevcasm_c_ssd(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b, int w, int h)
+{
+	int total = 0;
+	for (int y = 0; y < h; ++y, a += stride_a, b += stride_b)
+		for (int x = 0; x < w; ++x)
+		{
+			const int d = a[x] - b[x];
+			total += d * d;
+		}
+	return total;
+}
+
+/* -------------------------------------------------------------------------- inter prediction */
+
+int hevcasm_c_filter_tap(int n, int frac, int k)
+{
+	/* HEVC spec tables 8-11 (luma) and 8-12 (chroma); reference pred_inter.c:53-83 */
+	static const signed char luma[4][8] = {
+		{ 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+		{ -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+	static const signed char chroma[8][4] = {
+		{ 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+		{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+	return n == 8 ? luma[frac][k] : chroma[frac][k];
+}
+
+/* 14-bit intermediate prediction of one reference: horizontal pass at full precision into
+ * int16, vertical pass >> 6 without rounding (reference pred_inter.c:506-527).  out has row
+ * stride 64.  Both passes run whatever the fractions (a zero fraction is the tap {64}). */
+static void predict_14bit(int taps, int16_t *out, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
+{
+	int16_t rows[(64 + 7) * 64];
+	const int before = taps / 2 - 1;
+	for (int y = 0; y < h + taps - 1; ++y)
+	{
+		const uint8_t *r = ref + (y - before) * stride_ref;
+		for (int x = 0; x < w; ++x)
+		{
+			int a = 0;
+			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, xFrac, k) * r[x + k - before];
+			rows[y * 64 + x] = (int16_t)a;
+		}
+	}
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			int a = 0;
+			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, yFrac, k) * rows[(y + k) * 64 + x];
+			out[y * 64 + x] = (int16_t)(a >> 6);
+		}
+}
+
+/* Uni-prediction = 14-bit prediction rounded back to 8 bits: (p + 32) >> 6, clipped.  This
+ * equals the reference's four special cases (copy, h: (sum+32)>>6, v: same, hv: (sum+2048)>>12;
+ * pred_inter.c:141-228) because the un-filtered direction contributes exactly a factor 64. */
+static void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
+{
+	const int before = taps / 2 - 1;
+	/* as predict_14bit, but all 12 fractional bits are kept until the single final rounding */
+	int16_t rows[(64 + 7) * 64];
+	for (int y = 0; y < h + taps - 1; ++y)
+	{
+		const uint8_t *r = ref + (y - before) * stride_ref;
+		for (int x = 0; x < w; ++x)
+		{
+			int a = 0;
+			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, xFrac, k) * r[x + k - before];
+			rows[y * 64 + x] = (int16_t)a;
+		}
+	}
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			int a = 0;
+			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, yFrac, k) * rows[(y + k) * 64 + x];
+			dst[y * stride_dst + x] = (uint8_t)clampi((a + 2048) >> 12, 0, 255);
+		}
+}
+
+void hevcasm_c_pred_uni_8tap(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int nPbW, int nPbH, int xFrac, int yFrac)
+{
+	pred_uni(8, dst, stride_dst, ref, stride_ref, nPbW, nPbH, xFrac, yFrac);
+}
+
+void hevcasm_c_pred_uni_4tap(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int nPbW, int nPbH, int xFrac, int yFrac)
+{
+	pred_uni(4, dst, stride_dst, ref, stride_ref, nPbW, nPbH, xFrac, yFrac);
+}
+
+static void pred_bi(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
+{
+	int16_t p0[64 * 64], p1[64 * 64];
+	predict_14bit(taps, p0, ref0, stride_ref, w, h, xFrac0, yFrac0);
+	predict_14bit(taps, p1, ref1, stride_ref, w, h, xFrac1, yFrac1);
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+			dst[y * stride_dst + x] = (uint8_t)clampi((p0[y * 64 + x] + p1[y * 64 + x] + 64) >> 7, 0, 255); /* pred_inter.c:490-501 */
+}
+
+void hevcasm_c_pred_bi_8tap(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref, int nPbW, int nPbH, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
+{
+	pred_bi(8, dst, stride_dst, ref0, ref1, stride_ref, nPbW, nPbH, xFrac0, yFrac0, xFrac1, yFrac1);
+}
+
+void hevcasm_c_pred_bi_4tap(uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref, int nPbW, int nPbH, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
+{
+	pred_bi(4, dst, stride_dst, ref0, ref1, stride_ref, nPbW, nPbH, xFrac0, yFrac0, xFrac1, yFrac1);
+}
+
+/* --------------------------------------------------------------------------------- transforms */
+
+/* 64 * sqrt(2) * cos(m * pi / 64) as HEVC rounds it, m = 0..32 (m = 0 is only used for row 0,
+ * where the spec has 64). */
+static const signed char cos_table[33] = {
+	64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+	61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+
+static signed char matrix32[32][32];
+static const signed char dst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+
+__attribute__((constructor)) static void build_matrix(void)
+{
+	for (int k = 0; k < 32; ++k)
+		for (int i = 0; i < 32; ++i)
+		{
+			int m = (k * (2 * i + 1)) % 128;
+			if (m > 64) m = 128 - m;
+			matrix32[k][i] = (signed char)(k == 0 ? 64 : (m > 32 ? -cos_table[64 - m] : cos_table[m]));
+		}
+}
+
+int hevcasm_c_transform_coefficient(int n, int k, int i)
+{
+	return matrix32[k * (32 / n)][i];
+}
+
+/* n x n coefficient matrix as ints, row k = basis function k */
+static void load_matrix(int trType, int n, int m[32][32])
+{
+	for (int k = 0; k < n; ++k)
+		for (int i = 0; i < n; ++i)
+			m[k][i] = trType ? dst4[k][i] : matrix32[k * (32 / n)][i];
+}
+
+/* Inverse: first stage over columns (shift 7), second over rows (shift 12), each clipped to
+ * int16 (reference residual_decode.c:113-116 and the drivers :371-413); then add to the
+ * prediction, narrowing the sum to int16 before the 8-bit clip as the reference does (:350-368).
+ * Loops are ordered so that the innermost one runs over contiguous accumulators. */
+static void inverse_add(int trType, int n, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *c)
+{
+	int m[32][32];
+	int16_t e[32 * 32];
+	int acc[32];
+	load_matrix(trType, n, m);
+
+	/* e[y][x] = clip16((sum_k m[k][y] * c[k][x] + 64) >> 7) */
+	for (int y = 0; y < n; ++y)
+	{
+		for (int x = 0; x < n; ++x) acc[x] = 64;
+		for (int k = 0; k < n; ++k)
+		{
+			const int mk = m[k][y];
+			for (int x = 0; x < n; ++x) acc[x] += mk * c[k * n + x];
+		}
+		for (int x = 0; x < n; ++x) e[y * n + x] = (int16_t)clampi(acc[x] >> 7, -32768, 32767);
+	}
+	/* r[y][x] = clip16((sum_k m[k][x] * e[y][k] + 2048) >> 12) */
+	for (int y = 0; y < n; ++y)
+	{
+		for (int x = 0; x < n; ++x) acc[x] = 2048;
+		for (int k = 0; k < n; ++k)
+		{
+			const int ek = e[y * n + k];
+			for (int x = 0; x < n; ++x) acc[x] += m[k][x] * ek;
+		}
+		for (int x = 0; x < n; ++x)
+		{
+			const int r = clampi(acc[x] >> 12, -32768, 32767);
+			const int16_t s = (int16_t)(pred[y * stride_pred + x] + r);
+			dst[y * stride_dst + x] = (uint8_t)clampi(s, 0, 255);
+		}
+	}
+}
+
+void hevcasm_c_idst_4(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse_add(1, 4, d, sd, p, sp, c); }
+void hevcasm_c_idct_4(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse_add(0, 4, d, sd, p, sp, c); }
+void hevcasm_c_idct_8(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse_add(0, 8, d, sd, p, sp, c); }
+void hevcasm_c_idct_16(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse_add(0, 16, d, sd, p, sp, c); }
+void hevcasm_c_idct_32(uint8_t *d, ptrdiff_t sd, const uint8_t *p, ptrdiff_t sp, const int16_t *c) { inverse_add(0, 32, d, sd, p, sp, c); }
+
+/* Forward: first stage along rows (shift log2(n) - 1), second along columns (shift log2(n) + 6);
+ * results are stored to int16 by truncation, never clipped (reference residual_decode.c:631-634,
+ * drivers :855-892). */
+static void forward(int trType, int n, int log2n, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride)
+{
+	int m[32][32], mt[32][32];
+	int16_t t[32 * 32];
+	int acc[32];
+	const int s1 = log2n - 1, s2 = log2n + 6;
+	load_matrix(trType, n, m);
+	for (int k = 0; k < n; ++k)
+		for (int i = 0; i < n; ++i) mt[i][k] = m[k][i];
+
+	/* t[y][k] = (sum_x m[k][x] * src[y][x] + round) >> s1 */
+	for (int y = 0; y < n; ++y)
+	{
+		for (int k = 0; k < n; ++k) acc[k] = 1 << (s1 - 1);
+		for (int x = 0; x < n; ++x)
+		{
+			const int sx = src[y * src_stride + x];
+			for (int k = 0; k < n; ++k) acc[k] += mt[x][k] * sx;
+		}
+		for (int k = 0; k < n; ++k) t[y * n + k] = (int16_t)(acc[k] >> s1);
+	}
+	/* coeffs[k][x] = (sum_y m[k][y] * t[y][x] + round) >> s2 */
+	for (int k = 0; k < n; ++k)
+	{
+		for (int x = 0; x < n; ++x) acc[x] = 1 << (s2 - 1);
+		for (int y = 0; y < n; ++y)
+		{
+			const int mk = m[k][y];
+			for (int x = 0; x < n; ++x) acc[x] += mk * t[y * n + x];
+		}
+		for (int x = 0; x < n; ++x) coeffs[k * n + x] = (int16_t)(acc[x] >> s2);
+	}
+}
+
+void hevcasm_c_dst_4(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(1, 4, 2, c, s, st); }
+void hevcasm_c_dct_4(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 4, 2, c, s, st); }
+void hevcasm_c_dct_8(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 8, 3, c, s, st); }
+void hevcasm_c_dct_16(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 16, 4, c, s, st); }
+void hevcasm_c_dct_32(int16_t *c, const int16_t *s, ptrdiff_t st) { forward(0, 32, 5, c, s, st); }
+
+/* ------------------------------------------------------------------------------ quantisation */
+
+void hevcasm_c_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
+{
+	const int round = 1 << (shift - 1);
+	for (int i = 0; i < n; ++i) dst[i] = (int16_t)clampi((src[i] * scale + round) >> shift, -32768, 32767);
+}
+
+int hevcasm_c_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
+{
+	const int round = offset << (shift - 16);
+	int any = 0;
+	for (int i = 0; i < n; ++i)
+	{
+		const int v = src[i];
+		const int mag = ((v < 0 ? -v : v) * scale + round) >> shift;
+		const int q = clampi(v < 0 ? -mag : mag, -32768, 32767);
+		any |= q;
+		dst[i] = (int16_t)q;
+	}
+	return any;
+}
+
+void hevcasm_c_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n)
+{
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x)
+			rec[y * stride_rec + x] = (uint8_t)clampi(pred[y * stride_pred + x] + res[y * n + x], 0, 255);
+}

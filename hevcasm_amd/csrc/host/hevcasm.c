@@ -1,0 +1,92 @@
+/*
+ * hevcasm.c -- library entry points: instruction-set discovery and the self-test main.
+ *
+ * Counterpart of the reference's src/lib/hevcasm.c.  hevcasm_instruction_set_support()
+ * (:99-138 there) additionally reports HEVCASM_HIP when the HIP side finds a gfx950 device.
+ * hevcasm_main() (:152-186 there) runs the ten hot-path self-tests in the reference's order;
+ * the reference's intra-DC and Hadamard tests belong to families this library does not
+ * implement (out of scope) and are not run.
+ */
+#include "hevcasm.h"
+#include "sad.h"
+#include "ssd.h"
+#include "pred_inter.h"
+#include "residual_decode.h"
+#include "quantize.h"
+#include "hevcasm_hip.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+#if defined(__x86_64__) || defined(__i386__)
+#include <cpuid.h>
+
+static uint64_t read_xcr0(void)
+{
+	uint32_t lo, hi;
+	__asm__ __volatile__("xgetbv" : "=a"(lo), "=d"(hi) : "c"(0));
+	return ((uint64_t)hi << 32) | lo;
+}
+
+static int x86_mask(void)
+{
+	unsigned a, b, c, d;
+	int mask = 0;
+	if (!__get_cpuid(1, &a, &b, &c, &d)) return 0;
+	if (d & (1u << 26)) mask |= HEVCASM_SSE2;
+	if (c & (1u << 0)) mask |= HEVCASM_SSE3;
+	if (c & (1u << 9)) mask |= HEVCASM_SSSE3;
+	if (c & (1u << 19)) mask |= HEVCASM_SSE41;
+	if (c & (1u << 20)) mask |= HEVCASM_SSE42;
+	/* AVX needs the CPU flag, OSXSAVE, and the OS saving XMM+YMM state */
+	if ((c & (1u << 28)) && (c & (1u << 27)) && (read_xcr0() & 6) == 6)
+	{
+		mask |= HEVCASM_AVX;
+		if (__get_cpuid_count(7, 0, &a, &b, &c, &d) && (b & (1u << 5))) mask |= HEVCASM_AVX2;
+	}
+	return mask;
+}
+#else
+static int x86_mask(void) { return 0; }
+#endif
+
+hevcasm_instruction_set hevcasm_instruction_set_support(void)
+{
+	int mask = HEVCASM_C_REF | HEVCASM_C_OPT | x86_mask();
+	const char *off = getenv("HEVCASM_DISABLE_HIP");
+	if (!(off && *off && strcmp(off, "0")) && hevcasm_hip_available()) mask |= HEVCASM_HIP;
+	return (hevcasm_instruction_set)mask;
+}
+
+void hevcasm_print_instruction_set_support(FILE *f, hevcasm_instruction_set mask)
+{
+	fprintf(f, "HEVCasm processor instruction set support:\n");
+#define X(value, name, description) fprintf(f, "[%c] " #name " (" description ")\n", (mask & (1 << value)) ? 'x' : ' ');
+	HEVCASM_INSTRUCTION_SET_XMACRO
+#undef X
+	fprintf(f, "\n");
+}
+
+int hevcasm_main(int argc, const char *argv[])
+{
+	(void)argc; (void)argv;
+	const hevcasm_instruction_set mask = hevcasm_instruction_set_support();
+
+	printf("HEVCasm self test\n\n");
+	hevcasm_print_instruction_set_support(stdout, mask);
+
+	int error_count = 0;
+	hevcasm_test_sad_multiref(&error_count, mask);
+	hevcasm_test_sad(&error_count, mask);
+	hevcasm_test_ssd(&error_count, mask);
+	hevcasm_test_quantize_inverse(&error_count, mask);
+	hevcasm_test_quantize(&error_count, mask);
+	hevcasm_test_quantize_reconstruct(&error_count, mask);
+	hevcasm_test_pred_uni(&error_count, mask);
+	hevcasm_test_pred_bi(&error_count, mask);
+	hevcasm_test_inverse_transform_add(&error_count, mask);
+	hevcasm_test_transform(&error_count, mask);
+
+	printf("\nHEVCasm self test: %d errors\n", error_count);
+	return error_count;
+}

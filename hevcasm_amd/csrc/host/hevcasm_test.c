@@ -1,0 +1,109 @@
+/*
+ * hevcasm_test.c -- differential self-test / timing harness (host C).
+ *
+ * Behaviour follows the reference's src/lib/hevcasm_test.c: hevcasm_test() (:110-137) binds the
+ * reference closure to HEVCASM_C_REF, runs it once, then for every other instruction-set bit
+ * present in `mask` binds the test closure, times it (hevcasm_count_average_cycles, :40-107) and
+ * compares.  Output grammar is the reference's: " NAME:ticks" for the first column,
+ * " NAME:ticks(xSPEEDUP)" after it, "-MISMATCH" appended on disagreement, newline per test.
+ *
+ * Differences, both deliberate:
+ *  - the instruction-set loop is an explicit loop over HEVCASM_INSTRUCTION_SET_COUNT bits (the
+ *    reference shifts a signed enum until it overflows, :126);
+ *  - a per-block call through the HIP column costs a kernel launch, so that column is timed
+ *    over at most HEVCASM_TEST_HIP_MAX_CALLS calls instead of `iterations`.
+ */
+#include "hevcasm_test.h"
+
+#define HEVCASM_TEST_HIP_MAX_CALLS 400
+
+int hevcasm_count_average_cycles(
+	void *boundRef, void *boundTest,
+	hevcasm_bound_invoke *f,
+	hevcasm_bound_mismatch *m,
+	double *first_result,
+	hevcasm_instruction_set set,
+	int iterations)
+{
+	/* Four calls per timestamp pair.  After a 100-sample warm-up a sample is accepted when it
+	 * lies within 7/8 .. 8/7 of the running mean; a much faster one restarts the statistics,
+	 * a much slower one (an interrupt, a migration) only restarts the warm-up. */
+	const int calls_per_sample = 4;
+	const int warmup_samples = (set == HEVCASM_HIP) ? 4 : 100;
+	hevcasm_timestamp total = 0;
+	int calls = 0, cooling = warmup_samples;
+
+	if (set == HEVCASM_HIP && iterations > HEVCASM_TEST_HIP_MAX_CALLS) iterations = HEVCASM_TEST_HIP_MAX_CALLS;
+
+	while (calls < iterations)
+	{
+		const hevcasm_timestamp t0 = hevcasm_get_timestamp();
+		f(boundTest, calls_per_sample);
+		const hevcasm_timestamp dt = hevcasm_get_timestamp() - t0;
+
+		if (cooling)
+		{
+			--cooling;
+			continue;
+		}
+		if (8 * dt * calls < 7 * calls_per_sample * total)
+		{
+			total = 0;
+			calls = 0;
+			cooling = warmup_samples;
+		}
+		else if (7 * dt * calls <= 8 * calls_per_sample * total)
+		{
+			calls += calls_per_sample;
+			total += dt;
+		}
+		else
+		{
+			cooling = warmup_samples;
+		}
+	}
+
+	const int average = (int)((total + calls / 2) / calls);
+	printf(" %s:%d", hevcasm_instruction_set_as_text(set), average);
+	if (*first_result != 0.0)
+		printf("(x%.2f)", *first_result / average);
+	else
+		*first_result = average;
+
+	if (boundRef)
+	{
+		f(boundRef, 1);
+		if (m(boundRef, boundTest))
+		{
+			printf("-MISMATCH");
+			return 1;
+		}
+	}
+	return 0;
+}
+
+int hevcasm_test(
+	void *ref,
+	void *test,
+	hevcasm_bound_get *get,
+	hevcasm_bound_invoke *invoke,
+	hevcasm_bound_mismatch *mismatch,
+	hevcasm_instruction_set mask,
+	int iterations)
+{
+	int errors = 0;
+
+	if (!get(ref, HEVCASM_C_REF)) return 0;
+	invoke(ref, 1);
+
+	double first_result = 0.0;
+	for (int bit = C_OPT; bit < HEVCASM_INSTRUCTION_SET_COUNT; ++bit)
+	{
+		const hevcasm_instruction_set set = (hevcasm_instruction_set)(1 << bit);
+		if (get(test, (hevcasm_instruction_set)(set & mask)))
+			errors += hevcasm_count_average_cycles(ref, test, invoke, mismatch, &first_result, set, iterations);
+	}
+	printf("\n");
+	fflush(stdout);
+	return errors;
+}

@@ -1,0 +1,166 @@
+/*
+ * hevcasm_hip.h -- C-ABI of the batched MI355X (gfx950) kernels: the drop-in boundary.
+ *
+ * The reference library has no process or device boundary: a codec calls one function pointer
+ * per block.  One 16x16 SAD moves 516 bytes, far below a kernel launch, so the
+ * GPU path is exposed as one `*_batch` entry point per reference function type.  Each takes
+ * the reference function's arguments with the per-block pointers replaced by
+ *
+ *     one base pointer per plane  +  a device array of per-block u32 offsets from that base
+ *
+ * and processes `n_blocks` independent blocks in one launch.  Everything else (strides, rect
+ * packing, fraction and shift semantics, rounding, clipping) is the reference's, and results
+ * are bit-identical to the reference's C path (HEVCASM_C_REF).
+ *
+ * Conventions
+ *  - `extern "C"`, plain pointers and sizes only.
+ *  - Every data pointer is a DEVICE pointer (hipMalloc or the helpers below); the caller keeps
+ *    frames resident in HBM across calls.  Offsets are in bytes for uint8 planes and in
+ *    elements for int16 planes; they must address memory inside the plane including the
+ *    filter margins.  A plane larger than 4 GiB is handled by splitting the batch and
+ *    advancing the base pointer.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
+ *    asynchronous: they return once the launch is queued.
+ *  - Return value: 0 on success; HEVCASM_HIP_EINVAL for arguments outside the domain the
+ *    reference function accepts (same conditions as the reference's asserts / NULL table
+ *    entries); otherwise the hipError_t of the failing runtime call.  There is no CPU
+ *    fallback: without a usable gfx950 device every entry point fails with
+ *    HEVCASM_HIP_ENODEV.  hevcasm_hip_last_error() returns text for the calling thread's last
+ *    failure.
+ *  - Thread safety: entry points may be called concurrently from several host threads (use one
+ *    stream per thread to overlap).
+ */
+#ifndef INCLUDED_hevcasm_hip_h
+#define INCLUDED_hevcasm_hip_h
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEVCASM_HIP_EINVAL (-1)
+#define HEVCASM_HIP_ENODEV (-2)
+
+/* ---- runtime ------------------------------------------------------------------------- */
+
+/* Number of visible gfx950 devices (0 when the HIP runtime finds none). */
+int hevcasm_hip_device_count(void);
+/* 1 when the current device is a usable gfx950, else 0.  Never throws, never falls back. */
+int hevcasm_hip_available(void);
+/* Select the device used by subsequent calls of this thread (hipSetDevice). */
+int hevcasm_hip_set_device(int device);
+const char *hevcasm_hip_last_error(void);
+
+/* Thin device-memory helpers so that a C codec needs no HIP headers. */
+int hevcasm_hip_malloc(void **dev_ptr, size_t bytes);
+int hevcasm_hip_free(void *dev_ptr);
+int hevcasm_hip_upload(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int hevcasm_hip_download(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int hevcasm_hip_stream_create(void **stream);
+int hevcasm_hip_stream_destroy(void *stream);
+int hevcasm_hip_stream_synchronize(void *stream);
+
+/* ---- SAD / SSD ------------------------------------------------------------------------ */
+
+/* Batched hevcasm_sad (sad.h; reference sad.h:50, C body sad.c:47-60).
+ * sad[i] = SAD(src + src_off[i], ref + ref_off[i]); width, height multiples of 4 in 4..64. */
+int hevcasm_hip_sad_batch(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad,
+	uint32_t rect, size_t n_blocks, void *stream);
+
+/* Batched hevcasm_sad_multiref, 4 ways (reference sad.h:95, C body sad.c:101-121).
+ * ref_off and sad hold 4 consecutive entries per block; all four candidates share `ref`
+ * and stride_ref, as the reference's ref[] pointers share stride_ref. */
+int hevcasm_hip_sad_multiref_batch(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad,
+	uint32_t rect, size_t n_blocks, void *stream);
+
+/* Batched hevcasm_ssd (reference ssd.h:53, C body ssd.c:43-55); w, h multiples of 4 in 4..64
+ * (the reference's table holds the square sizes 4..64, its C body takes any w x h). */
+int hevcasm_hip_ssd_batch(
+	const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB,
+	const uint32_t *offA, const uint32_t *offB, int *ssd,
+	int w, int h, size_t n_blocks, void *stream);
+
+/* ---- inter prediction ----------------------------------------------------------------- */
+
+/* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).
+ * taps = 8 (luma, fractions 0..3, nPbW/nPbH <= 64) or 4 (chroma, fractions 0..7, <= 32).
+ * frac[i] = xFrac | (yFrac << 4).  ref + ref_off[i] is the integer-pel top-left sample.
+ * Writes exactly nPbW x nPbH bytes per block. */
+int hevcasm_hip_pred_uni_8to8_batch(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
+
+/* Batched hevcasm_pred_bi_8to8 (reference pred_inter.h:76; C body pred_inter.c:490-530). */
+int hevcasm_hip_pred_bi_8to8_batch(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
+	const uint8_t *frac0, const uint8_t *frac1,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
+
+/* ---- transforms ------------------------------------------------------------------------ */
+
+/* Batched hevcasm_inverse_transform_add (reference residual_decode.h:54; C path
+ * residual_decode.c:69-413).  coeffs: n_blocks consecutive N x N int16 blocks (N = 1 <<
+ * log2TrafoSize, 2..5); trType 1 = 4x4 DST.  dst may equal pred (in-place reconstruction). */
+int hevcasm_hip_inverse_transform_add_batch(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *coeffs,
+	int trType, int log2TrafoSize, size_t n_blocks, void *stream);
+
+/* Fused hevcasm_quantize_inverse -> hevcasm_inverse_transform_add:
+ * levels are dequantised with (scale, shift) exactly as quantize.c:53-62, including the clip
+ * to int16, then transformed and added; the dequantised coefficients never touch HBM. */
+int hevcasm_hip_dequant_inverse_transform_add_batch(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *levels,
+	int scale, int shift,
+	int trType, int log2TrafoSize, size_t n_blocks, void *stream);
+
+/* Batched hevcasm_transform (reference residual_decode.h:82; C path residual_decode.c:592-892).
+ * src_off in int16 elements; coeffs: n_blocks consecutive N x N blocks. */
+int hevcasm_hip_transform_batch(
+	int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride, const uint32_t *src_off,
+	int trType, int log2TrafoSize, size_t n_blocks, void *stream);
+
+/* ---- quantisation ----------------------------------------------------------------------- */
+
+/* hevcasm_quantize_inverse over n coefficients (reference quantize.h:57; quantize.c:53-62).
+ * Already a flat array operation: a batch of blocks is one call with n = blocks * N * N. */
+int hevcasm_hip_quantize_inverse(
+	int16_t *dst, const int16_t *src, int scale, int shift, size_t n, void *stream);
+
+/* Batched hevcasm_quantize (reference quantize.h:78; quantize.c:160-186): n_blocks consecutive
+ * blocks of n_per_block coefficients (16, 64, 256 or 1024); cbf[i] = OR of block i's levels. */
+int hevcasm_hip_quantize_batch(
+	int16_t *dst, const int16_t *src, int scale, int shift, int offset,
+	int n_per_block, size_t n_blocks, int *cbf, void *stream);
+
+/* Batched hevcasm_quantize_reconstruct (reference quantize.h:99; quantize.c:292-302):
+ * res holds n_blocks consecutive nCbS x nCbS int16 blocks (nCbS = 4, 8, 16 or 32). */
+int hevcasm_hip_quantize_reconstruct_batch(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res,
+	int nCbS, size_t n_blocks, void *stream);
+
+/* ---- full-search motion estimation (composition of hevcasm_sad) -- */
+
+/* For each block: SAD at every displacement (dx, dy) in [-range, range]^2 around
+ * ref + ref_off[i]; result[3i..3i+2] = { dx, dy, cost } of the minimum, ties resolved to the
+ * first candidate in raster order of (dy, dx). */
+int hevcasm_hip_me_full_search_batch(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	uint32_t rect, int range, size_t n_blocks, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,489 @@
+/*
+ * hevc_oracle.c -- CPU restatement of the reference's C path (HEVCASM_C_REF).
+ *
+ * TEST INFRASTRUCTURE ONLY (see hevc_oracle.h).  Plain C99, one thread per
+ * call; the batch drivers may use OpenMP when built with -fopenmp.
+ *
+ * Parity: pinned against oracle/_ref/refdrv (the reference's own C files) and
+ * tests/golden/.  Citations are file:line into /root/reference/src/lib.
+ */
+#include "hevc_oracle.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+static int clip3(int lo, int hi, int v)
+{
+	return v < lo ? lo : (v > hi ? hi : v);
+}
+
+/* ------------------------------------------------------------------ SAD / SSD */
+
+/* sad.c:47-60: rect = (width << 8) | height (hevcasm.h:156) */
+int orc_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, uint32_t rect)
+{
+	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
+	int acc = 0;
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+			acc += abs((int)src[x + y * stride_src] - (int)ref[x + y * stride_ref]);
+	return acc;
+}
+
+/* sad.c:101-121 */
+void orc_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref[], ptrdiff_t stride_ref, int sad[], uint32_t rect)
+{
+	for (int way = 0; way < 4; ++way)
+		sad[way] = orc_sad(src, stride_src, ref[way], stride_ref, rect);
+}
+
+/* ssd.c:43-55 */
+int orc_ssd(const uint8_t *pA, ptrdiff_t strideA, const uint8_t *pB, ptrdiff_t strideB, int w, int h)
+{
+	int acc = 0;
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			const int d = (int)pA[x + y * strideA] - (int)pB[x + y * strideB];
+			acc += d * d;
+		}
+	return acc;
+}
+
+/* ------------------------------------------------------------ inter prediction */
+
+/* pred_inter.c:53-83: HEVC luma (8-tap, quarter-pel) and chroma (4-tap, eighth-pel) filters */
+int orc_pred_coefficient(int n, int frac, int k)
+{
+	static const int8_t luma[4][8] = {
+		{  0, 0,   0, 64,  0,   0, 0,  0 },
+		{ -1, 4, -10, 58, 17,  -5, 1,  0 },
+		{ -1, 4, -11, 40, 40, -11, 4, -1 },
+		{  0, 1,  -5, 17, 58, -10, 4, -1 } };
+	static const int8_t chroma[8][4] = {
+		{  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+		{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+	return n == 8 ? luma[frac][k] : chroma[frac][k];
+}
+
+/* pred_inter.c:90-138: one 1-D FIR pass.  src/dst element size 1 or 2 bytes; stride_tap = 1
+ * (horizontal) or the row stride (vertical).  16-bit stores truncate (plain assignment, :124),
+ * 8-bit stores clip to [0,255] (:128). */
+static void fir_pass(void *dst, int dst_bytes, ptrdiff_t stride_dst,
+		const void *src, int src_bytes, ptrdiff_t stride_src,
+		int w, int h, ptrdiff_t stride_tap, int n, int frac, int shift, int add)
+{
+	int16_t *d16 = (int16_t *)dst;
+	uint8_t *d8 = (uint8_t *)dst;
+	const int16_t *s16 = (const int16_t *)src;
+	const uint8_t *s8 = (const uint8_t *)src;
+
+	for (int y = 0; y < h; ++y)
+	{
+		for (int x = 0; x < w; ++x)
+		{
+			int a = add << shift >> 1; /* :106 */
+			for (int k = 0; k < n; ++k)
+			{
+				const ptrdiff_t o = x + (k - n / 2 + 1) * stride_tap; /* :110 */
+				const int s = src_bytes == 2 ? s16[o] : s8[o];
+				a += orc_pred_coefficient(n, frac, k) * s;
+			}
+			a >>= shift;
+			if (dst_bytes == 2) d16[x] = (int16_t)a;
+			else d8[x] = (uint8_t)clip3(0, 255, a);
+		}
+		d16 += stride_dst; d8 += stride_dst;
+		s16 += stride_src; s8 += stride_src;
+	}
+}
+
+/* Selector C branch pred_inter.c:234-283 picks copy / h / v / hv by (xFrac != 0, yFrac != 0);
+ * bodies: copy :141-151, h :154-159 / :203-208, v :162-167 / :211-216, hv :170-179 / :219-228. */
+void orc_pred_uni_8to8(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
+		int w, int h, int xFrac, int yFrac)
+{
+	if (!xFrac && !yFrac)
+	{
+		for (int y = 0; y < h; ++y) memcpy(dst + y * stride_dst, ref + y * stride_ref, (size_t)w);
+	}
+	else if (xFrac && !yFrac)
+	{
+		fir_pass(dst, 1, stride_dst, ref, 1, stride_ref, w, h, 1, taps, xFrac, 6, 1);
+	}
+	else if (!xFrac && yFrac)
+	{
+		fir_pass(dst, 1, stride_dst, ref, 1, stride_ref, w, h, stride_ref, taps, yFrac, 6, 1);
+	}
+	else
+	{
+		/* intermediate: (h + taps - 1) rows; row stride 64 (luma :172) or 32 (chroma :221) */
+		const int is = taps == 8 ? 64 : 32;
+		const int lead = taps / 2 - 1;
+		int16_t tmp[(64 + 7) * 64];
+		fir_pass(tmp, 2, is, ref - lead * stride_ref, 1, stride_ref, w, h + taps - 1, 1, taps, xFrac, 0, 0);
+		fir_pass(dst, 1, stride_dst, tmp + lead * is, 2, is, w, h, is, taps, yFrac, 12, 1);
+	}
+}
+
+/* pred_inter.c:504-530 (pipeline) + :490-501 (mean).  Runs the full H (shift 0) -> V (shift 6,
+ * no rounding) pipeline for each reference whatever the fractions, then (a + b + 64) >> 7, clip. */
+void orc_pred_bi_8to8(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
+{
+	static _Thread_local int16_t t[4][(64 + 7) * 64];
+	const int lead = taps / 2 - 1;
+
+	fir_pass(t[2], 2, 64, ref0 - lead * stride_ref, 1, stride_ref, w, h + taps - 1, 1, taps, xFrac0, 0, 0);
+	fir_pass(t[0], 2, 64, t[2] + lead * 64, 2, 64, w, h, 64, taps, yFrac0, 6, 0);
+	fir_pass(t[3], 2, 64, ref1 - lead * stride_ref, 1, stride_ref, w, h + taps - 1, 1, taps, xFrac1, 0, 0);
+	fir_pass(t[1], 2, 64, t[3] + lead * 64, 2, 64, w, h, 64, taps, yFrac1, 6, 0);
+
+	for (int y = 0; y < h; ++y)
+		for (int x = 0; x < w; ++x)
+		{
+			const int v = ((int)t[0][x + y * 64] + (int)t[1][x + y * 64] + (1 << 6)) >> 7;
+			dst[x + y * stride_dst] = (uint8_t)clip3(0, 255, v);
+		}
+}
+
+/* ------------------------------------------------------------------ transforms */
+
+/* The HEVC core transform matrix.  The reference spells it out as literals
+ * (32x32 at residual_decode.c:254-288 and :793-827; 16/8/4 at :182-200, :132-142, :99-105, which
+ * are the even rows of the next size up, truncated).  Here it is generated from the 31 distinct
+ * magnitudes: entry (k, i) of the 32-point matrix is +-mag[|angle|] with angle = k(2i+1) folded
+ * into a quarter period.  Parity tests against refdrv prove the table. */
+static const int8_t dct_mag[33] = {
+	64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
+	61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
+
+static int dct32(int k, int i)
+{
+	if (k == 0) return 64;
+	int a = (k * (2 * i + 1)) & 127;  /* angle in units of pi/64, period 128 */
+	if (a > 64) a = 128 - a;          /* cos is even about pi */
+	return a > 32 ? -dct_mag[64 - a] : dct_mag[a];
+}
+
+int orc_dct_matrix(int n, int k, int i)
+{
+	return dct32(k * (32 / n), i);
+}
+
+/* Inverse N-point transform of one column by even/odd decomposition, the structure of
+ * residual_decode.c:91-121 (4), :124-171 (8), :174-243 (16), :246-347 (32):
+ * out[k] = E[k] + O[k], out[N-1-k] = E[k] - O[k], E = inverse (N/2)-point of the even rows.
+ * 32-bit accumulation, no intermediate rounding. */
+static void inv_even_odd(int n, const int *in /* n coefficients */, int *out)
+{
+	if (n == 2)
+	{
+		/* rows 0 and N/2 of any size: 64, 64 / 64, -64 (e.g. :227-229 EEEE) */
+		out[0] = 64 * in[0] + 64 * in[1];
+		out[1] = 64 * in[0] - 64 * in[1];
+		return;
+	}
+	int even[16] = { 0 }, E[16] = { 0 }, O[16] = { 0 };
+	const int half = n / 2;
+	for (int k = 0; k < half; ++k) even[k] = in[2 * k];
+	inv_even_odd(half, even, E);
+	for (int k = 0; k < half; ++k)
+	{
+		int o = 0;
+		for (int r = 1; r < n; r += 2) o += orc_dct_matrix(n, r, k) * in[r]; /* e.g. :290-297 */
+		O[k] = o;
+	}
+	for (int k = 0; k < half; ++k)
+	{
+		out[k] = E[k] + O[k];
+		out[n - 1 - k] = E[k] - O[k];
+	}
+}
+
+/* One inverse pass over all columns: result clipped to int16 and stored transposed
+ * (dst row j = transform of src column j), e.g. :113-116, :341-342. */
+static void inv_pass_dct(int n, int16_t *dst, const int16_t *src, int shift)
+{
+	const int add = 1 << (shift - 1);
+	for (int j = 0; j < n; ++j)
+	{
+		int in[32], out[32];
+		for (int k = 0; k < n; ++k) in[k] = src[k * n + j];
+		inv_even_odd(n, in, out);
+		for (int k = 0; k < n; ++k) dst[j * n + k] = (int16_t)clip3(-32768, 32767, (out[k] + add) >> shift);
+	}
+}
+
+/* residual_decode.c:69-88: 4x4 inverse DST-VII pass */
+static void inv_pass_dst(int16_t *dst, const int16_t *src, int shift)
+{
+	const int add = 1 << (shift - 1);
+	for (int i = 0; i < 4; ++i)
+	{
+		const int s0 = src[i], s1 = src[4 + i], s2 = src[8 + i], s3 = src[12 + i];
+		const int c0 = s0 + s2, c1 = s2 + s3, c2 = s0 - s3, c3 = 74 * s1;
+		dst[4 * i + 0] = (int16_t)clip3(-32768, 32767, (29 * c0 + 55 * c1 + c3 + add) >> shift);
+		dst[4 * i + 1] = (int16_t)clip3(-32768, 32767, (55 * c2 - 29 * c1 + c3 + add) >> shift);
+		dst[4 * i + 2] = (int16_t)clip3(-32768, 32767, (74 * (s0 - s2 + s3) + add) >> shift);
+		dst[4 * i + 3] = (int16_t)clip3(-32768, 32767, (55 * c0 + 29 * c2 - c3 + add) >> shift);
+	}
+}
+
+/* residual_decode.c:350-356: the argument is narrowed to int16_t before the comparison */
+static uint8_t clip_pixel(int16_t x)
+{
+	if (x > 255) return 255;
+	if (x < 0) return 0;
+	return (uint8_t)x;
+}
+
+/* residual_decode.c:371-413 (drivers, shifts 7 then 12) + :359-368 (add residual) */
+void orc_inverse_transform_add(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *coeffs)
+{
+	const int n = 1 << log2TrafoSize;
+	int16_t t0[32 * 32], t1[32 * 32];
+	if (trType)
+	{
+		inv_pass_dst(t0, coeffs, 7);
+		inv_pass_dst(t1, t0, 12);
+	}
+	else
+	{
+		inv_pass_dct(n, t0, coeffs, 7);
+		inv_pass_dct(n, t1, t0, 12);
+	}
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x)
+			dst[x + y * stride_dst] = clip_pixel((int16_t)(pred[x + y * stride_pred] + t1[x + y * n]));
+}
+
+/* Forward N-point transform of one row by even/odd decomposition: structure of
+ * residual_decode.c:613-639 (4), :642-687 (8), :690-756 (16), :759-852 (32).
+ * E[k] = x[k] + x[N-1-k] feeds the even output rows, O[k] = x[k] - x[N-1-k] the odd ones. */
+static void fwd_even_odd(int n, int stride_rows /* row step in the n-point matrix */, const int *x, int *out /* out[k*... ] */)
+{
+	/* out[r] for r = 0..n-1 in natural order of this sub-transform */
+	if (n == 2)
+	{
+		out[0] = 64 * x[0] + 64 * x[1];
+		out[1] = 64 * x[0] - 64 * x[1];
+		(void)stride_rows;
+		return;
+	}
+	int E[16] = { 0 }, O[16] = { 0 }, sub[16] = { 0 };
+	const int half = n / 2;
+	for (int k = 0; k < half; ++k)
+	{
+		E[k] = x[k] + x[n - 1 - k];
+		O[k] = x[k] - x[n - 1 - k];
+	}
+	fwd_even_odd(half, stride_rows * 2, E, sub);
+	for (int k = 0; k < half; ++k) out[2 * k] = sub[k];
+	for (int r = 1; r < n; r += 2)
+	{
+		int a = 0;
+		for (int k = 0; k < half; ++k) a += orc_dct_matrix(n, r, k) * O[k]; /* e.g. :837-846 */
+		out[r] = a;
+	}
+}
+
+/* One forward pass: rows of src in, columns of dst out; plain (truncating) int16 store,
+ * no clipping (e.g. :631-634). */
+static void fwd_pass_dct(int n, int16_t *dst, const int16_t *src, ptrdiff_t src_stride, int shift)
+{
+	const int add = 1 << (shift - 1);
+	for (int j = 0; j < n; ++j)
+	{
+		int x[32], out[32];
+		for (int k = 0; k < n; ++k) x[k] = src[j * src_stride + k];
+		fwd_even_odd(n, 1, x, out);
+		for (int k = 0; k < n; ++k) dst[k * n + j] = (int16_t)((out[k] + add) >> shift);
+	}
+}
+
+/* residual_decode.c:592-610: forward 4x4 DST-VII pass */
+static void fwd_pass_dst(int16_t *dst, const int16_t *src, ptrdiff_t src_stride, int shift)
+{
+	const int add = 1 << (shift - 1);
+	for (int i = 0; i < 4; ++i)
+	{
+		const int s0 = src[src_stride * i + 0], s1 = src[src_stride * i + 1];
+		const int s2 = src[src_stride * i + 2], s3 = src[src_stride * i + 3];
+		const int c0 = s0 + s3, c1 = s1 + s3, c2 = s0 - s1, c3 = 74 * s2;
+		dst[0 * 4 + i] = (int16_t)((29 * c0 + 55 * c1 + c3 + add) >> shift);
+		dst[1 * 4 + i] = (int16_t)((74 * (s0 + s1 - s3) + add) >> shift);
+		dst[2 * 4 + i] = (int16_t)((29 * c2 + 55 * c0 - c3 + add) >> shift);
+		dst[3 * 4 + i] = (int16_t)((55 * c2 - 29 * c1 + c3 + add) >> shift);
+	}
+}
+
+/* residual_decode.c:855-892: shift pairs (1,8) (2,9) (3,10) (4,11) = (log2-1, log2+6) */
+void orc_transform(int trType, int log2TrafoSize, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride)
+{
+	const int n = 1 << log2TrafoSize;
+	int16_t tmp[32 * 32];
+	if (trType)
+	{
+		fwd_pass_dst(tmp, src, src_stride, 1);
+		fwd_pass_dst(coeffs, tmp, 4, 8);
+	}
+	else
+	{
+		fwd_pass_dct(n, tmp, src, src_stride, log2TrafoSize - 1);
+		fwd_pass_dct(n, coeffs, tmp, n, log2TrafoSize + 6);
+	}
+}
+
+/* ---------------------------------------------------------------- quantisation */
+
+/* quantize.c:53-62 */
+void orc_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n)
+{
+	for (int i = 0; i < n; ++i)
+		dst[i] = (int16_t)clip3(-32768, 32767, ((src[i] * scale) + (1 << (shift - 1))) >> shift);
+}
+
+/* quantize.c:160-186.  abs(-32768) = 32768 in int (:176); the return value is the OR of all
+ * quantised levels (:182), of which only zero / non-zero is meaningful (:257). */
+int orc_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n)
+{
+	offset <<= (shift - 16);
+	int cbf = 0;
+	for (int i = 0; i < n; ++i)
+	{
+		int x = src[i];
+		const int sign = x < 0 ? -1 : 1;
+		x = abs(x);
+		x = ((x * scale) + offset) >> shift;
+		x *= sign;
+		x = clip3(-32768, 32767, x);
+		cbf |= x;
+		dst[i] = (int16_t)x;
+	}
+	return cbf;
+}
+
+/* quantize.c:292-302 */
+void orc_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n)
+{
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x)
+			rec[x + y * stride_rec] = (uint8_t)clip3(0, 255, pred[x + y * stride_pred] + res[x + y * n]);
+}
+
+/* ---------------------------------------------------------------- batch drivers */
+
+void orc_sad_batch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *sad, uint32_t rect, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		sad[i] = orc_sad(src + src_off[i], stride_src, ref + ref_off[i], stride_ref, rect);
+}
+
+void orc_sad_multiref_batch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off4, int *sad4, uint32_t rect, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+	{
+		const uint8_t *r[4];
+		for (int way = 0; way < 4; ++way) r[way] = ref + ref_off4[4 * i + way];
+		orc_sad_multiref_4(src + src_off[i], stride_src, r, stride_ref, sad4 + 4 * i, rect);
+	}
+}
+
+void orc_ssd_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b,
+		const uint32_t *a_off, const uint32_t *b_off, int *ssd, int w, int h, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		ssd[i] = orc_ssd(a + a_off[i], stride_a, b + b_off[i], stride_b, w, h);
+}
+
+/* frac byte = xFrac | (yFrac << 4) */
+void orc_pred_uni_batch(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac, int w, int h, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		orc_pred_uni_8to8(taps, dst + dst_off[i], stride_dst, ref + ref_off[i], stride_ref, w, h, frac[i] & 15, frac[i] >> 4);
+}
+
+void orc_pred_bi_batch(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
+		const uint8_t *frac0, const uint8_t *frac1, int w, int h, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		orc_pred_bi_8to8(taps, dst + dst_off[i], stride_dst, ref0 + ref0_off[i], ref1 + ref1_off[i], stride_ref, w, h,
+				frac0[i] & 15, frac0[i] >> 4, frac1[i] & 15, frac1[i] >> 4);
+}
+
+void orc_inverse_transform_add_batch(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *dst_off, const uint32_t *pred_off,
+		const int16_t *coeffs, size_t n)
+{
+	const size_t nn = (size_t)1 << (2 * log2TrafoSize);
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		orc_inverse_transform_add(trType, log2TrafoSize, dst + dst_off[i], stride_dst, pred + pred_off[i], stride_pred, coeffs + nn * i);
+}
+
+void orc_dequant_inverse_transform_add_batch(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *dst_off, const uint32_t *pred_off,
+		const int16_t *levels, int scale, int shift, size_t n)
+{
+	const size_t nn = (size_t)1 << (2 * log2TrafoSize);
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+	{
+		int16_t c[32 * 32];
+		orc_quantize_inverse(c, levels + nn * i, scale, shift, (int)nn);
+		orc_inverse_transform_add(trType, log2TrafoSize, dst + dst_off[i], stride_dst, pred + pred_off[i], stride_pred, c);
+	}
+}
+
+/* src_off is in int16 elements */
+void orc_transform_batch(int trType, int log2TrafoSize, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride,
+		const uint32_t *src_off, size_t n)
+{
+	const size_t nn = (size_t)1 << (2 * log2TrafoSize);
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		orc_transform(trType, log2TrafoSize, coeffs + nn * i, src + src_off[i], src_stride);
+}
+
+void orc_quantize_batch(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n_per_block, int *cbf, size_t n_blocks)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n_blocks; ++i)
+		cbf[i] = orc_quantize(dst + (size_t)n_per_block * i, src + (size_t)n_per_block * i, scale, shift, offset, n_per_block);
+}
+
+void orc_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+		const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res, int nCbS, size_t n)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+		orc_quantize_reconstruct(rec + rec_off[i], stride_rec, pred + pred_off[i], stride_pred, res + (size_t)nCbS * nCbS * i, nCbS);
+}
+
+void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, int range, size_t n)
+{
+#pragma omp parallel for schedule(dynamic, 1)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+	{
+		int best = 0x7fffffff, bx = 0, by = 0;
+		for (int dy = -range; dy <= range; ++dy)
+			for (int dx = -range; dx <= range; ++dx)
+			{
+				const int c = orc_sad(src + src_off[i], stride_src, ref + (ptrdiff_t)ref_off[i] + dy * stride_ref + dx, stride_ref, rect);
+				if (c < best) { best = c; bx = dx; by = dy; }
+			}
+		out3[3 * i + 0] = bx; out3[3 * i + 1] = by; out3[3 * i + 2] = best;
+	}
+}

@@ -1,0 +1,101 @@
+/*
+ * hevc_oracle.h -- CPU restatement of the reference's C path for the hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the shipped
+ * library.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this; the product (hevcasm_amd/, libhevcasm_hip.so) never
+ * links, imports or calls it.
+ *
+ * Parity status: PINNED.  Every function here is checked bit-for-bit against
+ * (1) oracle/_ref/refdrv, which is the reference's own C files compiled where
+ * they lie under /root/reference (recipe: oracle/Makefile), and (2) the
+ * committed fixtures under tests/golden/ that were generated from that binary
+ * (tests/golden/make_golden.py).  The reference has no golden vectors of its
+ * own: its tests are differential against HEVCASM_C_REF, which
+ * is exactly the path refdrv runs.
+ *
+ * All citations are file:line into /root/reference/src/lib.
+ */
+#ifndef HEVC_ORACLE_H
+#define HEVC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- per-block functions (same argument meaning as the reference typedefs) ---- */
+
+/* sad.h:50, sad.c:47-60 */
+int orc_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, uint32_t rect);
+/* sad.h:95, sad.c:101-121 */
+void orc_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref[], ptrdiff_t stride_ref, int sad[], uint32_t rect);
+/* ssd.h:53, ssd.c:43-55 */
+int orc_ssd(const uint8_t *pA, ptrdiff_t strideA, const uint8_t *pB, ptrdiff_t strideB, int w, int h);
+
+/* pred_inter.c:53-83 */
+int orc_pred_coefficient(int n, int fractionalPosition, int k);
+/* pred_inter.h:56; dispatch as pred_inter.c:231-283 (C branch), bodies pred_inter.c:141-228 */
+void orc_pred_uni_8to8(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
+		int nPbW, int nPbH, int xFrac, int yFrac);
+/* pred_inter.h:76; pred_inter.c:490-530 */
+void orc_pred_bi_8to8(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		int nPbW, int nPbH, int xFrac0, int yFrac0, int xFrac1, int yFrac1);
+
+/* residual_decode.h:54; residual_decode.c:69-413 */
+void orc_inverse_transform_add(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *coeffs);
+/* residual_decode.h:82; residual_decode.c:592-892 */
+void orc_transform(int trType, int log2TrafoSize, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride);
+
+/* quantize.h:57; quantize.c:53-62 */
+void orc_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, int n);
+/* quantize.h:78; quantize.c:160-186 */
+int orc_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n);
+/* quantize.h:99; quantize.c:292-302 */
+void orc_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n);
+
+/* the transform matrix the oracle generates (checked against the literals at
+ * residual_decode.c:254-288 through the refdrv parity tests) */
+int orc_dct_matrix(int n, int k, int i);
+
+/* ---- batch drivers: loop the per-block function over a block list ----
+ * Offsets are byte offsets (element offsets for int16 planes) from the base
+ * pointer, the same descriptor the HIP C-ABI takes (include/hevcasm_hip.h). */
+
+void orc_sad_batch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *sad, uint32_t rect, size_t n);
+void orc_sad_multiref_batch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off4, int *sad4, uint32_t rect, size_t n);
+void orc_ssd_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b,
+		const uint32_t *a_off, const uint32_t *b_off, int *ssd, int w, int h, size_t n);
+void orc_pred_uni_batch(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac, int w, int h, size_t n);
+void orc_pred_bi_batch(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
+		const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
+		const uint8_t *frac0, const uint8_t *frac1, int w, int h, size_t n);
+void orc_inverse_transform_add_batch(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *dst_off, const uint32_t *pred_off,
+		const int16_t *coeffs, size_t n);
+/* a10 o a8: dequantise each block's levels, then inverse transform + add */
+void orc_dequant_inverse_transform_add_batch(int trType, int log2TrafoSize, uint8_t *dst, ptrdiff_t stride_dst,
+		const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *dst_off, const uint32_t *pred_off,
+		const int16_t *levels, int scale, int shift, size_t n);
+void orc_transform_batch(int trType, int log2TrafoSize, int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride,
+		const uint32_t *src_off, size_t n);
+void orc_quantize_batch(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n_per_block, int *cbf, size_t n_blocks);
+void orc_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+		const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res, int nCbS, size_t n);
+
+/* Full search: for each block, SAD (sad.c:47-60) at every
+ * displacement (dx,dy) in [-range,range]^2 around ref_off; best = minimum cost, ties broken by
+ * the first in raster order of (dy,dx).  out[3*i] = dx, dy, cost. */
+void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, int range, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
