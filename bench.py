@@ -1,0 +1,238 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json config #2 on MI355X: batched SAD + 4-way multi-reference SAD over
+all 20 block sizes >= 8x8, 1 Mi blocks per size per GPU, inputs resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One *step* = one pass of the hot path over the whole batch: for each of the 20 sizes, one
+hevcasm_hip_sad_batch launch and one hevcasm_hip_sad_multiref_batch launch over that size's
+blocks (sizes whose frame stack would exceed the 4 GiB offset window run as two launches).
+Every size has its own frame stacks (about 46 GB in total), so a launch never finds its data in
+the 256 MiB Infinity Cache left by the previous one: the numbers are cold-HBM numbers.
+
+value      = block evaluations per second of the whole job, in Mblocks/s (a 4-way call counts as
+             one block), all ranks, steps timed between barrier + synchronize brackets, MAX over ranks.
+roofline   = the kernel with the largest share of the timed region: algorithmic bytes per launch /
+             its mean duration, measured live with HIP events on the launch stream, against 8 TB/s.
+cpu_baseline = the REFERENCE's own C path (oracle/_ref/refdrv, gcc -O3) timed on this host's
+             cores on a bounded sample of the same mix (rank 0, N = 1 only).  Baseline, not target.
+Multi-GPU: weak scaling, each rank owns its own 1 Mi-block batch per size; no data-path collective.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+OFFSET_WINDOW = (1 << 32) - (1 << 24)
+
+
+def algorithmic_bytes(w, h, ways):
+    """SAD 2WH + 4, SADx4 5WH + 16; plus the u32 block descriptors this API reads
+    (4 bytes per offset: 1 source + `ways` references)."""
+    return (1 + ways) * w * h + 4 * ways + 4 * (1 + ways)
+
+
+def max_over_ranks(seconds, device="cuda"):
+    """Barrier, then the maximum of a per-rank elapsed time (identity when not distributed)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+class SizeBatch:
+    """Device-resident inputs of one block size: one or more chunks, each within the offset window."""
+
+    def __init__(self, w, h, n_blocks, seed, device):
+        import torch
+        from hevcasm_amd import batch as B, workload as wl
+        self.w, self.h, self.n = w, h, n_blocks
+        self.chunks = []
+        per_frame = (wl.FRAME_W // w) * (wl.FRAME_H // h)
+        ref_frame_bytes = (wl.FRAME_W + 32) * (wl.FRAME_H + 16)
+        max_frames = OFFSET_WINDOW // ref_frame_bytes
+        max_blocks = max_frames * per_frame
+        done = 0
+        while done < n_blocks:
+            m = min(n_blocks - done, max_blocks)
+            c = wl.sad_case(w, h, m, seed + done, ways=4, frame=(wl.FRAME_W, wl.FRAME_H), device=device)
+            ro4 = B.off32(c["ref_off"])
+            self.chunks.append(dict(
+                n=m, src=c["src"], ref=c["ref"], stride_src=c["stride_src"], stride_ref=c["stride_ref"],
+                src_off=B.off32(c["src_off"]), ref_off4=ro4, ref_off1=ro4.view(m, 4)[:, 0].contiguous(),
+                out1=torch.empty(m, dtype=torch.int32, device=device), out4=torch.empty((m, 4), dtype=torch.int32, device=device)))
+            done += m
+
+    def launch(self, ways, chunk):
+        from hevcasm_amd import batch as B
+        c = chunk
+        if ways == 1:
+            B.sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off1"], self.w, self.h, out=c["out1"])
+        else:
+            B.sad_multiref(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off4"], self.w, self.h, out=c["out4"])
+
+
+def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
+    """The reference's C path on the host: one refdrv process per core, each timing every
+    (size, ways) of the mix on `sample_blocks` blocks for an equal share of `budget_s`."""
+    from concurrent.futures import ThreadPoolExecutor
+    from hevcasm_amd import workload as wl
+    from oracle import pyref
+    if not pyref.available():
+        return None
+    procs_n = max(1, min(max_procs, os.cpu_count() or 1))
+    combos = [(w, h, ways) for (w, h) in sizes for ways in (1, 4)]
+    ms_each = max(20, int(1000.0 * budget_s / len(combos)))
+    cases = {(w, h): wl.sad_case(w, h, sample_blocks, 9000 + w * 64 + h, ways=4, frame=(wl.FRAME_W, wl.FRAME_H)) for (w, h) in sizes}
+
+    def worker(_):
+        rates = {}
+        with pyref.RefProc() as p:
+            for (w, h, ways) in combos:
+                c = cases[(w, h)]
+                ro = c["ref_off"] if ways == 4 else np.ascontiguousarray(c["ref_off"].reshape(-1, 4)[:, 0])
+                secs, blocks = p.bench_sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], ro, w, h, ways, ms_each)
+                rates[(w, h, ways)] = blocks / secs
+        return rates
+
+    with ThreadPoolExecutor(procs_n) as ex:
+        per_proc = list(ex.map(worker, range(procs_n)))
+    # throughput of the same mix (equal block counts per (size, ways)): harmonic combination per process, summed
+    total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
+    sad16 = sum(r[(16, 16, 1)] for r in per_proc)
+    return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference",
+                sample="reference C path (gcc -O3, HEVCASM_C_REF tables) via oracle/_ref/refdrv: %d processes x %d (size, ways) combos x %d blocks "
+                       "repeated for %d ms each, same size mix as the GPU step" % (procs_n, len(combos), sample_blocks, ms_each),
+                sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=1 << 20, help="blocks per size per GPU (config #2: 1 Mi)")
+    ap.add_argument("--sizes", default="all", help="'all' (20 sizes >= 8x8) or a comma list like 16x16,64x64")
+    ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from hevcasm_amd import capi, workload as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)   # RCCL; used for the timing barrier / max only
+
+    L = capi.lib()
+    if not L.hevcasm_hip_available():
+        sys.exit("no usable gfx950 device: the HIP path has no fallback")
+
+    sizes = wl.SAD_BENCH_SIZES if args.sizes == "all" else [tuple(int(v) for v in s.split("x")) for s in args.sizes.split(",")]
+    t0 = time.time()
+    batches = [SizeBatch(w, h, args.blocks, 1000 * (rank + 1) + 17 * i, device) for i, (w, h) in enumerate(sizes)]
+    torch.cuda.synchronize()
+    gen_s = time.time() - t0
+    launches = [(b, ways, c) for b in batches for ways in (1, 4) for c in b.chunks]
+
+    def step(events=None):
+        for (b, ways, c) in launches:
+            if events is None:
+                b.launch(ways, c)
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                b.launch(ways, c)
+                e1.record()
+                events.append(((b.w, b.h, ways), c["n"], e0, e1))
+
+    def bracket():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    events = []
+    bracket()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(events)
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local)
+    bracket()
+
+    # per-kernel durations from the HIP events recorded inside the timed region
+    per = {}
+    for key, n, e0, e1 in events:
+        d = per.setdefault(key, dict(ms=0.0, launches=0, blocks=0))
+        d["ms"] += e0.elapsed_time(e1)
+        d["launches"] += 1
+        d["blocks"] += n
+    detail = []
+    for (w, h, ways), d in per.items():
+        bytes_total = algorithmic_bytes(w, h, ways) * d["blocks"]
+        gbs = bytes_total / (d["ms"] * 1e-3) / 1e9
+        detail.append(dict(kernel="sad_multiref_4" if ways == 4 else "sad", size="%dx%d" % (w, h), ms_per_pass=round(d["ms"] / args.steps, 4),
+                           launches_per_pass=d["launches"] // args.steps, mblocks_per_s=round(d["blocks"] / (d["ms"] * 1e-3) / 1e6, 1),
+                           algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4), total_ms=d["ms"],
+                           bytes_per_block=algorithmic_bytes(w, h, ways)))
+    dom = max(detail, key=lambda r: r["total_ms"])
+    dom_key = (int(dom["size"].split("x")[0]), int(dom["size"].split("x")[1]), 4 if dom["kernel"] != "sad" else 1)
+    dom_d = per[dom_key]
+    dom_avg_s = dom_d["ms"] * 1e-3 / dom_d["launches"]
+    dom_bytes = algorithmic_bytes(*dom_key) * dom_d["blocks"] / dom_d["launches"]
+    for r in detail:
+        del r["total_ms"]
+    head = [r for r in detail if r["kernel"] == "sad" and r["size"] == "16x16"]
+
+    blocks_per_step = sum(c["n"] for (_, _, c) in launches)
+    value = world * blocks_per_step * args.steps / elapsed / 1e6
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(sizes, 2048, args.cpu_seconds)
+        line = {
+            "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
+            "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: batched SAD + 4-way multiref SAD, %d block sizes %s, %d blocks per size per GPU, "
+                                   "ref displaced +-7 px, device-resident frames" % (len(sizes), "8x8..64x64" if args.sizes == "all" else args.sizes, args.blocks),
+                       "blocks_per_step_per_gpu": blocks_per_step, "launches_per_step": len(launches), "parallelism": "batch split x%d, no collectives" % world,
+                       "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1)},
+            "roofline": {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
+            "cpu_baseline": cpu,
+            "headline": {"sad_16x16_single_ref": head[0] if head else None},
+            "detail": detail,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

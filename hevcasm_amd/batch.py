@@ -1,0 +1,135 @@
+"""Batched hot-path calls on torch CUDA tensors.
+
+torch is used only as plumbing: it owns the device memory and the stream.  Every function
+passes raw device pointers to the C-ABI (include/hevcasm_hip.h) and raises ``HevcasmError``
+on a non-zero return code -- there is no eager/PyTorch fallback for any of these.
+"""
+import numpy as np
+import torch
+
+from . import capi
+from .capi import check, lib, rect
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(x, dtype):
+    """numpy array or tensor -> contiguous CUDA tensor of ``dtype`` (uint32 travels as int32 bits)."""
+    if isinstance(x, np.ndarray):
+        if x.dtype == np.uint32:
+            x = x.view(np.int32)
+        x = torch.from_numpy(np.ascontiguousarray(x))
+    if not x.is_cuda:
+        x = x.cuda()
+    assert x.dtype == dtype, (x.dtype, dtype)
+    return x.contiguous()
+
+
+def u8(x):
+    return _dev(x, torch.uint8)
+
+
+def i16(x):
+    return _dev(x, torch.int16)
+
+
+def off32(x):
+    return _dev(x, torch.int32)
+
+
+def sad(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, out=None):
+    n = src_off.numel()
+    out = torch.empty(n, dtype=torch.int32, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_sad_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(), ref_off.data_ptr(),
+                                      out.data_ptr(), rect(w, h), n, _stream()), "sad_batch")
+    return out
+
+
+def sad_multiref(src, stride_src, ref, stride_ref, src_off, ref_off4, w, h, out=None):
+    n = src_off.numel()
+    assert ref_off4.numel() == 4 * n
+    out = torch.empty((n, 4), dtype=torch.int32, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_sad_multiref_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(),
+                                               ref_off4.data_ptr(), out.data_ptr(), rect(w, h), n, _stream()), "sad_multiref_batch")
+    return out
+
+
+def ssd(a, stride_a, b, stride_b, a_off, b_off, w, h, out=None):
+    n = a_off.numel()
+    out = torch.empty(n, dtype=torch.int32, device=a.device) if out is None else out
+    check(lib().hevcasm_hip_ssd_batch(a.data_ptr(), stride_a, b.data_ptr(), stride_b, a_off.data_ptr(), b_off.data_ptr(),
+                                      out.data_ptr(), w, h, n, _stream()), "ssd_batch")
+    return out
+
+
+def pred_uni(dst, stride_dst, ref, stride_ref, dst_off, ref_off, frac, taps, w, h):
+    n = dst_off.numel()
+    check(lib().hevcasm_hip_pred_uni_8to8_batch(dst.data_ptr(), stride_dst, ref.data_ptr(), stride_ref, dst_off.data_ptr(),
+                                                ref_off.data_ptr(), frac.data_ptr(), taps, w, h, n, _stream()), "pred_uni_8to8_batch")
+    return dst
+
+
+def pred_bi(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, taps, w, h):
+    n = dst_off.numel()
+    check(lib().hevcasm_hip_pred_bi_8to8_batch(dst.data_ptr(), stride_dst, ref0.data_ptr(), ref1.data_ptr(), stride_ref,
+                                               dst_off.data_ptr(), ref0_off.data_ptr(), ref1_off.data_ptr(),
+                                               frac0.data_ptr(), frac1.data_ptr(), taps, w, h, n, _stream()), "pred_bi_8to8_batch")
+    return dst
+
+
+def inverse_transform_add(dst, stride_dst, pred, stride_pred, dst_off, pred_off, coeffs, tr_type, log2n):
+    n = dst_off.numel()
+    check(lib().hevcasm_hip_inverse_transform_add_batch(dst.data_ptr(), stride_dst, pred.data_ptr(), stride_pred, dst_off.data_ptr(),
+                                                        pred_off.data_ptr(), coeffs.data_ptr(), tr_type, log2n, n, _stream()),
+          "inverse_transform_add_batch")
+    return dst
+
+
+def dequant_inverse_transform_add(dst, stride_dst, pred, stride_pred, dst_off, pred_off, levels, scale, shift, tr_type, log2n):
+    n = dst_off.numel()
+    check(lib().hevcasm_hip_dequant_inverse_transform_add_batch(dst.data_ptr(), stride_dst, pred.data_ptr(), stride_pred,
+                                                                dst_off.data_ptr(), pred_off.data_ptr(), levels.data_ptr(),
+                                                                scale, shift, tr_type, log2n, n, _stream()),
+          "dequant_inverse_transform_add_batch")
+    return dst
+
+
+def transform(src, src_stride, src_off, tr_type, log2n, out=None):
+    n = src_off.numel()
+    out = torch.empty(n << (2 * log2n), dtype=torch.int16, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_transform_batch(out.data_ptr(), src.data_ptr(), src_stride, src_off.data_ptr(), tr_type, log2n, n, _stream()),
+          "transform_batch")
+    return out
+
+
+def quantize_inverse(src, scale, shift, out=None):
+    out = torch.empty_like(src) if out is None else out
+    check(lib().hevcasm_hip_quantize_inverse(out.data_ptr(), src.data_ptr(), scale, shift, src.numel(), _stream()), "quantize_inverse")
+    return out
+
+
+def quantize(src, scale, shift, offset, n_per_block, out=None, cbf=None):
+    nb = src.numel() // n_per_block
+    out = torch.empty_like(src) if out is None else out
+    cbf = torch.empty(nb, dtype=torch.int32, device=src.device) if cbf is None else cbf
+    check(lib().hevcasm_hip_quantize_batch(out.data_ptr(), src.data_ptr(), scale, shift, offset, n_per_block, nb, cbf.data_ptr(), _stream()),
+          "quantize_batch")
+    return out, cbf
+
+
+def quantize_reconstruct(rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, ncbs):
+    n = rec_off.numel()
+    check(lib().hevcasm_hip_quantize_reconstruct_batch(rec.data_ptr(), stride_rec, pred.data_ptr(), stride_pred, rec_off.data_ptr(),
+                                                       pred_off.data_ptr(), res.data_ptr(), ncbs, n, _stream()), "quantize_reconstruct_batch")
+    return rec
+
+
+def me_full_search(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, search_range, out=None):
+    n = src_off.numel()
+    out = torch.empty((n, 3), dtype=torch.int32, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_me_full_search_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(),
+                                                 ref_off.data_ptr(), out.data_ptr(), rect(w, h), search_range, n, _stream()),
+          "me_full_search_batch")
+    return out

@@ -1,0 +1,192 @@
+"""Seeded synthetic workloads for the hot path, shared by tests and bench.py.
+
+Data model (what include/hevcasm_hip.h consumes): 8-bit planes stay in frame layout -- a stack
+of frames, each ``frame_h`` rows of ``stride`` bytes -- and a block is a u32 byte offset from
+the plane's base.  Block ``i`` of a batch is tile ``i`` of the stack in raster order, so
+consecutive blocks are horizontal neighbours (what a codec walking a frame produces).
+
+Geometry and offsets are always computed with numpy (cheap, deterministic).  Pixel payloads
+come from ``fill_u8`` / ``fill_i16``, either numpy (tests: same bytes go to the oracle and the
+GPU) or torch on the device (bench: tens of GB are generated in HBM, never on the host).
+"""
+import numpy as np
+
+# reference sad.c:231-240
+SAD_PARTITIONS = [(64, 64), (64, 48), (64, 32), (64, 16), (48, 64), (32, 64), (32, 32), (32, 24), (32, 16), (32, 8),
+                  (24, 32), (16, 64), (16, 32), (16, 16), (16, 12), (16, 8), (16, 4), (12, 16),
+                  (8, 32), (8, 16), (8, 8), (8, 4), (4, 8)]
+# BASELINE.json config #2: both dimensions >= 8
+SAD_BENCH_SIZES = [p for p in SAD_PARTITIONS if p[0] >= 8 and p[1] >= 8]
+# reference pred_inter.c:438-444 (luma; chroma = half)
+PU_SIZES = [(8, 4), (8, 8), (4, 8), (16, 4), (16, 8), (16, 12), (16, 16), (12, 16), (8, 16), (4, 16),
+            (32, 8), (32, 16), (32, 24), (32, 32), (24, 32), (16, 32), (8, 32),
+            (64, 16), (64, 32), (64, 48), (64, 64), (48, 64), (32, 64), (16, 64)]
+PU_SIZES_BI = [p for p in PU_SIZES if p not in ((8, 4), (4, 8))]
+TRANSFORMS = [(1, 2), (0, 2), (0, 3), (0, 4), (0, 5)]  # (trType, log2TrafoSize)
+
+# A frame every hot-path block size tiles exactly: 1920 = lcm-friendly width, 1152 = 6 * 192 rows.
+FRAME_W, FRAME_H = 1920, 1152
+# Small frame with the same property, for CPU-sized tests.
+SMALL_W, SMALL_H = 192, 192
+
+
+class Plane:
+    """Geometry of a frame stack: ``frames`` frames of (frame_h + 2*border_y) rows of ``stride`` bytes."""
+
+    def __init__(self, frame_w, frame_h, frames, border_x=0, border_y=0):
+        self.frame_w, self.frame_h, self.frames = frame_w, frame_h, frames
+        self.border_x, self.border_y = border_x, border_y
+        self.stride = frame_w + 2 * border_x
+        self.rows_per_frame = frame_h + 2 * border_y
+        self.size = self.stride * self.rows_per_frame * frames
+
+    def tile_offsets(self, n, w, h):
+        """Offsets of the first n w x h tiles in raster order (frame after frame)."""
+        per_row, per_col = self.frame_w // w, self.frame_h // h
+        per_frame = per_row * per_col
+        i = np.arange(n, dtype=np.int64)
+        f, r = i // per_frame, i % per_frame
+        by, bx = r // per_row, r % per_row
+        off = (f * self.rows_per_frame + self.border_y + by * h) * self.stride + self.border_x + bx * w
+        assert off.max(initial=0) < 2 ** 32, "plane exceeds the 4 GiB offset window: split the batch"
+        return off
+
+    @staticmethod
+    def frames_for(n, w, h, frame_w, frame_h):
+        per_frame = (frame_w // w) * (frame_h // h)
+        return max(1, -(-n // per_frame))
+
+
+def fill_u8(size, seed, kind="noise", device=None):
+    """``size`` bytes.  kind: 'noise' (uniform 0..255), 'zeros', 'max' (all 255)."""
+    if device is None:
+        if kind == "zeros":
+            return np.zeros(size, dtype=np.uint8)
+        if kind == "max":
+            return np.full(size, 255, dtype=np.uint8)
+        return np.random.default_rng(seed).integers(0, 256, size=size, dtype=np.uint8)
+    import torch
+    if kind == "zeros":
+        return torch.zeros(size, dtype=torch.uint8, device=device)
+    if kind == "max":
+        return torch.full((size,), 255, dtype=torch.uint8, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    out = torch.empty(size, dtype=torch.uint8, device=device)
+    step = 1 << 30  # bounded temporaries
+    for s in range(0, size, step):
+        e = min(size, s + step)
+        out[s:e] = torch.randint(0, 256, (e - s,), generator=g, device=device, dtype=torch.uint8)
+    return out
+
+
+def fill_i16(size, seed, kind="full", device=None):
+    """``size`` int16 values.  kind: 'full' (uniform over all 16 bits, as reference
+    residual_decode.c:574), 'residual9' (9-bit, reference :1000), 'natural' (sparse Laplacian-like
+    levels), 'neg256' (reference quantize.c:145), 'min' / 'max' (all -32768 / +32767)."""
+    rng = np.random.default_rng(seed)
+    if kind == "full":
+        a = rng.integers(-32768, 32768, size=size, dtype=np.int32)
+    elif kind == "residual9":
+        a = rng.integers(-256, 256, size=size, dtype=np.int32)
+    elif kind == "neg256":
+        a = rng.integers(-256, 0, size=size, dtype=np.int32)
+    elif kind == "natural":
+        mag = rng.geometric(0.25, size=size).astype(np.int32)
+        a = np.where(rng.random(size) < 0.7, 0, mag * rng.choice(np.array([-1, 1], dtype=np.int32), size=size))
+    elif kind == "min":
+        a = np.full(size, -32768, dtype=np.int32)
+    elif kind == "max":
+        a = np.full(size, 32767, dtype=np.int32)
+    elif kind == "alternating":
+        a = np.where(np.arange(size) & 1, -32767, 32767).astype(np.int32)
+    else:
+        raise ValueError(kind)
+    a = a.astype(np.int16)
+    if device is None:
+        return a
+    import torch
+    return torch.from_numpy(a).to(device)
+
+
+def fill_i16_device(size, seed, device, lo=-32768, hi=32768):
+    """Uniform int16 generated on the device (bench-sized buffers)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return torch.randint(lo, hi, (size,), generator=g, device=device, dtype=torch.int16)
+
+
+# ---------------------------------------------------------------------------------------------
+# cases: dicts of numpy arrays + scalars; keys match the argument names of the batch API
+
+
+def sad_case(w, h, n, seed, ways=1, max_disp=7, frame=(SMALL_W, SMALL_H), kind="noise", device=None):
+    """Config #2: src block i = tile i; ref block i = same tile in a second stack displaced by
+    (dx, dy) uniform in [-max_disp, max_disp]^2 (so byte-misaligned, as reference sad.c:214)."""
+    fw, fh = frame
+    frames = Plane.frames_for(n, w, h, fw, fh)
+    sp = Plane(fw, fh, frames)
+    rp = Plane(fw, fh, frames, border_x=16, border_y=8)
+    assert max_disp <= 8
+    rng = np.random.default_rng(seed + 1)
+    src_off = sp.tile_offsets(n, w, h)
+    base = rp.tile_offsets(n, w, h)
+    d = rng.integers(-max_disp, max_disp + 1, size=(n, ways, 2))
+    ref_off = base[:, None] + d[:, :, 1] * rp.stride + d[:, :, 0]
+    return dict(
+        src=fill_u8(sp.size, seed, kind, device), stride_src=sp.stride,
+        ref=fill_u8(rp.size, seed + 2, kind if kind != "max" else "zeros", device), stride_ref=rp.stride,
+        src_off=src_off.astype(np.uint32), ref_off=ref_off.reshape(-1).astype(np.uint32),
+        w=w, h=h, n=n, ways=ways)
+
+
+def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noise", fracs=None, device=None):
+    """Config #3: dst tiled by w x h PUs; reference origin = same position displaced by an integer
+    motion vector in [-8, 8]^2; fractions uniform over all phases (4 luma / 8 chroma per axis)
+    unless ``fracs`` = (xFrac, yFrac) pins them."""
+    fw, fh = frame
+    frames = Plane.frames_for(n, w, h, fw, fh)
+    dp = Plane(fw, fh, frames)
+    rp = Plane(fw, fh, frames, border_x=16, border_y=16)
+    rng = np.random.default_rng(seed + 1)
+    dst_off = dp.tile_offsets(n, w, h)
+    base = rp.tile_offsets(n, w, h)
+    phases = 4 if taps == 8 else 8
+    out = dict(taps=taps, w=w, h=h, n=n, stride_dst=dp.stride, stride_ref=rp.stride, dst_bytes=dp.size,
+               dst_off=dst_off.astype(np.uint32))
+    for r in range(2 if bi else 1):
+        mv = rng.integers(-8, 9, size=(n, 2))
+        off = base + mv[:, 1] * rp.stride + mv[:, 0]
+        if fracs is None:
+            fx, fy = rng.integers(0, phases, size=n), rng.integers(0, phases, size=n)
+        else:
+            fx, fy = np.full(n, fracs[0]), np.full(n, fracs[1])
+        out["ref%d" % r] = fill_u8(rp.size, seed + 2 + r, kind, device)
+        out["ref%d_off" % r] = off.astype(np.uint32)
+        out["frac%d" % r] = (fx | (fy << 4)).astype(np.uint8)
+    return out
+
+
+def inverse_case(tr_type, log2n, n, seed, coeff_kind="full", frame=(SMALL_W, SMALL_H), device=None):
+    """Config #4: n coefficient blocks (contiguous), prediction and destination planes tiled by N x N."""
+    size = 1 << log2n
+    fw, fh = frame
+    frames = Plane.frames_for(n, size, size, fw, fh)
+    pp = Plane(fw, fh, frames)
+    dp = Plane(fw, fh, frames, border_x=16)  # a different stride from the prediction plane
+    return dict(
+        tr_type=tr_type, log2n=log2n, n=n,
+        pred=fill_u8(pp.size, seed, "noise", device), stride_pred=pp.stride, pred_off=pp.tile_offsets(n, size, size).astype(np.uint32),
+        stride_dst=dp.stride, dst_bytes=dp.size, dst_off=dp.tile_offsets(n, size, size).astype(np.uint32),
+        coeffs=fill_i16(n * size * size, seed + 1, coeff_kind, device))
+
+
+def forward_case(tr_type, log2n, n, seed, kind="residual9", frame=(SMALL_W, SMALL_H), device=None):
+    """Residual plane (int16, frame layout) tiled by N x N; offsets in int16 elements."""
+    size = 1 << log2n
+    fw, fh = frame
+    frames = Plane.frames_for(n, size, size, fw, fh)
+    p = Plane(fw, fh, frames)
+    return dict(tr_type=tr_type, log2n=log2n, n=n, src=fill_i16(p.size, seed, kind, device), src_stride=p.stride,
+                src_off=p.tile_offsets(n, size, size).astype(np.uint32))

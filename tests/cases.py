@@ -1,0 +1,321 @@
+"""Case builders and runners shared by the parity tests and tests/golden/make_golden.py.
+
+A *case* is (family, kwargs) where kwargs are numpy inputs named as in hevcasm_amd.workload.
+Three runners evaluate a case and return a tuple of numpy arrays:
+  run_oracle     oracle/liboracle.so   (our C restatement)
+  run_reference  oracle/_ref/refdrv    (the reference's own C files)
+  run_hip        the product, through the C-ABI, on cuda:0
+"""
+import numpy as np
+
+from hevcasm_amd import workload as wl
+
+
+def _dst_rows(buf, stride, off, w, h):
+    """Gather the w x h blocks at `off` from a plane into (n, h, w)."""
+    idx = off.astype(np.int64)[:, None, None] + np.arange(h)[None, :, None] * stride + np.arange(w)[None, None, :]
+    return buf[idx]
+
+
+# ---------------------------------------------------------------------------------- case lists
+
+def sad_cases(n=96, sizes=None, seed=100):
+    out = []
+    for i, (w, h) in enumerate(sizes or wl.SAD_PARTITIONS):
+        out.append(("sad_%dx%d" % (w, h), "sad", wl.sad_case(w, h, n, seed + i)))
+        out.append(("sad4_%dx%d" % (w, h), "sad4", wl.sad_case(w, h, n, seed + 50 + i, ways=4)))
+    # extremes: maximum possible sums (all-255 against all-0), all-equal
+    c = wl.sad_case(64, 64, 8, seed + 99, kind="max")
+    out.append(("sad_64x64_max", "sad", c))
+    c = wl.sad_case(64, 64, 8, seed + 98, ways=4, kind="max")
+    out.append(("sad4_64x64_max", "sad4", c))
+    c = wl.sad_case(16, 16, 8, seed + 97, kind="zeros")
+    out.append(("sad_16x16_zero", "sad", c))
+    # generic (non-table) sizes served by sadGeneric: every multiple of 4 is legal
+    for (w, h) in [(4, 4), (20, 28), (36, 4), (44, 60), (52, 12), (60, 64), (28, 8), (40, 40), (56, 20)]:
+        out.append(("sad_%dx%d" % (w, h), "sad", wl.sad_case(w, h, 40, seed + w + h)))
+        out.append(("sad4_%dx%d" % (w, h), "sad4", wl.sad_case(w, h, 40, seed + w + h + 1, ways=4)))
+    # ragged batch sizes around the wave / workgroup granularity
+    for n_odd in (1, 3, 63, 65, 257):
+        out.append(("sad_16x16_n%d" % n_odd, "sad", wl.sad_case(16, 16, n_odd, seed + n_odd)))
+        out.append(("sad4_24x32_n%d" % n_odd, "sad4", wl.sad_case(24, 32, n_odd, seed + n_odd, ways=4)))
+    return out
+
+
+def ssd_cases(n=64, seed=200):
+    out = []
+    for i, s in enumerate((4, 8, 16, 32, 64)):
+        out.append(("ssd_%d" % s, "ssd", wl.sad_case(s, s, n, seed + i)))
+    for (w, h) in [(12, 16), (24, 32), (48, 64), (64, 16), (8, 4)]:
+        out.append(("ssd_%dx%d" % (w, h), "ssd", wl.sad_case(w, h, 24, seed + w)))
+    out.append(("ssd_64_max", "ssd", wl.sad_case(64, 64, 4, seed + 9, kind="max")))
+    return out
+
+
+def pred_uni_cases(n=24, seed=300, sizes=None):
+    out = []
+    for taps in (8, 4):
+        for i, (w, h) in enumerate(sizes or wl.PU_SIZES):
+            pw, ph = w * taps // 8, h * taps // 8
+            out.append(("uni%d_%dx%d" % (taps, pw, ph), "pred_uni", wl.pred_case(taps, pw, ph, n, seed + i + taps)))
+    # every fraction pair on one size per tap count (the reference's own test only reaches 0 and 1)
+    for taps, (w, h) in ((8, (16, 16)), (4, (8, 8))):
+        ph = 4 if taps == 8 else 8
+        for fx in range(ph):
+            for fy in range(ph):
+                out.append(("uni%d_f%d%d" % (taps, fx, fy), "pred_uni", wl.pred_case(taps, w, h, 6, seed + fx * 8 + fy, fracs=(fx, fy))))
+    # both clip rails: saturated inputs
+    out.append(("uni8_max", "pred_uni", wl.pred_case(8, 32, 32, 8, seed + 70, kind="max")))
+    out.append(("uni8_zero", "pred_uni", wl.pred_case(8, 32, 32, 8, seed + 71, kind="zeros")))
+    out.append(("uni8_checker", "pred_uni", _checker(wl.pred_case(8, 64, 64, 6, seed + 72))))
+    out.append(("uni4_checker", "pred_uni", _checker(wl.pred_case(4, 32, 32, 6, seed + 73))))
+    return out
+
+
+def _checker(case):
+    """0/255 patterns drive the filters to both extremes of their range."""
+    for k in ("ref0", "ref1"):
+        if k in case:
+            r = case[k]
+            i = np.arange(r.size)
+            case[k] = np.where(((i // 3) ^ (i // case["stride_ref"])) & 1, 255, 0).astype(np.uint8)
+    return case
+
+
+def pred_bi_cases(n=16, seed=400, sizes=None):
+    out = []
+    for taps in (8, 4):
+        for i, (w, h) in enumerate(sizes or wl.PU_SIZES_BI):
+            pw, ph = w * taps // 8, h * taps // 8
+            out.append(("bi%d_%dx%d" % (taps, pw, ph), "pred_bi", wl.pred_case(taps, pw, ph, n, seed + i + taps, bi=True)))
+        out.append(("bi%d_zero_frac" % taps, "pred_bi", wl.pred_case(taps, 16, 16, 8, seed + 50 + taps, bi=True, fracs=(0, 0))))
+    out.append(("bi8_max", "pred_bi", wl.pred_case(8, 32, 32, 6, seed + 60, bi=True, kind="max")))
+    out.append(("bi8_checker", "pred_bi", _checker(wl.pred_case(8, 64, 64, 4, seed + 61, bi=True))))
+    return out
+
+
+def inverse_cases(n=40, seed=500):
+    out = []
+    for tr, lg in wl.TRANSFORMS:
+        tag = "dst4" if tr else "dct%d" % (1 << lg)
+        for kind in ("full", "natural", "max", "min", "alternating"):
+            out.append(("inv_%s_%s" % (tag, kind), "inverse", wl.inverse_case(tr, lg, n if kind in ("full", "natural") else 3, seed + lg, kind)))
+        c = wl.inverse_case(tr, lg, 6, seed + 7, "natural")
+        c["coeffs"][:] = 0
+        c["coeffs"][:: 1 << (2 * lg)] = [-32768, 32767, 1, -1, 255, -4096]   # DC only
+        out.append(("inv_%s_dc" % tag, "inverse", c))
+    return out
+
+
+def dequant_inverse_cases(n=24, seed=600):
+    out = []
+    for tr, lg in wl.TRANSFORMS:
+        tag = "dst4" if tr else "dct%d" % (1 << lg)
+        # reference self-test parameters (quantize.c:149-150) and an HEVC-style sweep: scale = levelScale[qP % 6] << (qP / 6), shift = bitDepth + log2N - 5
+        for scale, shift in ((51, 14), (40 << 3, 8 + lg - 5 if 8 + lg - 5 > 0 else 1), (72 << 5, 8 + lg - 5 if 8 + lg - 5 > 0 else 1)):
+            for kind in ("natural", "neg256"):
+                c = wl.inverse_case(tr, lg, n, seed + lg + scale, kind)
+                c["scale"], c["shift"] = scale, shift
+                out.append(("deqinv_%s_%d_%d_%s" % (tag, scale, shift, kind), "dequant_inverse", c))
+    return out
+
+
+def forward_cases(n=40, seed=700):
+    out = []
+    for tr, lg in wl.TRANSFORMS:
+        tag = "dst4" if tr else "dct%d" % (1 << lg)
+        for kind in ("residual9", "full", "max", "min"):
+            out.append(("fwd_%s_%s" % (tag, kind), "forward", wl.forward_case(tr, lg, n if kind in ("residual9", "full") else 3, seed + lg, kind)))
+        c = wl.forward_case(tr, lg, 6, seed + 3, "residual9")
+        c["src"] = np.where(np.arange(c["src"].size) % 3 == 0, 255, -255).astype(np.int16)
+        out.append(("fwd_%s_pm255" % tag, "forward", c))
+    return out
+
+
+def quant_cases(seed=800):
+    out = []
+    rng = np.random.default_rng(seed)
+    for lg in (2, 3, 4, 5):
+        nn = 1 << (2 * lg)
+        nb = 20
+        out.append(("deq_%d_ref" % nn, "dequant", dict(src=wl.fill_i16(nn * nb, seed + lg, "neg256"), scale=51, shift=14)))
+        out.append(("deq_%d_full" % nn, "dequant", dict(src=wl.fill_i16(nn * nb, seed + lg, "full"), scale=40, shift=5)))
+        src = (rng.integers(0, 2 ** 31, nn * nb) - rng.integers(0, 2 ** 31, nn * nb)).astype(np.int16)  # reference quantize.c:273: rand() - rand() truncated
+        out.append(("q_%d_ref" % nn, "quant", dict(src=src, scale=51, shift=20, offset=14, n_per_block=nn)))
+        out.append(("q_%d_hevc" % nn, "quant", dict(src=wl.fill_i16(nn * nb, seed + 9 + lg, "full"), scale=26214, shift=21, offset=171 << 7, n_per_block=nn)))
+        z = wl.fill_i16(nn * nb, seed + 19 + lg, "natural")
+        z[: nn * 5] = 0                                      # whole blocks that quantise to zero: cbf == 0
+        out.append(("q_%d_sparse" % nn, "quant", dict(src=z, scale=51, shift=20, offset=14, n_per_block=nn)))
+        e = np.zeros(nn * 2, dtype=np.int16)
+        e[0], e[1], e[nn] = -32768, 32767, -32768              # abs(-32768) = 32768 in C (quantize.c:176)
+        out.append(("q_%d_min" % nn, "quant", dict(src=e, scale=32767, shift=16, offset=32767, n_per_block=nn)))
+        size = 1 << lg
+        c = wl.inverse_case(0, lg, 30, seed + 30 + lg, "residual9")
+        out.append(("rec_%d" % size, "recon", dict(pred=c["pred"], stride_pred=c["stride_pred"], pred_off=c["pred_off"], stride_rec=c["stride_dst"],
+                                                   rec_bytes=c["dst_bytes"], rec_off=c["dst_off"], res=c["coeffs"], ncbs=size)))
+        c = wl.inverse_case(0, lg, 6, seed + 40 + lg, "full")
+        out.append(("rec_%d_full" % size, "recon", dict(pred=c["pred"], stride_pred=c["stride_pred"], pred_off=c["pred_off"], stride_rec=c["stride_dst"],
+                                                        rec_bytes=c["dst_bytes"], rec_off=c["dst_off"], res=c["coeffs"], ncbs=size)))
+    out.append(("deq_tail", "dequant", dict(src=wl.fill_i16(16 * 3 + 5, seed + 77, "full"), scale=51, shift=14)))
+    return out
+
+
+def me_cases(seed=900):
+    out = []
+    for (w, h, r, n) in ((16, 16, 8, 6), (64, 64, 8, 2), (64, 48, 6, 2), (8, 8, 7, 5), (32, 16, 5, 3)):
+        c = _me_case(w, h, r, n, seed + w + r)
+        out.append(("me_%dx%d_r%d" % (w, h, r), "me", c))
+    # ties: flat reference => every candidate costs the same => first in raster order (-r, -r)
+    c = _me_case(16, 16, 4, 3, seed + 5)
+    c["ref"][:] = 7
+    out.append(("me_ties", "me", c))
+    return out
+
+
+def _me_case(w, h, r, n, seed):
+    fw, fh = wl.SMALL_W, wl.SMALL_H
+    frames = wl.Plane.frames_for(n, w, h, fw, fh)
+    sp = wl.Plane(fw, fh, frames)
+    rp = wl.Plane(fw, fh, frames, border_x=16, border_y=16)
+    assert r <= 16
+    rng = np.random.default_rng(seed)
+    src = wl.fill_u8(sp.size, seed)
+    ref = wl.fill_u8(rp.size, seed + 1)
+    src_off = sp.tile_offsets(n, w, h)
+    ref_off = rp.tile_offsets(n, w, h)
+    # plant the source block somewhere in the window of half the blocks so the minimum is unique and interior
+    for i in range(0, n, 2):
+        dx, dy = rng.integers(-r, r + 1, 2)
+        blk = _dst_rows(src, sp.stride, src_off[i:i + 1], w, h)[0]
+        base = int(ref_off[i]) + dy * rp.stride + dx
+        for y in range(h):
+            ref[base + y * rp.stride: base + y * rp.stride + w] = blk[y]
+    return dict(src=src, stride_src=sp.stride, ref=ref, stride_ref=rp.stride, src_off=src_off.astype(np.uint32),
+                ref_off=ref_off.astype(np.uint32), w=w, h=h, range=r, n=n)
+
+
+ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
+                      dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases)
+
+
+# ------------------------------------------------------------------------------------- runners
+
+def _run_cpu(api, family, c):
+    """api = oracle.pyoracle module or a pyref.RefProc (same method names and arguments)."""
+    if family == "sad":
+        return (api.sad_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+    if family == "sad4":
+        return (api.sad_multiref_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+    if family == "ssd":
+        return (api.ssd_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+    if family == "pred_uni":
+        d = api.pred_uni_batch(c["taps"], c["dst_bytes"], c["stride_dst"], c["ref0"], c["stride_ref"], c["dst_off"], c["ref0_off"], c["frac0"], c["w"], c["h"])
+        return (_dst_rows(d, c["stride_dst"], c["dst_off"], c["w"], c["h"]),)
+    if family == "pred_bi":
+        d = api.pred_bi_batch(c["taps"], c["dst_bytes"], c["stride_dst"], c["ref0"], c["ref1"], c["stride_ref"], c["dst_off"], c["ref0_off"], c["ref1_off"],
+                              c["frac0"], c["frac1"], c["w"], c["h"])
+        return (_dst_rows(d, c["stride_dst"], c["dst_off"], c["w"], c["h"]),)
+    if family == "inverse":
+        s = 1 << c["log2n"]
+        d = api.inverse_transform_add_batch(c["tr_type"], c["log2n"], c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"], c["pred_off"], c["coeffs"])
+        return (_dst_rows(d, c["stride_dst"], c["dst_off"], s, s),)
+    if family == "dequant_inverse":
+        s = 1 << c["log2n"]
+        d = api.dequant_inverse_transform_add_batch(c["tr_type"], c["log2n"], c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"], c["pred_off"],
+                                                    c["coeffs"], c["scale"], c["shift"])
+        return (_dst_rows(d, c["stride_dst"], c["dst_off"], s, s),)
+    if family == "forward":
+        return (api.transform_batch(c["tr_type"], c["log2n"], c["src"], c["src_stride"], c["src_off"]),)
+    if family == "dequant":
+        return (api.quantize_inverse(c["src"], c["scale"], c["shift"]),)
+    if family == "quant":
+        q, cbf = api.quantize_batch(c["src"], c["scale"], c["shift"], c["offset"], c["n_per_block"])
+        return (q, cbf)
+    if family == "recon":
+        d = api.quantize_reconstruct_batch(c["rec_bytes"], c["stride_rec"], c["pred"], c["stride_pred"], c["rec_off"], c["pred_off"], c["res"], c["ncbs"])
+        return (_dst_rows(d, c["stride_rec"], c["rec_off"], c["ncbs"], c["ncbs"]),)
+    if family == "me":
+        return (api.me_full_search(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"], c["range"]),)
+    raise ValueError(family)
+
+
+def run_oracle(family, c):
+    from oracle import pyoracle
+    return _run_cpu(pyoracle, family, c)
+
+
+def run_reference(proc, family, c):
+    return _run_cpu(proc, family, c)
+
+
+def run_hip(family, c):
+    """The product path: device buffers via torch, compute via the C-ABI (hevcasm_amd.batch)."""
+    import torch
+    from hevcasm_amd import batch as B
+    u8, i16, off = B.u8, B.i16, B.off32
+
+    def plane(nbytes):
+        return torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def cpu(t):
+        torch.cuda.synchronize()
+        return t.cpu().numpy()
+
+    if family == "sad":
+        return (cpu(B.sad(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+    if family == "sad4":
+        return (cpu(B.sad_multiref(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+    if family == "ssd":
+        return (cpu(B.ssd(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+    if family == "pred_uni":
+        d = B.pred_uni(plane(c["dst_bytes"]), c["stride_dst"], u8(c["ref0"]), c["stride_ref"], off(c["dst_off"]), off(c["ref0_off"]), u8(c["frac0"]), c["taps"], c["w"], c["h"])
+        return _only_blocks(cpu(d), c["stride_dst"], c["dst_off"], c["w"], c["h"])
+    if family == "pred_bi":
+        d = B.pred_bi(plane(c["dst_bytes"]), c["stride_dst"], u8(c["ref0"]), u8(c["ref1"]), c["stride_ref"], off(c["dst_off"]), off(c["ref0_off"]), off(c["ref1_off"]),
+                      u8(c["frac0"]), u8(c["frac1"]), c["taps"], c["w"], c["h"])
+        return _only_blocks(cpu(d), c["stride_dst"], c["dst_off"], c["w"], c["h"])
+    if family == "inverse":
+        s = 1 << c["log2n"]
+        d = B.inverse_transform_add(plane(c["dst_bytes"]), c["stride_dst"], u8(c["pred"]), c["stride_pred"], off(c["dst_off"]), off(c["pred_off"]), i16(c["coeffs"]), c["tr_type"], c["log2n"])
+        return _only_blocks(cpu(d), c["stride_dst"], c["dst_off"], s, s)
+    if family == "dequant_inverse":
+        s = 1 << c["log2n"]
+        d = B.dequant_inverse_transform_add(plane(c["dst_bytes"]), c["stride_dst"], u8(c["pred"]), c["stride_pred"], off(c["dst_off"]), off(c["pred_off"]), i16(c["coeffs"]),
+                                            c["scale"], c["shift"], c["tr_type"], c["log2n"])
+        return _only_blocks(cpu(d), c["stride_dst"], c["dst_off"], s, s)
+    if family == "forward":
+        return (cpu(B.transform(i16(c["src"]), c["src_stride"], off(c["src_off"]), c["tr_type"], c["log2n"])),)
+    if family == "dequant":
+        return (cpu(B.quantize_inverse(i16(c["src"]), c["scale"], c["shift"])),)
+    if family == "quant":
+        q, cbf = B.quantize(i16(c["src"]), c["scale"], c["shift"], c["offset"], c["n_per_block"])
+        return (cpu(q), cpu(cbf))
+    if family == "recon":
+        d = B.quantize_reconstruct(plane(c["rec_bytes"]), c["stride_rec"], u8(c["pred"]), c["stride_pred"], off(c["rec_off"]), off(c["pred_off"]), i16(c["res"]), c["ncbs"])
+        return _only_blocks(cpu(d), c["stride_rec"], c["rec_off"], c["ncbs"], c["ncbs"])
+    if family == "me":
+        return (cpu(B.me_full_search(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"], c["range"])),)
+    raise ValueError(family)
+
+
+def _only_blocks(buf, stride, off, w, h):
+    """Blocks gathered from the plane, plus a flag that nothing OUTSIDE the blocks was written
+    (the plane started as zeros): the kernels must not over-write to the right as the
+    reference's SIMD kernels may (reference pred_inter.h:42)."""
+    blocks = _dst_rows(buf, stride, off, w, h)
+    mask = np.ones(buf.size, dtype=bool)
+    idx = off.astype(np.int64)[:, None, None] + np.arange(h)[None, :, None] * stride + np.arange(w)[None, None, :]
+    mask[idx.reshape(-1)] = False
+    assert not buf[mask].any(), "kernel wrote outside its destination blocks"
+    return (blocks,)
+
+
+def assert_same(name, got, want):
+    assert len(got) == len(want), name
+    for g, w in zip(got, want):
+        g, w = np.asarray(g), np.asarray(w)
+        assert g.shape == w.shape, (name, g.shape, w.shape)
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g != w)
+            raise AssertionError("%s: %d of %d elements differ; first at %s: got %s want %s" % (
+                name, len(bad), g.size, tuple(bad[0]), g[tuple(bad[0])], w[tuple(bad[0])]))

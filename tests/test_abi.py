@@ -1,0 +1,151 @@
+"""The drop-in boundary without a GPU: the C-ABI library loads, exports every symbol that
+include/*.h declares, keeps the reference's table layouts, selects by mask like the reference,
+and refuses (rather than emulates) GPU work when no gfx950 device is usable."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from hevcasm_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INCLUDE = os.path.join(ROOT, "include")
+PTR = C.sizeof(C.c_void_p)
+
+
+def _declared_functions():
+    names = set()
+    for fn in sorted(os.listdir(INCLUDE)):
+        text = open(os.path.join(INCLUDE, fn)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"typedef[^;{]*;", "", text)  # function typedefs are types, not symbols
+        # prototypes: "<ret> [HEVCASM_API] name(...);" and "hevcasm_test_function name;"
+        names |= set(re.findall(r"\b(hevcasm_hip_\w+)\s*\(", text))
+        names |= set(re.findall(r"HEVCASM_API\s+(hevcasm_\w+)\s*\(", text))
+        names |= set(re.findall(r"hevcasm_test_function\s+(hevcasm_\w+)\s*;", text))
+        names |= set(re.findall(r"^int (hevcasm_(?:test|count_average_cycles))\s*\(", text, flags=re.M))
+    return names
+
+
+def test_every_declared_symbol_is_exported():
+    declared = _declared_functions()
+    assert len(declared) >= 45, sorted(declared)
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if " T " in line}
+    missing = declared - exported
+    assert not missing, "declared in include/ but not exported: %s" % sorted(missing)
+    # and the ctypes tables used by tests/bench name exactly the declared hip entry points
+    assert set(capi.HIP_API) == {n for n in declared if n.startswith("hevcasm_hip_")}
+    assert set(capi.HOST_API) <= declared
+
+
+def test_library_loads_and_binds():
+    L = capi.lib()
+    assert L.hevcasm_hip_device_count() >= 0
+
+
+def test_table_layouts_match_reference_abi():
+    """Field counts of the caller-owned tables: a codec compiled against the
+    reference's headers indexes these structs directly."""
+    from_header = {
+        "sad": 12, "sad_multiref": 16 * 16 + 1, "ssd": 5, "pred_uni_8to8": 2 * 9 * 2 * 2, "pred_bi_8to8": 2 * 5 * 2,
+        "inverse_transform_add": 5, "transform": 5, "quantize_inverse": 1, "quantize": 1, "quantize_reconstruct": 4}
+    L = capi.lib()
+    for name, slots in from_header.items():
+        buf = (C.c_void_p * (slots + 2))()
+        guard = 0x5a5a5a5a5a5a5a5a
+        buf[slots] = guard
+        buf[slots + 1] = guard
+        fn = getattr(L, "hevcasm_populate_" + name)
+        if name == "inverse_transform_add":
+            fn(buf, capi.C_REF, 0)
+        else:
+            fn(buf, capi.C_REF)
+        assert buf[slots] == guard and buf[slots + 1] == guard, "%s: populate wrote past %d slots" % (name, slots)
+        filled = [buf[i] for i in range(slots)]
+        assert all(filled), "%s: C_REF must fill every slot" % name
+
+
+@pytest.mark.parametrize("name", ["sad", "sad_multiref", "ssd", "pred_uni_8to8", "pred_bi_8to8", "transform",
+                                  "quantize_inverse", "quantize", "quantize_reconstruct"])
+def test_selector_masks(name):
+    """NULL = unsupported (reference convention): x86 SIMD bits alone select nothing here;
+    C bits select the C path; the HIP bit selects different (per-block HIP) entries."""
+    L = capi.lib()
+    slots = 300
+
+    def pop(mask):
+        buf = (C.c_void_p * slots)()
+        getattr(L, "hevcasm_populate_" + name)(buf, mask)
+        return [buf[i] for i in range(slots)]
+
+    none = pop(capi.SSE2 | capi.AVX2)
+    assert not any(none)
+    c_ref, c_opt, hip = pop(capi.C_REF), pop(capi.C_OPT), pop(capi.HIP)
+    assert any(c_ref) and c_ref == c_opt
+    assert any(hip) and [bool(x) for x in hip] == [bool(x) for x in c_ref]
+    assert all(h != c for h, c in zip(hip, c_ref) if h)
+    assert pop(capi.C_REF | capi.HIP) == hip  # highest instruction set wins, as in the reference
+
+
+def test_get_sad_multiref_ways():
+    """hevcasm_get_sad_multiref returns NULL for ways != 4 (reference sad.h:106): checked through
+    a tiny C program compiled against our headers."""
+    src = r'''
+#include "sad.h"
+#include "pred_inter.h"
+#include "residual_decode.h"
+#include "quantize.h"
+#include "ssd.h"
+int main(void) {
+	hevcasm_table_sad_multiref t; hevcasm_table_sad s; hevcasm_table_pred_uni_8to8 u; hevcasm_table_pred_bi_8to8 b;
+	if (hevcasm_get_sad_multiref(&t, 3, 16, 16)) return 1;
+	if (hevcasm_get_sad_multiref(&t, 4, 64, 64) != &t.lookup[15][15]) return 2;
+	if (hevcasm_get_sad(&s, 16, 16) != &s.sad16x16) return 3;
+	if (hevcasm_get_sad(&s, 48, 64) != &s.sadGeneric) return 4;
+	if (hevcasm_get_pred_uni_8to8(&u, 8, 64, 64, 3, 0) != &u.p[1][8][1][0]) return 5;
+	if (hevcasm_get_pred_uni_8to8(&u, 4, 2, 4, 0, 7) != &u.p[0][1][0][1]) return 6;
+	if (hevcasm_get_pred_bi_8to8(&b, 8, 48, 64, 0, 0, 0, 2) != &b.p[1][3][1]) return 7;
+	if (HEVCASM_RECT(16, 8) != 0x1008) return 8;
+	if (HEVCASM_HIP != 512 || HEVCASM_AVX2 != 256 || HEVCASM_INSTRUCTION_SET_COUNT != 10) return 9;
+	return 0;
+}'''
+    exe = "/tmp/hevcasm_abi_probe"
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I", INCLUDE, "-x", "c", "-", "-o", exe], input=src, text=True, check=True)
+    assert subprocess.run([exe]).returncode == 0
+
+
+def test_no_gpu_means_refusal_not_fallback():
+    """Without a usable gfx950 device every batch entry point returns ENODEV and the mask has no
+    HIP bit.  (On the GPU box this test checks the opposite side: the bit is present.)"""
+    L = capi.lib()
+    mask = L.hevcasm_instruction_set_support()
+    assert mask & capi.C_REF and mask & capi.C_OPT
+    if L.hevcasm_hip_available():
+        assert mask & capi.HIP
+        return
+    assert not mask & capi.HIP
+    assert L.hevcasm_hip_sad_batch(None, 0, None, 0, None, None, None, capi.rect(16, 16), 1, None) == capi.ENODEV
+    assert L.hevcasm_hip_quantize_inverse(None, None, 1, 1, 16, None) == capi.ENODEV
+    p = C.c_void_p()
+    assert L.hevcasm_hip_malloc(C.byref(p), 16) == capi.ENODEV
+    assert b"gfx950" in L.hevcasm_hip_last_error()
+
+
+def test_product_never_touches_the_oracle():
+    """Nothing under hevcasm_amd/ or include/ may import, link or mention oracle/."""
+    bad = []
+    for base in ("hevcasm_amd", "include"):
+        for d, _, files in os.walk(os.path.join(ROOT, base)):
+            if os.sep + "build" in d or d.endswith(os.sep + "lib"):
+                continue
+            for f in files:
+                if f.endswith((".py", ".c", ".h", ".hip", ".hpp", "Makefile")):
+                    text = open(os.path.join(d, f)).read()
+                    if re.search(r"liboracle|hevc_oracle|import oracle|from oracle|orc_\w+\(|refdrv", text):
+                        bad.append(os.path.join(d, f))
+    assert not bad, bad
+    deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in deps

@@ -1,0 +1,123 @@
+"""The library's own C path (HEVCASM_C_REF / C_OPT table entries, hevcasm_amd/csrc/host/cpath.c)
+against the oracle, through the reference's calling pattern: populate a table, fetch the slot,
+call the function pointer per block.  CPU only."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cases
+from hevcasm_amd import capi
+
+PD = C.c_ssize_t
+VP = C.c_void_p
+
+
+def _slot(populate, nslots, index, mask=capi.C_REF, extra=()):
+    buf = (C.c_void_p * nslots)()
+    getattr(capi.lib(), populate)(buf, mask, *extra)
+    assert buf[index], "NULL table entry"
+    return buf[index]
+
+
+def _ptr(a, byte_off=0):
+    return a.ctypes.data + int(byte_off)
+
+
+def _sad_slot_index(w, h):
+    order = [(64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8), (8, 16), (8, 8), (8, 4)]
+    return order.index((w, h)) if (w, h) in order else 11
+
+
+def test_sad_and_multiref_and_ssd(oracle_lib):
+    for name, family, c in cases.sad_cases(n=12) + cases.ssd_cases(n=12):
+        w, h, n = c["w"], c["h"], c["n"]
+        src, ref = np.ascontiguousarray(c["src"]), np.ascontiguousarray(c["ref"])
+        want = cases.run_oracle(family, c)[0]
+        if family == "sad":
+            f = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD, C.c_uint32)(_slot("hevcasm_populate_sad", 12, _sad_slot_index(w, h)))
+            got = [f(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, c["ref_off"][i]), c["stride_ref"], capi.rect(w, h)) for i in range(n)]
+            assert np.array_equal(np.array(got), want), name
+        elif family == "sad4":
+            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP, C.c_uint32)(_slot("hevcasm_populate_sad_multiref", 257, ((w >> 2) - 1) * 16 + (h >> 2) - 1))
+            for i in range(n):
+                refs = (C.c_void_p * 4)(*[_ptr(ref, c["ref_off"][4 * i + k]) for k in range(4)])
+                out = (C.c_int * 4)()
+                f(_ptr(src, c["src_off"][i]), c["stride_src"], refs, c["stride_ref"], out, capi.rect(w, h))
+                assert list(out) == list(want[i]), name
+        else:
+            if w != h:
+                continue
+            f = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD, C.c_int, C.c_int)(_slot("hevcasm_populate_ssd", 5, int(np.log2(w)) - 2))
+            got = [f(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, c["ref_off"][i]), c["stride_ref"], w, h) for i in range(n)]
+            assert np.array_equal(np.array(got), want), name
+
+
+def test_pred_uni_and_bi(oracle_lib):
+    for name, family, c in cases.pred_uni_cases(n=6) + cases.pred_bi_cases(n=4):
+        taps, w, h, n = c["taps"], c["w"], c["h"], c["n"]
+        want = cases.run_oracle(family, c)[0]
+        dst = np.zeros(c["dst_bytes"], dtype=np.uint8)
+        ref0 = np.ascontiguousarray(c["ref0"])
+        for i in range(n):
+            x0, y0 = int(c["frac0"][i]) & 15, int(c["frac0"][i]) >> 4
+            if family == "pred_uni":
+                idx = (((taps // 4 - 1) * 9 + (w + taps - 1) // taps) * 2 + (1 if x0 else 0)) * 2 + (1 if y0 else 0)
+                f = C.CFUNCTYPE(None, VP, PD, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_uni_8to8", 72, idx))
+                f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(ref0, c["ref0_off"][i]), c["stride_ref"], w, h, x0, y0)
+            else:
+                ref1 = np.ascontiguousarray(c["ref1"])
+                x1, y1 = int(c["frac1"][i]) & 15, int(c["frac1"][i]) >> 4
+                idx = ((taps // 4 - 1) * 5 + (w + 2 * taps - 1) // (2 * taps)) * 2 + (1 if (x0 or y0 or x1 or y1) else 0)
+                f = C.CFUNCTYPE(None, VP, PD, VP, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_bi_8to8", 20, idx))
+                f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(ref0, c["ref0_off"][i]), _ptr(ref1, c["ref1_off"][i]), c["stride_ref"], w, h, x0, y0, x1, y1)
+        got = cases._dst_rows(dst, c["stride_dst"], c["dst_off"], w, h)
+        cases.assert_same(name, (got,), (want,))
+
+
+def test_transforms(oracle_lib):
+    for name, family, c in cases.inverse_cases(n=10) + cases.forward_cases(n=10):
+        tr, lg, n = c["tr_type"], c["log2n"], c["n"]
+        size = 1 << lg
+        idx = 0 if tr else lg - 1
+        want = cases.run_oracle(family, c)[0]
+        if family == "inverse":
+            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP)(_slot("hevcasm_populate_inverse_transform_add", 5, idx, extra=(0,)))
+            dst = np.zeros(c["dst_bytes"], dtype=np.uint8)
+            pred, coeffs = np.ascontiguousarray(c["pred"]), np.ascontiguousarray(c["coeffs"])
+            for i in range(n):
+                f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(pred, c["pred_off"][i]), c["stride_pred"], _ptr(coeffs, 2 * size * size * i))
+            cases.assert_same(name, (cases._dst_rows(dst, c["stride_dst"], c["dst_off"], size, size),), (want,))
+        else:
+            f = C.CFUNCTYPE(None, VP, VP, PD)(_slot("hevcasm_populate_transform", 5, idx))
+            src = np.ascontiguousarray(c["src"])
+            out = np.zeros(n * size * size, dtype=np.int16)
+            for i in range(n):
+                f(_ptr(out, 2 * size * size * i), _ptr(src, 2 * int(c["src_off"][i])), c["src_stride"])
+            cases.assert_same(name, (out,), (want,))
+
+
+def test_quant_family(oracle_lib):
+    for name, family, c in cases.quant_cases():
+        want = cases.run_oracle(family, c)
+        if family == "dequant":
+            f = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize_inverse", 1, 0))
+            src = np.ascontiguousarray(c["src"])
+            out = np.zeros_like(src)
+            f(_ptr(out), _ptr(src), c["scale"], c["shift"], src.size)
+            cases.assert_same(name, (out,), want)
+        elif family == "quant":
+            f = C.CFUNCTYPE(C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize", 1, 0))
+            src = np.ascontiguousarray(c["src"])
+            out = np.zeros_like(src)
+            npb = c["n_per_block"]
+            cbf = [f(_ptr(out, 2 * npb * i), _ptr(src, 2 * npb * i), c["scale"], c["shift"], c["offset"], npb) for i in range(src.size // npb)]
+            cases.assert_same(name, (out, np.array(cbf, dtype=np.int32)), want)
+        else:
+            size = c["ncbs"]
+            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP, C.c_int)(_slot("hevcasm_populate_quantize_reconstruct", 4, int(np.log2(size)) - 2))
+            rec = np.zeros(c["rec_bytes"], dtype=np.uint8)
+            pred, res = np.ascontiguousarray(c["pred"]), np.ascontiguousarray(c["res"])
+            for i in range(len(c["rec_off"])):
+                f(_ptr(rec, c["rec_off"][i]), c["stride_rec"], _ptr(pred, c["pred_off"][i]), c["stride_pred"], _ptr(res, 2 * size * size * i), size)
+            cases.assert_same(name, (cases._dst_rows(rec, c["stride_rec"], c["rec_off"], size, size),), want)

@@ -1,0 +1,66 @@
+"""BASELINE.json config #1: the library's own hevcasm_test SAD self-test on the CPU C path
+(plumbing, no GPU): reference grammar, 23 partitions incl. 16x16, no -MISMATCH, zero errors.
+Also the reference's OWN self-test output (through oracle/_ref/refdrv) has the same rows."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_DRIVER = r'''
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from hevcasm_amd import capi
+L = capi.lib()
+e = C.c_int(0)
+for f in %r:
+    getattr(L, "hevcasm_test_" + f)(C.byref(e), capi.C_REF | capi.C_OPT)
+L.hevcasm_print_instruction_set_support(None, 0) if False else None
+print("ERRORS", e.value)
+'''
+
+ROW = re.compile(r"^\t(\d+)x(\d+): C_OPT:(\d+)$")
+
+
+def _run(families):
+    r = subprocess.run([sys.executable, "-c", _DRIVER % (ROOT, tuple(families))], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_sad_selftest_grammar_and_zero_errors():
+    out = _run(["sad"])
+    assert "hevcasm_sad - Sum of Absolute Differences" in out
+    rows = [ROW.match(l) for l in out.splitlines() if l.startswith("\t")]
+    assert all(rows) and len(rows) == 23, out
+    assert any(m.group(1) == "16" and m.group(2) == "16" for m in rows)
+    assert "MISMATCH" not in out and "ERRORS 0" in out
+
+
+def test_quick_families_zero_errors():
+    out = _run(["sad_multiref", "ssd", "quantize_inverse", "quantize", "quantize_reconstruct", "pred_uni", "pred_bi"])
+    assert "MISMATCH" not in out and "ERRORS 0" in out
+    assert out.count("C_OPT:") == 23 + 5 + 4 + 4 + 4 + 24 * 8 + 22 * 4
+
+
+def test_same_rows_as_the_reference_selftest(tmp_path, refproc):
+    """The reference's hevcasm_test_sad (its own C files) prints the same partitions, in the same
+    grammar, as ours."""
+    path = str(tmp_path / "ref_selftest.txt")
+    assert refproc.selftest(1, path) == 0
+    ref_rows = [ROW.match(l).groups()[:2] for l in open(path).read().splitlines() if l.startswith("\t")]
+    ours = [ROW.match(l).groups()[:2] for l in _run(["sad"]).splitlines() if l.startswith("\t")]
+    assert ref_rows == ours
+
+
+def test_executable_reports_instruction_sets():
+    exe = os.path.join(ROOT, "hevcasm_amd", "lib", "hevcasm")
+    assert os.path.exists(exe)
+    # the full self-test takes minutes on the C path; only check that it starts and prints the header
+    p = subprocess.Popen([exe], stdout=subprocess.PIPE, text=True, env=dict(os.environ, HEVCASM_DISABLE_HIP="1"))
+    head = [p.stdout.readline() for _ in range(14)]
+    p.kill()
+    p.wait()
+    text = "".join(head)
+    assert "HEVCasm self test" in text and "[x] C_REF" in text and "[ ] HIP" in text
