@@ -4,13 +4,13 @@
 // hevcasm_sad_multiref 4-way (sad.h:95, sad.c:101-121) and hevcasm_ssd (ssd.h:53, ssd.c:43-55).
 //
 // Layout: frames stay as the codec has them (row-strided u8 planes in HBM); a block is a base
-// pointer + u32 byte offset.  Mapping: each block row of W bytes is cut into chunks of
-// C = 16 / 8 / 4 bytes (the widest that divides W); LPB = W / C adjacent lanes own one block and
-// every lane walks its chunk down all H rows.  A wave therefore covers 64 / LPB blocks, and when
-// consecutive blocks are horizontal neighbours in the frame (the usual case) one wave-wide load
-// instruction reads one contiguous run of up to 1 KiB of a frame row: fully coalesced, no LDS.
-// Reference blocks sit at arbitrary byte alignment (motion vectors); the loads carry no
-// alignment promise and the hardware splits the few that straddle a line.
+// pointer + u32 byte offset.  Mapping: each block row of W bytes is cut into chunks of C = 16 / 8 /
+// 4 bytes, one lane per chunk, and R rows of the block are in flight per instruction, so
+// (W / C) * R adjacent lanes own one block (see Tiling below for the measurements behind the
+// choice) and a wave covers 64 / LPB blocks.  Consecutive blocks are normally horizontal
+// neighbours in the frame, so the lanes of a wave read a few long runs of a few frame rows: no
+// LDS staging is needed.  Reference blocks sit at arbitrary byte alignment (motion vectors);
+// the loads carry no alignment promise (byte misalignment measured free on gfx950).
 // Arithmetic: v_sad_u8 accumulates 4 byte differences per instruction; SSD uses
 // sum(a-b)^2 = sum a^2 + sum b^2 - 2 sum ab with three v_dot4_u32_u8 (exact: every partial sum
 // is below 2^30 for blocks up to 64x64).  The LPB partial sums are combined with wave shuffles.
@@ -20,11 +20,48 @@
 
 namespace hevc {
 
-template <int W> struct Tiling
+// Lane mapping of one W x H block: LPR = W / C lanes side by side cover a row, R such rows are
+// in flight per instruction, so LPB = LPR * R lanes own a block and lane (r, c) walks rows
+// r, r + R, r + 2R, ...  A wave holds 64 / LPB blocks.
+//
+// Why not simply one lane per block (R = 1)?  With per-block motion vectors the lanes of a wave
+// then read 64 different frame rows per instruction and the vector L1 (TCP) becomes the limit:
+// measured on MI355X, 1 Mi 16x16 blocks, displacements uniform in +-7: R = 1 -> 3.0 TB/s, 6.4x
+// the TCP accesses of the aligned case (profiles/r01_sad16_counters.txt).  Keeping a block's
+// rows together (8-32 lanes per block) lets neighbouring lanes hit the same lines:
+// C = 8, R = 4 -> 4.7 TB/s at 16x16; C = 16, R = 8 -> 5.7 TB/s at 32x32 and 6.2 TB/s at 64x64
+// (gpurun sweep, tools/explore_tiling.py).  Coherent motion is within 10 % of its best mapping.
+template <int W, int C, int R> struct Tiling
 {
-	static constexpr int C = (W % 16 == 0) ? 16 : ((W % 8 == 0) ? 8 : 4);  // chunk bytes per lane per row
-	static constexpr int LPB = W / C;                                       // lanes per block
-	static constexpr int BPW = kWave / LPB;                                 // blocks per wave
+	static constexpr int LPR = W / C;        // lanes per row
+	static constexpr int LPB = LPR * R;      // lanes per block
+	static constexpr int BPW = kWave / LPB;  // blocks per wave
+	static_assert(LPB <= kWave, "a block must fit in one wave");
+};
+
+// Chunk bytes and rows in flight for a block width.  Among R = 8, 4, 2, 1 that fit a wave, take the
+// one with the best (lane utilisation x row-locality weight); narrow blocks stop at R = 4.
+constexpr int tiling_score(int lpr, int r)
+{
+	const int lpb = lpr * r;
+	if (lpb > kWave) return 0;
+	const int used = (kWave / lpb) * lpb;                       // busy lanes out of 64
+	const int weight = r >= 4 ? 100 : (r == 2 ? 85 : 70);      // measured: R = 1 loses 30-40 % on divergent motion
+	return used * weight;
+}
+constexpr int best_rows(int lpr, int max_r)
+{
+	int best = 1, best_score = 0;
+	for (int r = max_r; r >= 1; r /= 2)
+		if (tiling_score(lpr, r) > best_score) { best = r; best_score = tiling_score(lpr, r); }
+	return best;
+}
+template <int W> struct Plan
+{
+	static constexpr int C = (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
+	static constexpr int LPR = W / C;
+	static constexpr int R_PREF = best_rows(LPR, W >= 32 ? 8 : 4);   // used when it divides H
+	static constexpr int R_SAFE = best_rows(LPR, 4);                  // H is always a multiple of 4
 };
 
 enum { OP_SAD = 0, OP_SSD = 1 };
@@ -53,36 +90,42 @@ template <int C, int OP> struct Acc
 	__device__ __forceinline__ uint32_t value() const { return OP == OP_SAD ? a : a - 2u * b; }
 };
 
-// Sum `v` over the LPB consecutive lanes of a block; the result is valid in the block's first lane.
-template <int LPB> __device__ __forceinline__ uint32_t reduce_lanes(uint32_t v)
+// Sum `v` over the LPR x R lanes of a block (lane j = r * LPR + c); valid in the block's lane 0.
+template <int LPR, int R> __device__ __forceinline__ uint32_t reduce_block(uint32_t v)
 {
-	if (LPB == 1) return v;
+	constexpr int LPB = LPR * R;
 	if ((LPB & (LPB - 1)) == 0)
 	{
 #pragma unroll
 		for (int d = LPB / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
 		return v;
 	}
+	// rows first (R is a power of two), then the LPR chunks of row 0
+#pragma unroll
+	for (int d = R / 2; d >= 1; d >>= 1) v += __shfl_down(v, d * LPR, kWave);
 	uint32_t t = v;
 #pragma unroll
-	for (int j = 1; j < LPB; ++j) t += __shfl_down(v, j, kWave);
+	for (int c = 1; c < LPR; ++c) t += __shfl_down(v, c, kWave);
 	return t;
 }
 
-template <int W, int WAYS, int OP>
+// U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
+template <int W, int C, int R, int U, int WAYS, int OP>
 __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
 	int *__restrict__ out, int H, uint32_t n_blocks)
 {
-	typedef Tiling<W> T;
-	constexpr int C = T::C, LPB = T::LPB, BPW = T::BPW;
+	typedef Tiling<W, C, R> T;
+	constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t sub = lane / LPB, chunk = lane - sub * LPB;
+	const uint32_t sub = lane / LPB, j = lane - sub * LPB;
+	const uint32_t row0 = j / LPR, chunk = j - row0 * LPR;
+	const ptrdiff_t step_src = R * stride_src, step_ref = R * stride_ref;
 
 	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
 	// block so that every lane executes the same loads and shuffles; only real leaders store.
@@ -90,38 +133,43 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const bool live = sub < (uint32_t)BPW && blk < n_blocks;
 	if (blk >= n_blocks) blk = n_blocks - 1;
 
-	const uint8_t *ps = src + src_off[blk] + chunk * C;
+	// descriptor loads first: independent, one memory round trip
+	const uint32_t so = src_off[blk];
+	uint32_t ro[WAYS];
+#pragma unroll
+	for (int k = 0; k < WAYS; ++k) ro[k] = ref_off[(size_t)blk * WAYS + k];
+
+	const uint8_t *ps = src + so + (ptrdiff_t)row0 * stride_src + chunk * C;
 	const uint8_t *pr[WAYS];
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) pr[k] = ref + ref_off[(size_t)blk * WAYS + k] + chunk * C;
+	for (int k = 0; k < WAYS; ++k) pr[k] = ref + ro[k] + (ptrdiff_t)row0 * stride_ref + chunk * C;
 
 	Acc<C, OP> acc[WAYS];
 
-	// H is a multiple of 4: four rows per trip keeps 4 * (1 + WAYS) independent loads in flight per lane.
-	for (int y = 0; y < H; y += 4)
+	for (int y = 0; y < H; y += R * U)
 	{
-		Chunk<C> s[4], r[4][WAYS];
+		Chunk<C> s[U], r[U][WAYS];
 #pragma unroll
-		for (int j = 0; j < 4; ++j)
+		for (int u = 0; u < U; ++u)
 		{
-			s[j].load(ps + j * stride_src);
+			s[u].load(ps + u * step_src);
 #pragma unroll
-			for (int k = 0; k < WAYS; ++k) r[j][k].load(pr[k] + j * stride_ref);
+			for (int k = 0; k < WAYS; ++k) r[u][k].load(pr[k] + u * step_ref);
 		}
 #pragma unroll
-		for (int j = 0; j < 4; ++j)
+		for (int u = 0; u < U; ++u)
 #pragma unroll
-			for (int k = 0; k < WAYS; ++k) acc[k].add(s[j], r[j][k]);
-		ps += 4 * stride_src;
+			for (int k = 0; k < WAYS; ++k) acc[k].add(s[u], r[u][k]);
+		ps += U * step_src;
 #pragma unroll
-		for (int k = 0; k < WAYS; ++k) pr[k] += 4 * stride_ref;
+		for (int k = 0; k < WAYS; ++k) pr[k] += U * step_ref;
 	}
 
 	uint32_t total[WAYS];
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) total[k] = reduce_lanes<LPB>(acc[k].value());
+	for (int k = 0; k < WAYS; ++k) total[k] = reduce_block<LPR, R>(acc[k].value());
 
-	if (live && chunk == 0)
+	if (live && j == 0)
 	{
 		if (WAYS == 4)
 		{
@@ -137,15 +185,35 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	}
 }
 
-template <int W, int WAYS, int OP>
-static int launch_w(const uint8_t *src, ptrdiff_t ss, const uint8_t *ref, ptrdiff_t sr,
-		const uint32_t *so, const uint32_t *ro, int *out, int H, size_t n, hipStream_t st)
+struct Args
 {
-	constexpr int blocks_per_wg = Tiling<W>::BPW * (kThreads / kWave);
-	const uint32_t grid = ceil_div(n, blocks_per_wg);
-	hipLaunchKernelGGL((block_cost_kernel<W, WAYS, OP>), dim3(grid), dim3(kThreads), 0, st,
-			src, ss, ref, sr, so, ro, out, H, (uint32_t)n);
+	const uint8_t *src; ptrdiff_t ss; const uint8_t *ref; ptrdiff_t sr;
+	const uint32_t *so; const uint32_t *ro; int *out; int H; size_t n; hipStream_t st;
+};
+
+template <int W, int C, int R, int U, int WAYS, int OP> static int launch_cfg(const Args &a)
+{
+	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
+	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
+	hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP>), dim3(grid), dim3(kThreads), 0, a.st,
+			a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
 	return launch_status("block_cost_kernel");
+}
+
+// rows per lane = H / R; take the deepest unroll that divides it
+template <int W, int C, int R, int WAYS, int OP> static int launch_rows(const Args &a)
+{
+	const int rows_per_lane = a.H / R;
+	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP>(a);
+	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP>(a);
+	return launch_cfg<W, C, R, 1, WAYS, OP>(a);
+}
+
+template <int W, int WAYS, int OP> static int launch_w(const Args &a)
+{
+	typedef Plan<W> P;
+	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP>(a);
+	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP>(a);
 }
 
 template <int WAYS, int OP>
@@ -158,10 +226,10 @@ static int launch(const uint8_t *src, ptrdiff_t ss, const uint8_t *ref, ptrdiff_
 	if (n == 0) return 0;
 	if (n > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!src || !ref || !so || !ro || !out) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	hipStream_t st = as_stream(stream);
+	const Args a = { src, ss, ref, sr, so, ro, out, H, n, as_stream(stream) };
 	switch (W)
 	{
-#define CASE(w) case w: return launch_w<w, WAYS, OP>(src, ss, ref, sr, so, ro, out, H, n, st);
+#define CASE(w) case w: return launch_w<w, WAYS, OP>(a);
 		CASE(4) CASE(8) CASE(12) CASE(16) CASE(20) CASE(24) CASE(28) CASE(32)
 		CASE(36) CASE(40) CASE(44) CASE(48) CASE(52) CASE(56) CASE(60) CASE(64)
 #undef CASE
