@@ -64,9 +64,11 @@ class SizeBatch:
         ref_frame_bytes = (wl.FRAME_W + 32) * (wl.FRAME_H + 16)
         max_frames = OFFSET_WINDOW // ref_frame_bytes
         max_blocks = max_frames * per_frame
+        n_chunks = -(-n_blocks // max_blocks)
+        per_chunk = -(-n_blocks // n_chunks)          # equal launches, each inside the 4 GiB offset window
         done = 0
         while done < n_blocks:
-            m = min(n_blocks - done, max_blocks)
+            m = min(n_blocks - done, per_chunk)
             c = wl.sad_case(w, h, m, seed + done, ways=4, frame=(wl.FRAME_W, wl.FRAME_H), device=device)
             ro4 = B.off32(c["ref_off"])
             self.chunks.append(dict(
@@ -206,6 +208,17 @@ def main():
         del r["total_ms"]
     head = [r for r in detail if r["kernel"] == "sad" and r["size"] == "16x16"]
 
+    # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/traffic.json, made by
+    # tools/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f).get("%s %s" % (dom["kernel"], dom["size"]))
+        if t and t.get("blocks_per_launch") == dom_d["blocks"] // dom_d["launches"]:
+            traffic = t["hbm_bytes_per_launch"]
+    except (OSError, ValueError):
+        pass
+
     blocks_per_step = sum(c["n"] for (_, _, c) in launches)
     value = world * blocks_per_step * args.steps / elapsed / 1e6
 
@@ -223,7 +236,7 @@ def main():
                        "blocks_per_step_per_gpu": blocks_per_step, "launches_per_step": len(launches), "parallelism": "batch split x%d, no collectives" % world,
                        "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
             "cpu_baseline": cpu,
             "headline": {"sad_16x16_single_ref": head[0] if head else None},

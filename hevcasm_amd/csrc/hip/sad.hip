@@ -27,7 +27,7 @@ namespace hevc {
 // Why not simply one lane per block (R = 1)?  With per-block motion vectors the lanes of a wave
 // then read 64 different frame rows per instruction and the vector L1 (TCP) becomes the limit:
 // measured on MI355X, 1 Mi 16x16 blocks, displacements uniform in +-7: R = 1 -> 3.0 TB/s, 6.4x
-// the TCP accesses of the aligned case (profiles/r01_sad16_counters.txt).  Keeping a block's
+// the TCP accesses of the aligned case (profiles/r01_sad16_counters_R1_mapping.txt).  Keeping a block's
 // rows together (8-32 lanes per block) lets neighbouring lanes hit the same lines:
 // C = 8, R = 4 -> 4.7 TB/s at 16x16; C = 16, R = 8 -> 5.7 TB/s at 32x32 and 6.2 TB/s at 64x64
 // (gpurun sweep, tools/explore_tiling.py).  Coherent motion is within 10 % of its best mapping.

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Throughput of the non-SAD hot-path families on one MI355X (BASELINE.json configs #3, #4, #5 and
+the quantiser): Mblocks/s and algorithmic GB/s (SURVEY.md 8d byte counts) per kernel, measured
+with HIP events over cold, device-resident inputs.  Prints one JSON line per measurement.
+
+    python tools/bench_families.py [pred] [transform] [quant] [me]
+"""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hevcasm_amd import batch as B, workload as wl
+
+PEAK = 8000.0
+
+
+def timed(fn, reps=5):
+    ts = []
+    for i in range(reps + 1):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(i); e1.record(); torch.cuda.synchronize()
+        if i: ts.append(e0.elapsed_time(e1))
+    return float(np.median(ts))
+
+
+def report(name, n, bytes_per_block, ms, **kw):
+    gbs = n * bytes_per_block / (ms * 1e-3) / 1e9
+    print(json.dumps(dict(kernel=name, blocks=n, ms=round(ms, 4), mblocks_per_s=round(n / ms / 1e3, 1), bytes_per_block=bytes_per_block,
+                          algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK, 4), **kw)), flush=True)
+
+
+def bench_pred(frames=64):
+    """Config #3: 1920x1080 luma tiled by each PU size (chroma planes 960x540, 4-tap), all phases,
+    `frames` frames per launch so that the launch is far above the launch floor."""
+    for taps, fw, fh in ((8, 1920, 1080), (4, 960, 540)):
+        for (w, h) in wl.PU_SIZES:
+            pw, ph = w * taps // 8, h * taps // 8
+            n = (fw // pw) * (fh // ph) * frames
+            for bi in (False, True):
+                if bi and (w, h) in ((8, 4), (4, 8)):
+                    continue
+                # distinct inputs per repetition so that nothing is served from the Infinity Cache
+                cs = [wl.pred_case(taps, pw, ph, n, 50 + i, bi=bi, frame=(fw, fh), device="cuda") for i in range(3)]
+                devs = []
+                for c in cs:
+                    d = dict(dst=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), dst_off=B.off32(c["dst_off"]))
+                    for r in range(2 if bi else 1):
+                        d["ref%d" % r] = c["ref%d" % r]; d["ref%d_off" % r] = B.off32(c["ref%d_off" % r]); d["frac%d" % r] = B.u8(c["frac%d" % r])
+                    devs.append(d)
+                c0 = cs[0]
+
+                def run(i):
+                    d = devs[i % len(devs)]
+                    if bi:
+                        B.pred_bi(d["dst"], c0["stride_dst"], d["ref0"], d["ref1"], c0["stride_ref"], d["dst_off"], d["ref0_off"], d["ref1_off"], d["frac0"], d["frac1"], taps, pw, ph)
+                    else:
+                        B.pred_uni(d["dst"], c0["stride_dst"], d["ref0"], c0["stride_ref"], d["dst_off"], d["ref0_off"], d["frac0"], taps, pw, ph)
+                ms = timed(run, reps=4)
+                refs = 2 if bi else 1
+                report("pred_%s_%dtap" % ("bi" if bi else "uni", taps), n, refs * (pw + taps - 1) * (ph + taps - 1) + pw * ph + 4 * (1 + refs) + refs, ms, size="%dx%d" % (pw, ph), frames=frames)
+                del cs, devs
+                torch.cuda.empty_cache()
+
+
+def bench_transform(coeffs_per_launch=1 << 26):
+    for tr, lg in wl.TRANSFORMS:
+        size = 1 << lg
+        n = coeffs_per_launch >> (2 * lg)
+        tag = "dst4" if tr else "dct%d" % size
+        cs = [wl.inverse_case(tr, lg, n, 70 + i, "natural", frame=(wl.FRAME_W, wl.FRAME_H)) for i in range(2)]
+        devs = [dict(pred=B.u8(c["pred"]), pred_off=B.off32(c["pred_off"]), dst=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"),
+                     dst_off=B.off32(c["dst_off"]), coeffs=B.i16(c["coeffs"])) for c in cs]
+        c0 = cs[0]
+        ms = timed(lambda i: B.inverse_transform_add(devs[i % 2]["dst"], c0["stride_dst"], devs[i % 2]["pred"], c0["stride_pred"], devs[i % 2]["dst_off"], devs[i % 2]["pred_off"], devs[i % 2]["coeffs"], tr, lg))
+        report("inverse_transform_add", n, 4 * size * size + 8, ms, size=tag)
+        ms = timed(lambda i: B.dequant_inverse_transform_add(devs[i % 2]["dst"], c0["stride_dst"], devs[i % 2]["pred"], c0["stride_pred"], devs[i % 2]["dst_off"], devs[i % 2]["pred_off"], devs[i % 2]["coeffs"], 51, 14, tr, lg))
+        report("dequant_inverse_transform_add", n, 4 * size * size + 8, ms, size=tag)
+        fs = [wl.forward_case(tr, lg, n, 80 + i, frame=(wl.FRAME_W, wl.FRAME_H)) for i in range(2)]
+        fd = [dict(src=B.i16(f["src"]), off=B.off32(f["src_off"]), out=torch.empty(n * size * size, dtype=torch.int16, device="cuda")) for f in fs]
+        ms = timed(lambda i: B.transform(fd[i % 2]["src"], fs[0]["src_stride"], fd[i % 2]["off"], tr, lg, out=fd[i % 2]["out"]))
+        report("transform", n, 4 * size * size + 4, ms, size=tag)
+        del cs, devs, fs, fd
+        torch.cuda.empty_cache()
+
+
+def bench_quant(n=1 << 27):
+    srcs = [wl.fill_i16_device(n, 90 + i, "cuda") for i in range(2)]
+    outs = [torch.empty_like(s) for s in srcs]
+    ms = timed(lambda i: B.quantize_inverse(srcs[i % 2], 51, 14, out=outs[i % 2]))
+    report("quantize_inverse", n // 256, 4 * 256, ms, size="flat (per 16x16)")
+    for npb in (16, 64, 256, 1024):
+        cbf = torch.empty(n // npb, dtype=torch.int32, device="cuda")
+        ms = timed(lambda i: B.quantize(srcs[i % 2], 51, 20, 14, npb, out=outs[i % 2], cbf=cbf))
+        report("quantize", n // npb, 4 * npb + 4, ms, size="%d coeffs" % npb)
+    for lg in (2, 3, 4, 5):
+        size = 1 << lg
+        nb = (1 << 26) >> (2 * lg)
+        cs = [wl.inverse_case(0, lg, nb, 95 + i, "residual9", frame=(wl.FRAME_W, wl.FRAME_H)) for i in range(2)]
+        devs = [dict(pred=B.u8(c["pred"]), pred_off=B.off32(c["pred_off"]), rec=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"),
+                     rec_off=B.off32(c["dst_off"]), res=B.i16(c["coeffs"])) for c in cs]
+        c0 = cs[0]
+        ms = timed(lambda i: B.quantize_reconstruct(devs[i % 2]["rec"], c0["stride_dst"], devs[i % 2]["pred"], c0["stride_pred"], devs[i % 2]["rec_off"], devs[i % 2]["pred_off"], devs[i % 2]["res"], size))
+        report("quantize_reconstruct", nb, 4 * size * size + 8, ms, size="%dx%d" % (size, size))
+        del cs, devs
+        torch.cuda.empty_cache()
+
+
+def bench_me():
+    """Config #5: one 3840x2160 luma frame, 64x64 CTUs (+ one row of 64x48), +-64 full search."""
+    fw, fh, r = 3840, 2160, 64
+    stride_s, stride_r = fw, fw + 2 * r
+    src = wl.fill_u8(fw * fh, 5, device="cuda")
+    ref = wl.fill_u8(stride_r * (fh + 2 * r), 6, device="cuda")
+    total_ms, total_sads, total_blocks = 0.0, 0, 0
+    for (w, h, y0, rows) in ((64, 64, 0, 33), (64, 48, 33 * 64, 1)):
+        by, bx = np.meshgrid(np.arange(rows), np.arange(fw // w), indexing="ij")
+        so = ((y0 + by * h) * stride_s + bx * w).reshape(-1).astype(np.uint32)
+        ro = ((y0 + by * h + r) * stride_r + bx * w + r).reshape(-1).astype(np.uint32)
+        so_d, ro_d = B.off32(so), B.off32(ro)
+        ms = timed(lambda i: B.me_full_search(src, stride_s, ref, stride_r, so_d, ro_d, w, h, r), reps=3)
+        total_ms += ms; total_blocks += so.size; total_sads += so.size * (2 * r + 1) ** 2
+        report("me_full_search", so.size, w * h + (w + 2 * r) * (h + 2 * r) + 8 + 12, ms, size="%dx%d +-%d" % (w, h, r), gsad_evals_per_s=round(so.size * (2 * r + 1) ** 2 / ms / 1e6, 2))
+    print(json.dumps(dict(kernel="me_full_search frame total", ms=round(total_ms, 3), ctus=total_blocks, frames_per_s=round(1e3 / total_ms, 1),
+                          gsad_evals_per_s=round(total_sads / total_ms / 1e6, 2))), flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["quant", "transform", "pred", "me"]
+    torch.cuda.set_device(0)
+    for w in what:
+        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me)[w]()
