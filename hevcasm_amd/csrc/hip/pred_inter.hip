@@ -4,165 +4,347 @@
 // hevcasm_pred_bi_8to8 (pred_inter.h:76; C body pred_inter.c:490-530) for whole batches of
 // equally sized prediction units (PUs) with per-PU motion-vector fractions.
 //
-// Arithmetic.  One code path serves every fraction pair: horizontal FIR at full precision into
-// int16 (never overflows: |sum| <= 88 * 255), then vertical FIR in 32 bits.
-//   uni: (v + 2048) >> 12, clip to 8 bits.  Identical to the reference's copy / H-only / V-only /
-//        HV special cases because an unfiltered direction is the tap {64}, i.e. an exact factor
-//        64 that the final shift removes (64 * (s + 32) == 64 s + 2048).
-//   bi:  v >> 6 per reference (no rounding), then (a + b + 64) >> 7, clip.
+// Arithmetic.  The 2-D filter is separable and the reference keeps the first pass at full
+// precision (shift 0, pred_inter.c:175), so the pass order can be swapped without changing a bit:
+// the sum S = sum_j sum_i cy[j] cx[i] s[y+j][x+i] is exact either way.  One path serves every
+// fraction pair (an unfiltered direction is the tap {64}):
+//   uni: (S + 2048) >> 12, clip to 8 bits  == the reference's copy / H-only / V-only / HV cases,
+//        because 64 * (s + 32) == 64 s + 2048 makes the single-direction rounding identical;
+//   bi:  p = S >> 6 per reference (pred_inter.c:515: shift 6, no rounding), then
+//        (p0 + p1 + 64) >> 7, clip (pred_inter.c:490-501).
 //
-// Mapping.  LPP lanes (8..256, chosen from the PU area) own one PU; a 256-thread workgroup
-// carries 256 / LPP PUs.  Per PU the (W + T - 1) x (H + T - 1) reference window is copied to LDS
-// (the line buffer of the separable filter), the horizontal pass writes an int16 plane to LDS,
-// and the vertical pass reads it column-wise.  Lanes are laid out LX across by LPP / LX down so
-// consecutive lanes touch consecutive pixels.
-// Algorithmic bytes per PU: refs * (W + T - 1)(H + T - 1) + W * H.
+// Mapping: everything stays in registers, no LDS.  Lane j of a PU owns the 4 window columns
+// u = 4j .. 4j+3 (window = the W + T - 1 columns the filter reads, starting BEFORE = T/2 - 1
+// left of the block) and produces output columns 4j .. 4j+3.  It streams down the rows with one
+// dword load per row, runs the VERTICAL filter first on the bytes unpacked to packed int16
+// (v_pk_mad_u16, partial sums stay below 2^15: |sum| <= 88 * 255), then takes its two right-hand
+// neighbours' vertical results with DPP wave shifts and runs the HORIZONTAL filter with
+// v_dot2_i32_i16 on (even, even) / (odd, odd) column pairs.  A sliding window of T unpacked rows
+// lives in registers (loop unrolled by T so the slot indices are static).  ceil((W + T - 1) / 4)
+// lanes per PU, as many PUs per wave as fit.  Reads exactly the reference's window (the last
+// lane's dword is shifted left to end at the window's last byte), writes exactly W x H.
+// Algorithmic bytes per PU: refs * (W + T - 1)(H + T - 1) + W * H (+ 4 (1 + refs) + refs descriptor bytes).
 
 #include "common.hpp"
 
 namespace hevc {
 
-__constant__ signed char kLumaTaps[4][8] = {
-	{ 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
-	{ -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
-__constant__ signed char kChromaTaps[8][4] = {
-	{ 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
-	{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-template <int TAPS> __device__ __forceinline__ void load_taps(int frac, int (&c)[TAPS])
+// packed coefficient tables: V pass wants (c, c); H pass wants (c[k], c[k + 2]) pairs
+struct PredTables
 {
-#pragma unroll
-	for (int k = 0; k < TAPS; ++k) c[k] = TAPS == 8 ? kLumaTaps[frac & 3][k] : kChromaTaps[frac & 7][k];
-}
-
-struct PredGeom
-{
-	int W, H;
-	int log2_lx;      // lanes across = 1 << log2_lx
-	int win_stride;   // bytes per window row in LDS
-	int win_bytes;    // window plane, rounded up to 16
-	int tmp_bytes;    // int16 (H + T - 1) x W plane, rounded up to 16
-	int pu_bytes;     // LDS per PU
+	uint32_t luma_v[4][8], luma_h[4][4], chroma_v[8][4], chroma_h[8][2];
 };
 
-template <int TAPS, int LPP, bool BI>
-__global__ __launch_bounds__(kThreads) void pred_kernel(
+constexpr uint32_t pk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+constexpr PredTables make_pred_tables()
+{
+	constexpr int luma[4][8] = {
+		{ 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+		{ -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
+	constexpr int chroma[8][4] = {
+		{ 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+		{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
+	PredTables t = {};
+	for (int f = 0; f < 4; ++f)
+	{
+		for (int k = 0; k < 8; ++k) t.luma_v[f][k] = pk(luma[f][k], luma[f][k]);
+		t.luma_h[f][0] = pk(luma[f][0], luma[f][2]);
+		t.luma_h[f][1] = pk(luma[f][1], luma[f][3]);
+		t.luma_h[f][2] = pk(luma[f][4], luma[f][6]);
+		t.luma_h[f][3] = pk(luma[f][5], luma[f][7]);
+	}
+	for (int f = 0; f < 8; ++f)
+	{
+		for (int k = 0; k < 4; ++k) t.chroma_v[f][k] = pk(chroma[f][k], chroma[f][k]);
+		t.chroma_h[f][0] = pk(chroma[f][0], chroma[f][2]);
+		t.chroma_h[f][1] = pk(chroma[f][1], chroma[f][3]);
+	}
+	return t;
+}
+
+__constant__ PredTables kPred = make_pred_tables();
+
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+{
+	const s16x2 r = __builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c);
+	return __builtin_bit_cast(uint32_t, r);
+}
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
+}
+// value held by lane + 1 (lane 63 receives 0)
+__device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true /* bound_ctrl: out-of-range source reads 0 */);
+}
+
+template <int TAPS> struct Coefs
+{
+	uint32_t v[TAPS];        // (cy[k], cy[k])
+	uint32_t h[TAPS / 2];    // (cx[0], cx[2]) (cx[1], cx[3]) [(cx[4], cx[6]) (cx[5], cx[7])]
+	__device__ __forceinline__ void load(int frac)
+	{
+		const int xf = frac & 15, yf = frac >> 4;
+#pragma unroll
+		for (int k = 0; k < TAPS; ++k) v[k] = TAPS == 8 ? kPred.luma_v[yf & 3][k] : kPred.chroma_v[yf & 7][k];
+#pragma unroll
+		for (int k = 0; k < TAPS / 2; ++k) h[k] = TAPS == 8 ? kPred.luma_h[xf & 3][k] : kPred.chroma_h[xf & 7][k];
+	}
+};
+
+// One reference's state: the sliding window of unpacked rows, and the row stream.
+// NDW = dwords (4 window columns each) per lane per row.
+template <int TAPS, int NDW> struct RefStream
+{
+	static constexpr int NX = NDW + (TAPS == 8 ? 2 : 1);   // column groups the horizontal pass reads
+	uint32_t e[TAPS][NDW], o[TAPS][NDW];   // window slots: even / odd columns of each dword as int16 pairs
+	uint32_t cur[TAPS][NDW], nxt[TAPS][NDW];
+	const uint8_t *p;            // this lane's bytes of the next window row to load
+	ptrdiff_t stride;
+	uint32_t shift;              // 8 * bytes the last lane's load was moved left to stay inside the window
+	Coefs<TAPS> c;
+
+	// next window row of the stream (rows are consumed strictly in order)
+	__device__ __forceinline__ void next_row(uint32_t (&d)[NDW])
+	{
+		if (NDW == 1)
+		{
+			d[0] = reinterpret_cast<const U1 *>(p)->v >> shift;
+		}
+		else
+		{
+			const u32x2 v = reinterpret_cast<const U2 *>(p)->v;
+			const unsigned long long q = (((unsigned long long)v.y << 32) | v.x) >> shift;
+			d[0] = (uint32_t)q;
+			d[NDW - 1] = (uint32_t)(q >> 32);
+		}
+		p += stride;
+	}
+	__device__ __forceinline__ void zero_row(uint32_t (&d)[NDW])
+	{
+#pragma unroll
+		for (int m = 0; m < NDW; ++m) d[m] = 0;
+	}
+	__device__ __forceinline__ void unpack(int slot, const uint32_t (&d)[NDW])
+	{
+#pragma unroll
+		for (int m = 0; m < NDW; ++m)
+		{
+			e[slot][m] = __builtin_amdgcn_perm(0, d[m], 0x0c020c00);   // (byte 0, byte 2) zero-extended
+			o[slot][m] = __builtin_amdgcn_perm(0, d[m], 0x0c030c01);   // (byte 1, byte 3)
+		}
+	}
+	// vertical filter for the output row whose oldest window row sits in slot `first`
+	__device__ __forceinline__ void vertical(int first, uint32_t (&ve)[NX], uint32_t (&vo)[NX]) const
+	{
+#pragma unroll
+		for (int m = 0; m < NDW; ++m)
+		{
+			ve[m] = 0; vo[m] = 0;
+#pragma unroll
+			for (int k = 0; k < TAPS; ++k)
+			{
+				ve[m] = pk_mad(e[(first + k) % TAPS][m], c.v[k], ve[m]);
+				vo[m] = pk_mad(o[(first + k) % TAPS][m], c.v[k], vo[m]);
+			}
+		}
+	}
+	// horizontal filter: exact 2-D sums S for this lane's 4 * NDW output columns.  ve/vo[0..NDW) are
+	// this lane's vertical results; the rest is fetched from the lanes to the right.  `bias` seeds
+	// every sum (the uni-prediction rounding constant rides along for free).
+	__device__ __forceinline__ void horizontal(uint32_t (&ve)[NX], uint32_t (&vo)[NX], int bias, int (&s)[4 * NDW]) const
+	{
+#pragma unroll
+		for (int m = NDW; m < NX; ++m)
+		{
+			// column group m lives in lane + 1 as its group m - NDW (NDW == 1, 8 taps: group 2 = lane + 2)
+			ve[m] = from_next_lane(ve[m - NDW]);
+			vo[m] = from_next_lane(vo[m - NDW]);
+		}
+		uint32_t a[NX - 1], b[NX - 1];
+#pragma unroll
+		for (int m = 0; m < NX - 1; ++m)
+		{
+			a[m] = __builtin_amdgcn_alignbit(ve[m + 1], ve[m], 16);   // (col 4m+2, col 4m+4)
+			b[m] = __builtin_amdgcn_alignbit(vo[m + 1], vo[m], 16);   // (col 4m+3, col 4m+5)
+		}
+#pragma unroll
+		for (int m = 0; m < NDW; ++m)
+		{
+			if (TAPS == 8)
+			{
+				s[4 * m + 0] = dot2(vo[m + 1], c.h[3], dot2(ve[m + 1], c.h[2], dot2(vo[m], c.h[1], dot2(ve[m], c.h[0], bias))));
+				s[4 * m + 1] = dot2(a[m + 1], c.h[3], dot2(vo[m + 1], c.h[2], dot2(a[m], c.h[1], dot2(vo[m], c.h[0], bias))));
+				s[4 * m + 2] = dot2(b[m + 1], c.h[3], dot2(a[m + 1], c.h[2], dot2(b[m], c.h[1], dot2(a[m], c.h[0], bias))));
+				s[4 * m + 3] = dot2(ve[m + 2], c.h[3], dot2(b[m + 1], c.h[2], dot2(ve[m + 1], c.h[1], dot2(b[m], c.h[0], bias))));
+			}
+			else
+			{
+				s[4 * m + 0] = dot2(vo[m], c.h[1], dot2(ve[m], c.h[0], bias));
+				s[4 * m + 1] = dot2(a[m], c.h[1], dot2(vo[m], c.h[0], bias));
+				s[4 * m + 2] = dot2(b[m], c.h[1], dot2(a[m], c.h[0], bias));
+				s[4 * m + 3] = dot2(ve[m + 1], c.h[1], dot2(b[m], c.h[0], bias));
+			}
+		}
+	}
+};
+
+template <int TAPS, int NDW, bool BI>
+__global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
-	PredGeom g, uint32_t n_blocks)
+	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	constexpr int PPWG = kThreads / LPP;
+	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
+	constexpr int CPL = 4 * NDW;            // window / output columns per lane
+	typedef RefStream<TAPS, NDW> Stream;
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t local = threadIdx.x / LPP, l = threadIdx.x % LPP;
-	uint32_t pu = wg * PPWG + local;
-	const bool live = pu < n_blocks;
-	if (!live) pu = n_blocks - 1;
+	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	int sub = lane / LW;
+	int j = lane - sub * LW;
+	const bool spare = sub >= PPW;          // lanes left over when 64 % LW != 0: park them on lane 0's data
+	if (spare) { sub = PPW - 1; j = 0; }
+	uint32_t pu = wave * PPW + sub;
+	const bool in_batch = pu < n_blocks;
+	if (!in_batch) pu = n_blocks - 1;
 
-	uint8_t *win = lds + local * g.pu_bytes;
-	int16_t *tmp = reinterpret_cast<int16_t *>(win + g.win_bytes);
-	int16_t *first = reinterpret_cast<int16_t *>(win + g.win_bytes + g.tmp_bytes);  // bi only: 14-bit prediction of ref 0
+	const int window = W + TAPS - 1;                  // columns the filter reads (>= CPL is guaranteed by the launcher)
+	const int natural_end = CPL * j + CPL;
+	const int over = natural_end > window ? natural_end - window : 0;   // only the last lane: 0 .. CPL-1
+	const int cols = min(CPL, W - CPL * j);           // output columns this lane stores (<= 0: none)
+	const bool stores = in_batch && !spare && cols > 0;
 
-	const int W = g.W, H = g.H, WS = g.win_stride;
-	const int LX = 1 << g.log2_lx, LY = LPP >> g.log2_lx;
-	const int lx = l & (LX - 1), ly = l >> g.log2_lx;
-	const int rows = H + TAPS - 1, cols = W + TAPS - 1;
-
+	Stream rs[NREF];
 #pragma unroll
-	for (int r = 0; r < (BI ? 2 : 1); ++r)
+	for (int r = 0; r < NREF; ++r)
 	{
-		const uint8_t *ref = (r ? ref1 : ref0) + (r ? ref1_off : ref0_off)[pu];
-		const int fr = (r ? frac1 : frac0)[pu];
-		int cx[TAPS], cy[TAPS];
-		load_taps<TAPS>(fr & 15, cx);
-		load_taps<TAPS>(fr >> 4, cy);
+		const uint8_t *base = (r ? ref1 : ref0) + (r ? ref1_off : ref0_off)[pu];
+		rs[r].stride = stride_ref;
+		rs[r].p = base - (ptrdiff_t)BEFORE * stride_ref - BEFORE + CPL * j - over;
+		rs[r].shift = 8 * over;
+		rs[r].c.load((r ? frac1 : frac0)[pu]);
+	}
+	uint8_t *out = dst + dst_off[pu] + CPL * j;
+	const int rows = H + TAPS - 1;                    // window rows
 
-		// reference window -> LDS
-		for (int y = ly; y < rows; y += LY)
+	// prologue: window rows 0 .. T-2 into slots 0 .. T-2; rows T-1 .. 2T-2 are group 0's stream
+#pragma unroll
+	for (int r = 0; r < NREF; ++r)
+	{
+#pragma unroll
+		for (int q = 0; q < TAPS - 1; ++q)
 		{
-			const uint8_t *src_row = ref + (ptrdiff_t)(y - BEFORE) * stride_ref - BEFORE;
-			for (int x = lx; x < cols; x += LX) win[y * WS + x] = src_row[x];
+			if (q < rows) rs[r].next_row(rs[r].cur[q]); else rs[r].zero_row(rs[r].cur[q]);
 		}
-		__syncthreads();
-
-		// horizontal pass, full precision (pred_inter.c:175, shift 0)
-		for (int y = ly; y < rows; y += LY)
-			for (int x = lx; x < W; x += LX)
-			{
-				int a = 0;
 #pragma unroll
-				for (int k = 0; k < TAPS; ++k) a += cx[k] * win[y * WS + x + k];
-				tmp[y * W + x] = (int16_t)a;
-			}
-		__syncthreads();
-
-		// vertical pass
-		for (int y = ly; y < H; y += LY)
-			for (int x = lx; x < W; x += LX)
-			{
-				int a = 0;
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].unpack(q, rs[r].cur[q]);
 #pragma unroll
-				for (int k = 0; k < TAPS; ++k) a += cy[k] * tmp[(y + k) * W + x];
-				if (!BI)
-				{
-					if (live) dst[dst_off[pu] + (ptrdiff_t)y * stride_dst + x] = (uint8_t)clip3(0, 255, (a + 2048) >> 12);
-				}
-				else if (r == 0)
-				{
-					first[y * W + x] = (int16_t)(a >> 6);  // pred_inter.c:515, shift 6, no rounding
-				}
-				else
-				{
-					const int v = ((int)first[y * W + x] + (int)(int16_t)(a >> 6) + 64) >> 7;  // pred_inter.c:490-501
-					if (live) dst[dst_off[pu] + (ptrdiff_t)y * stride_dst + x] = (uint8_t)clip3(0, 255, v);
-				}
+		for (int i = 0; i < TAPS; ++i)
+		{
+			if (TAPS - 1 + i < rows) rs[r].next_row(rs[r].cur[i]); else rs[r].zero_row(rs[r].cur[i]);
+		}
+	}
+
+	for (int y0 = 0; y0 < H; y0 += TAPS)
+	{
+		// next group's rows: issued now, consumed one group later
+#pragma unroll
+		for (int r = 0; r < NREF; ++r)
+#pragma unroll
+			for (int i = 0; i < TAPS; ++i)
+			{
+				if (y0 + 2 * TAPS - 1 + i < rows) rs[r].next_row(rs[r].nxt[i]); else rs[r].zero_row(rs[r].nxt[i]);
 			}
-		__syncthreads();
+
+#pragma unroll
+		for (int i = 0; i < TAPS; ++i)
+		{
+			const int y = y0 + i;
+			if (y < H)   // wave-uniform
+			{
+				int s[NREF][CPL];
+#pragma unroll
+				for (int r = 0; r < NREF; ++r)
+				{
+					rs[r].unpack((i + TAPS - 1) % TAPS, rs[r].cur[i]);   // window row y + T - 1
+					uint32_t ve[Stream::NX], vo[Stream::NX];
+					rs[r].vertical(i, ve, vo);
+					rs[r].horizontal(ve, vo, BI ? 0 : 2048, s[r]);
+				}
+				uint32_t px[NDW];
+#pragma unroll
+				for (int m = 0; m < NDW; ++m)
+				{
+					px[m] = 0;
+#pragma unroll
+					for (int b = 0; b < 4; ++b)
+					{
+						int v;
+						if (BI) v = ((s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64) >> 7;
+						else v = s[0][4 * m + b] >> 12;   // 2048 already inside
+						px[m] |= (uint32_t)clip3(0, 255, v) << (8 * b);
+					}
+				}
+				if (stores)
+				{
+					if (cols >= CPL)
+					{
+						if (NDW == 1) reinterpret_cast<U1 *>(out)->v = px[0];
+						else
+						{
+							u32x2 v; v.x = px[0]; v.y = px[NDW - 1];
+							reinterpret_cast<U2 *>(out)->v = v;
+						}
+					}
+					else
+					{
+						for (int b = 0; b < cols; ++b) out[b] = (uint8_t)(px[b >> 2] >> (8 * (b & 3)));
+					}
+				}
+				out += stride_dst;
+			}
+		}
+#pragma unroll
+		for (int r = 0; r < NREF; ++r)
+#pragma unroll
+			for (int i = 0; i < TAPS; ++i)
+#pragma unroll
+				for (int m = 0; m < NDW; ++m) rs[r].cur[i][m] = rs[r].nxt[i][m];
 	}
 }
 
-static int round16(int v) { return (v + 15) & ~15; }
+template <int TAPS, int NDW, bool BI>
+static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
+		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
+		int W, int H, size_t n, hipStream_t st)
+{
+	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
+	const int ppw = kWave / lw;
+	const uint32_t grid = ceil_div(n, (size_t)ppw * (kThreads / kWave));
+	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI>), dim3(grid), dim3(kThreads), 0, st,
+			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n);
+	return launch_status("pred_stream_kernel");
+}
 
 template <int TAPS, bool BI>
 static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
 		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
 		int W, int H, size_t n, hipStream_t st)
 {
-	PredGeom g;
-	g.W = W; g.H = H;
-	g.win_stride = (W + TAPS - 1 + 3) & ~3;
-	g.win_bytes = round16(g.win_stride * (H + TAPS - 1));
-	g.tmp_bytes = round16(2 * W * (H + TAPS - 1));
-	g.pu_bytes = g.win_bytes + g.tmp_bytes + (BI ? round16(2 * W * H) : 0);
-	int lx = 0;
-	while ((1 << lx) < W) ++lx;
-
-	const int area = W * H;
-	const int lpp = area >= 2048 ? 256 : area >= 1024 ? 128 : area >= 512 ? 64 : area >= 256 ? 32 : area >= 128 ? 16 : 8;
-	int lpp_log2 = 0;
-	while ((1 << lpp_log2) < lpp) ++lpp_log2;
-	g.log2_lx = lx < lpp_log2 ? lx : lpp_log2;
-
-	const int ppwg = kThreads / lpp;
-	const uint32_t grid = ceil_div(n, ppwg);
-	const size_t shmem = (size_t)g.pu_bytes * ppwg;
-#define LAUNCH(L) hipLaunchKernelGGL((pred_kernel<TAPS, L, BI>), dim3(grid), dim3(kThreads), shmem, st, \
-		dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, g, (uint32_t)n); break;
-	switch (lpp)
-	{
-	case 8: LAUNCH(8)
-	case 16: LAUNCH(16)
-	case 32: LAUNCH(32)
-	case 64: LAUNCH(64)
-	case 128: LAUNCH(128)
-	default: LAUNCH(256)
-	}
-#undef LAUNCH
-	return launch_status("pred_kernel");
+	// 8 bytes per lane per row halves the load instructions (the texture-address unit handles 4 lanes
+	// per cycle whatever their width); PUs narrower than 8 keep 4 bytes so that no lane is half idle.
+	// The window must hold at least one full lane load: W + T - 1 >= 8 for the wide variant.
+	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
+	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
 }
 
 static int check_pred_args(int taps, int W, int H, size_t n)

@@ -141,7 +141,7 @@ def sad_case(w, h, n, seed, ways=1, max_disp=7, frame=(SMALL_W, SMALL_H), kind="
         w=w, h=h, n=n, ways=ways)
 
 
-def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noise", fracs=None, device=None):
+def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noise", fracs=None, device=None, coherent_mv=False):
     """Config #3: dst tiled by w x h PUs; reference origin = same position displaced by an integer
     motion vector in [-8, 8]^2; fractions uniform over all phases (4 luma / 8 chroma per axis)
     unless ``fracs`` = (xFrac, yFrac) pins them."""
@@ -157,6 +157,8 @@ def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noi
                dst_off=dst_off.astype(np.uint32))
     for r in range(2 if bi else 1):
         mv = rng.integers(-8, 9, size=(n, 2))
+        if coherent_mv:               # one motion vector for the whole batch (exploration only)
+            mv[:] = mv[0]
         off = base + mv[:, 1] * rp.stride + mv[:, 0]
         if fracs is None:
             fx, fy = rng.integers(0, phases, size=n), rng.integers(0, phases, size=n)

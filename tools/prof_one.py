@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""One family / one configuration, a few launches on cold buffers -- the target of rocprofv3 --pmc.
+usage: prof_one.py pred_uni TAPS W H | inverse LOG2 | forward LOG2 | me"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hevcasm_amd import batch as B, workload as wl
+kind = sys.argv[1]
+if kind in ("pred_uni", "pred_bi"):
+    taps, w, h = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    bi = kind == "pred_bi"
+    fw, fh = (1920, 1080) if taps == 8 else (960, 540)
+    n = (fw // w) * (fh // h) * 64
+    for i in range(3):
+        c = wl.pred_case(taps, w, h, n, 50 + i, bi=bi, frame=(fw, fh), device="cuda")
+        dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        if bi:
+            B.pred_bi(dst, c["stride_dst"], c["ref0"], c["ref1"], c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.off32(c["ref1_off"]), B.u8(c["frac0"]), B.u8(c["frac1"]), taps, w, h)
+        else:
+            B.pred_uni(dst, c["stride_dst"], c["ref0"], c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"]), taps, w, h)
+elif kind in ("inverse", "forward"):
+    lg = int(sys.argv[2]); size = 1 << lg; n = (1 << 26) >> (2 * lg)
+    for i in range(3):
+        if kind == "inverse":
+            c = wl.inverse_case(0, lg, n, 70 + i, "natural", frame=(wl.FRAME_W, wl.FRAME_H))
+            B.inverse_transform_add(torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), c["stride_dst"], B.u8(c["pred"]), c["stride_pred"], B.off32(c["dst_off"]), B.off32(c["pred_off"]), B.i16(c["coeffs"]), 0, lg)
+        else:
+            f = wl.forward_case(0, lg, n, 80 + i, frame=(wl.FRAME_W, wl.FRAME_H))
+            B.transform(B.i16(f["src"]), f["src_stride"], B.off32(f["src_off"]), 0, lg)
+torch.cuda.synchronize()
+print("done")
