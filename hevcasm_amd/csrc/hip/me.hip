@@ -1,14 +1,17 @@
 // me.hip -- full-search motion estimation: hevcasm_sad evaluated at every displacement of a
 // +-range window, arg-min per block.
 //
-// One workgroup per block.  The source block and the (W + 2R) x (H + 2R) reference window are
-// staged once in LDS (64x64, R = 64: 4 KiB + 36 KiB); each thread then walks its share of the
-// (2R + 1)^2 candidates.  A candidate row starts at an arbitrary byte of the window, so each
-// 4-byte group is assembled from two aligned LDS dwords with v_alignbyte_b32 and fed to
-// v_sad_u8.  Consecutive threads take consecutive dx, i.e. consecutive LDS bytes: conflict-free.
+// One workgroup per block.  The source block and the reference window are staged once in LDS
+// (64x64, R = 64: 4 KiB + 39 KiB).  Work item = (dy, group of 16 consecutive dx): for each block
+// row the thread reads W + 16 window bytes with aligned 16-byte LDS reads and feeds
+// v_qsad_pk_u16_u8, which slides a 4-pixel source dword over an 8-byte reference window and
+// accumulates FOUR neighbouring candidates per instruction (16 byte differences per lane-op, no
+// byte realignment: the groups start on dword boundaries of the window).  The packed u16 sums are
+// folded into 32-bit accumulators every 4 rows (4 rows x 16 dwords x 1020 < 65536).
+// Consecutive threads take consecutive groups: consecutive 16-byte LDS addresses, conflict free.
 // The arg-min key is (cost << 16) | candidate index, so ties go to the first candidate in raster
 // order of (dy, dx), the order of the nested loops a CPU full search uses.
-// VALU/LDS-bound (about 1.7 k byte operations per byte fetched), not HBM-bound.
+// VALU/LDS-bound (about 1.7 k byte differences per byte fetched), not HBM-bound.
 
 #include "common.hpp"
 
@@ -17,14 +20,14 @@ namespace hevc {
 __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	int W, int H, int R, int win_stride /* bytes, multiple of 4 */)
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, int n_groups)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 	__shared__ unsigned long long best_of_wave[kThreads / kWave];
 
 	const uint32_t blk = blockIdx.x;
 	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds);                 // H rows of W / 4 dwords
-	uint8_t *s_win = lds + W * H;                                          // (H + 2R) rows of win_stride bytes
+	uint8_t *s_win = lds + ((W * H + 15) & ~15);                           // (H + 2R) rows of win_stride bytes
 	const int wd = W / 4;
 	const int win_w = W + 2 * R, win_h = H + 2 * R;
 
@@ -34,46 +37,87 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		const int y = i / wd, x = i - y * wd;
 		s_src[i] = reinterpret_cast<const U1 *>(sp + (ptrdiff_t)y * stride_src + 4 * x)->v;
 	}
+	// window rows, zero-padded to win_stride so that the last dx group may read past the real window
 	const uint8_t *rp = ref + ref_off[blk] - (ptrdiff_t)R * stride_ref - R;
-	const int row_dwords = (win_w + 3) / 4;
+	const int row_dwords = win_stride / 4;
 	for (int i = threadIdx.x; i < row_dwords * win_h; i += kThreads)
 	{
 		const int y = i / row_dwords, x = i - y * row_dwords;
 		const uint8_t *p = rp + (ptrdiff_t)y * stride_ref + 4 * x;
-		uint32_t v;
+		uint32_t v = 0;
 		if (4 * x + 4 <= win_w) v = reinterpret_cast<const U1 *>(p)->v;
 		else
-		{
-			v = 0;  // last partial dword of a row: never read past the window the caller guarantees
-			for (int b = 0; 4 * x + b < win_w; ++b) v |= (uint32_t)p[b] << (8 * b);
-		}
+			for (int b = 0; 4 * x + b < win_w; ++b) v |= (uint32_t)p[b] << (8 * b);   // never read past the window the caller guarantees
 		*reinterpret_cast<uint32_t *>(s_win + y * win_stride + 4 * x) = v;
 	}
 	__syncthreads();
 
 	const int side = 2 * R + 1;
-	const int n_cand = side * side;
 	unsigned long long best = ~0ull;
-	for (int c = threadIdx.x; c < n_cand; c += kThreads)
+	for (int item = threadIdx.x; item < side * n_groups; item += kThreads)
 	{
-		const int cy = c / side, cx = c - cy * side;   // = dy + R, dx + R
-		uint32_t acc = 0;
-		for (int y = 0; y < H; ++y)
+		const int cy = item / n_groups, g = item - cy * n_groups;   // candidates (cy, 16 g .. 16 g + 15)
+		uint32_t acc[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) acc[k] = 0;
+		for (int y0 = 0; y0 < H; y0 += 4)
 		{
-			const uint32_t a = (uint32_t)((y + cy) * win_stride + cx);
-			const uint32_t *q = reinterpret_cast<const uint32_t *>(s_win + (a & ~3u));
-			const uint32_t sh = a & 3u;
-			uint32_t lo = q[0];
-			const uint32_t *s = s_src + y * wd;
-			for (int j = 0; j < wd; ++j)
+			unsigned long long pk[4] = { 0, 0, 0, 0 };   // 4 x (4 packed u16 sums): candidates 4q .. 4q+3
+			for (int y = y0; y < y0 + 4; ++y)
 			{
-				const uint32_t hi = q[j + 1];
-				acc = __builtin_amdgcn_sad_u8(s[j], __builtin_amdgcn_alignbyte(hi, lo, sh), acc);
-				lo = hi;
+				const uint8_t *wrow = s_win + (y + cy) * win_stride + 16 * g;
+				const uint32_t *srow = s_src + y * wd;
+				int j = 0;
+				for (; j + 4 <= wd; j += 4)
+				{
+					// 16 source bytes (same address in every lane: LDS broadcast) and the 36 window bytes
+					// starting above them, as two aligned 16-byte reads and one dword
+					const u32x4 s4 = *reinterpret_cast<const u32x4 *>(srow + j);
+					const u32x4 wa = *reinterpret_cast<const u32x4 *>(wrow + 4 * j);
+					const u32x4 wb = *reinterpret_cast<const u32x4 *>(wrow + 4 * j + 16);
+					const uint32_t wc = *reinterpret_cast<const uint32_t *>(wrow + 4 * j + 32);
+					const uint32_t w[9] = { wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc };
+					const uint32_t sv[4] = { s4.x, s4.y, s4.z, s4.w };
+#pragma unroll
+					for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+						for (int q = 0; q < 4; ++q)
+						{
+							// candidates 4q .. 4q+3 of this group see source dword j + jj against window dwords (j + jj + q, j + jj + q + 1)
+							const unsigned long long window = ((unsigned long long)w[jj + q + 1] << 32) | w[jj + q];
+							pk[q] = __builtin_amdgcn_qsad_pk_u16_u8(window, sv[jj], pk[q]);
+						}
+				}
+				for (; j < wd; ++j)   // widths that are not a multiple of 16: one source dword at a time
+				{
+					const uint32_t sv = srow[j];
+					uint32_t w[5];
+#pragma unroll
+					for (int q = 0; q < 5; ++q) w[q] = *reinterpret_cast<const uint32_t *>(wrow + 4 * (j + q));
+#pragma unroll
+					for (int q = 0; q < 4; ++q)
+						pk[q] = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w[q + 1] << 32) | w[q], sv, pk[q]);
+				}
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+			{
+				acc[4 * q + 0] += (uint32_t)(pk[q] & 0xffff);
+				acc[4 * q + 1] += (uint32_t)((pk[q] >> 16) & 0xffff);
+				acc[4 * q + 2] += (uint32_t)((pk[q] >> 32) & 0xffff);
+				acc[4 * q + 3] += (uint32_t)(pk[q] >> 48);
 			}
 		}
-		const unsigned long long key = ((unsigned long long)acc << 16) | (unsigned)c;
-		best = key < best ? key : best;
+#pragma unroll
+		for (int k = 0; k < 16; ++k)
+		{
+			const int cx = 16 * g + k;
+			if (cx < side)
+			{
+				const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + cx);
+				best = key < best ? key : best;
+			}
+		}
 	}
 
 #pragma unroll
@@ -110,11 +154,12 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (n_blocks == 0) return 0;
 	if (n_blocks > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	// one spare dword per row so that the (hi, lo) pair of the last group stays inside the row
-	const int win_stride = ((W + 2 * range + 3) & ~3) + 4;
-	const size_t shmem = (size_t)W * H + (size_t)win_stride * (H + 2 * range) + 16;
+	// dx groups of 16; a group reads W + 16 (+16 of look-ahead) window bytes starting at 16 * g
+	const int n_groups = (2 * range + 1 + 15) / 16;
+	const int win_stride = (16 * n_groups + W + 32 + 15) & ~15;
+	const size_t shmem = (((size_t)W * H + 15) & ~(size_t)15) + (size_t)win_stride * (H + 2 * range);
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
 	hipLaunchKernelGGL(me_full_search_kernel, dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride);
+			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups);
 	return launch_status("me_full_search_kernel");
 }

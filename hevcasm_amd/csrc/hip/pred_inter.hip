@@ -280,19 +280,19 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 					rs[r].vertical(i, ve, vo);
 					rs[r].horizontal(ve, vo, BI ? 0 : 2048, s[r]);
 				}
+				// shift, saturate to [0, 255] and pack: v_ashr_pk_u8_i32 does two pixels per instruction
 				uint32_t px[NDW];
 #pragma unroll
 				for (int m = 0; m < NDW; ++m)
 				{
-					px[m] = 0;
+					int t[4];
 #pragma unroll
 					for (int b = 0; b < 4; ++b)
-					{
-						int v;
-						if (BI) v = ((s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64) >> 7;
-						else v = s[0][4 * m + b] >> 12;   // 2048 already inside
-						px[m] |= (uint32_t)clip3(0, 255, v) << (8 * b);
-					}
+						t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside
+					constexpr int SHIFT = BI ? 7 : 12;
+					const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
+					const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
+					px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);   // low halves of (hi, lo)
 				}
 				if (stores)
 				{

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void quantize_kernel(
 	if (live && part == 0) cbf[blk] = any;
 }
 
-// quantize.c:292-302.  A lane owns PX = min(8, N) horizontally adjacent pixels.
+// quantize.c:292-302.  A lane owns PX = min(8, N) horizontally adjacent pixels; 256 / (N * N / PX) blocks per workgroup.
 template <int N>
 __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	uint8_t *__restrict__ rec, ptrdiff_t stride_rec, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
@@ -97,13 +97,16 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	const int16_t *__restrict__ res, uint32_t n_blocks)
 {
 	constexpr int PX = N < 8 ? N : 8;
-	constexpr int LPR = N / PX;          // lanes per row
-	constexpr int LPB = LPR * N;         // lanes per block
-	const size_t lane_global = (size_t)xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	const size_t blk = lane_global / LPB;
+	constexpr int LPR = N / PX;              // lanes per row
+	constexpr int LPB = LPR * N;             // lanes per block
+	constexpr int BPWG = kThreads / LPB;     // blocks per workgroup
+	// Lane order inside a workgroup: x-part fastest, then block, then row -- so consecutive lanes
+	// walk along ONE frame row across neighbouring blocks (contiguous for raster-ordered blocks).
+	const uint32_t tid = threadIdx.x;
+	const uint32_t xpart = tid % LPR, b = (tid / LPR) % BPWG, y = tid / (LPR * BPWG);
+	const size_t blk = (size_t)xcd_contiguous(blockIdx.x, gridDim.x) * BPWG + b;
 	if (blk >= n_blocks) return;
-	const uint32_t part = (uint32_t)(lane_global % LPB);
-	const uint32_t y = part / LPR, x = (part % LPR) * PX;
+	const uint32_t x = xpart * PX;
 
 	Chunk<PX> p;
 	Chunk<2 * PX> r;
@@ -177,7 +180,7 @@ extern "C" int hevcasm_hip_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t st
 	hipStream_t st = as_stream(stream);
 #define LAUNCH(N) { \
 		constexpr int lpb = (N / (N < 8 ? N : 8)) * N; \
-		const uint32_t grid = ceil_div(n_blocks * lpb, kThreads); \
+		const uint32_t grid = ceil_div(n_blocks, kThreads / lpb); \
 		hipLaunchKernelGGL((reconstruct_kernel<N>), dim3(grid), dim3(kThreads), 0, st, rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, (uint32_t)n_blocks); \
 		return launch_status("reconstruct_kernel"); }
 	switch (nCbS)

@@ -48,34 +48,103 @@ template <int N> __device__ __forceinline__ constexpr int dct(int k, int i) { re
 
 // ---- 1-D transforms in registers ----------------------------------------------------------
 
-// out[n] = sum_k dct<N>(k, n) * in[k]     (inverse: coefficient index k -> sample index n)
-template <int N> struct Inverse1D
+// ---- inverse 1-D transform on packed int16 pairs --------------------------------------------
+//
+// The even/odd factorisation consumes its inputs in a fixed pair order: the odd rows of the
+// N-point stage two by two, then the odd rows of the N/2-point stage (rows 2, 6, 10, ...), and so
+// on down to the pair (0, N/2).  Both LDS tiles store the data already paired in that order, so a
+// lane's 1-D transform is N/2 dword reads followed by v_dot2_i32_i16 against compile-time
+// coefficient pairs: two multiply-accumulates per instruction, exact 32-bit sums.
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+
+template <int N> struct PairOrder
 {
-	static __device__ __forceinline__ void run(const int (&in)[N], int (&out)[N])
+	int first[N / 2], second[N / 2];   // pair p = rows (first[p], second[p])
+	int pair_of[N], half_of[N];        // row k sits in pair pair_of[k], half half_of[k] (0 = low 16 bits)
+};
+
+template <int N> constexpr PairOrder<N> make_pair_order()
+{
+	PairOrder<N> o = {};
+	int idx = 0;
+	for (int step = 1; step < N / 2; step *= 2)
+		for (int r = step; r < N; r += 4 * step)
+		{
+			o.first[idx] = r; o.second[idx] = r + 2 * step; ++idx;
+		}
+	o.first[idx] = 0; o.second[idx] = N / 2;
+	for (int p = 0; p < N / 2; ++p)
 	{
-		int even[N / 2], e[N / 2];
+		o.pair_of[o.first[p]] = p; o.half_of[o.first[p]] = 0;
+		o.pair_of[o.second[p]] = p; o.half_of[o.second[p]] = 1;
+	}
+	return o;
+}
+
+// byte offset of row k inside a pair-ordered row: 4 * pair + 2 * half
+struct PairBytes { unsigned char at[4][32]; };
+constexpr PairBytes make_pair_bytes()
+{
+	PairBytes t = {};
+	constexpr PairOrder<4> o4 = make_pair_order<4>();
+	constexpr PairOrder<8> o8 = make_pair_order<8>();
+	constexpr PairOrder<16> o16 = make_pair_order<16>();
+	constexpr PairOrder<32> o32 = make_pair_order<32>();
+	for (int k = 0; k < 4; ++k) t.at[0][k] = (unsigned char)(4 * o4.pair_of[k] + 2 * o4.half_of[k]);
+	for (int k = 0; k < 8; ++k) t.at[1][k] = (unsigned char)(4 * o8.pair_of[k] + 2 * o8.half_of[k]);
+	for (int k = 0; k < 16; ++k) t.at[2][k] = (unsigned char)(4 * o16.pair_of[k] + 2 * o16.half_of[k]);
+	for (int k = 0; k < 32; ++k) t.at[3][k] = (unsigned char)(4 * o32.pair_of[k] + 2 * o32.half_of[k]);
+	return t;
+}
+__constant__ PairBytes kPairBytes = make_pair_bytes();
+
+__device__ __forceinline__ int dot2(uint32_t pair, int c_lo, int c_hi, int acc)
+{
+	const uint32_t c = ((uint32_t)c_lo & 0xffffu) | ((uint32_t)c_hi << 16);
+	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, c), acc, false);
+}
+
+// n-point stage of the N-point inverse transform; its inputs are every (N / n)-th row, found in
+// pairs p[base ...].  out[i] = bias + sum over those rows.
+template <int N, int n> struct InversePacked
+{
+	static __device__ __forceinline__ void run(const uint32_t (&p)[N / 2], int base, int bias, int (&out)[n])
+	{
+		int e[n / 2];
+		InversePacked<N, n / 2>::run(p, base + n / 4, bias, e);
 #pragma unroll
-		for (int k = 0; k < N / 2; ++k) even[k] = in[2 * k];
-		Inverse1D<N / 2>::run(even, e);
-#pragma unroll
-		for (int n = 0; n < N / 2; ++n)
+		for (int k = 0; k < n / 2; ++k)
 		{
 			int o = 0;
 #pragma unroll
-			for (int k = 1; k < N; k += 2) o += dct<N>(k, n) * in[k];
-			out[n] = e[n] + o;
-			out[N - 1 - n] = e[n] - o;
+			for (int q = 0; q < n / 4; ++q) o = dot2(p[base + q], dct<n>(4 * q + 1, k), dct<n>(4 * q + 3, k), o);
+			out[k] = e[k] + o;
+			out[n - 1 - k] = e[k] - o;
 		}
 	}
 };
-template <> struct Inverse1D<2>
+template <int N> struct InversePacked<N, 2>
 {
-	static __device__ __forceinline__ void run(const int (&in)[2], int (&out)[2])
+	static __device__ __forceinline__ void run(const uint32_t (&p)[N / 2], int base, int bias, int (&out)[2])
 	{
-		out[0] = 64 * (in[0] + in[1]);
-		out[1] = 64 * (in[0] - in[1]);
+		out[0] = dot2(p[base], 64, 64, bias);
+		out[1] = dot2(p[base], 64, -64, bias);
 	}
 };
+
+// 4-point inverse DST-VII on the same pair order as the 4-point DCT: p[0] = (s1, s3), p[1] = (s0, s2)
+__device__ __forceinline__ void dst4_inverse_packed(const uint32_t (&p)[2], int bias, int (&o)[4])
+{
+	o[0] = dot2(p[1], 29, 84, dot2(p[0], 74, 55, bias));
+	o[1] = dot2(p[1], 55, -29, dot2(p[0], 74, -84, bias));
+	o[2] = dot2(p[1], 74, -74, dot2(p[0], 0, 74, bias));
+	o[3] = dot2(p[1], 84, 55, dot2(p[0], -74, -29, bias));
+}
+
+template <int N, bool DST> __device__ __forceinline__ void inverse_packed(const uint32_t (&p)[N / 2], int bias, int (&out)[N])
+{
+	if constexpr (DST) dst4_inverse_packed(p, bias, out); else InversePacked<N, N>::run(p, 0, bias, out);
+}
 
 // out[k] = sum_n dct<N>(k, n) * in[n]     (forward)
 template <int N> struct Forward1D
@@ -112,13 +181,6 @@ template <> struct Forward1D<2>
 };
 
 // 4-point DST-VII, basis rows {29,55,74,84} {74,74,0,-74} {84,-29,-74,55} {55,-84,74,-29}
-__device__ __forceinline__ void dst4_inverse(const int (&s)[4], int (&o)[4])
-{
-	o[0] = 29 * s[0] + 74 * s[1] + 84 * s[2] + 55 * s[3];
-	o[1] = 55 * s[0] + 74 * s[1] - 29 * s[2] - 84 * s[3];
-	o[2] = 74 * (s[0] - s[2] + s[3]);
-	o[3] = 84 * s[0] - 74 * s[1] + 55 * s[2] - 29 * s[3];
-}
 __device__ __forceinline__ void dst4_forward(const int (&s)[4], int (&o)[4])
 {
 	o[0] = 29 * s[0] + 55 * s[1] + 74 * s[2] + 84 * s[3];
@@ -127,10 +189,6 @@ __device__ __forceinline__ void dst4_forward(const int (&s)[4], int (&o)[4])
 	o[3] = 55 * s[0] - 84 * s[1] + 74 * s[2] - 29 * s[3];
 }
 
-template <int N, bool DST> __device__ __forceinline__ void inverse_1d(const int (&in)[N], int (&out)[N])
-{
-	if constexpr (DST) dst4_inverse(in, out); else Inverse1D<N>::run(in, out);
-}
 template <int N, bool DST> __device__ __forceinline__ void forward_1d(const int (&in)[N], int (&out)[N])
 {
 	if constexpr (DST) dst4_forward(in, out); else Forward1D<N>::run(in, out);
@@ -202,26 +260,43 @@ template <int N> __device__ __forceinline__ void global_row_store(int16_t *p, co
 
 // ---- inverse transform + add ---------------------------------------------------------------
 
+// LDS per block: tile P1 holds the coefficient block as [pair of rows][column] (one dword = the two
+// rows of a pair at that column; row stride N + 1 dwords, so the column walk of the first pass and
+// the 16-bit scatter that fills it are conflict free), tile P2 holds the first-pass result as
+// [row][pair of columns] (row stride N/2 (+4) dwords: 16-byte aligned, conflict-free b128 reads).
+template <int N> struct InverseTiles
+{
+	static constexpr int S1 = N + 1;
+	static constexpr int S2 = N / 2 + (N >= 16 ? 4 : 0);
+	static constexpr int P1_DWORDS = (N / 2) * S1;
+	static constexpr int P2_DWORDS = N * S2;
+	static constexpr int DWORDS = (P1_DWORDS + P2_DWORDS + 3) & ~3;
+};
+
 template <int N, bool DST, bool DEQUANT>
 __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {
+	typedef InverseTiles<N> T;
 	constexpr int BPWG = kThreads / N;
-	constexpr int S = Tile<N>::S;
-	__shared__ __attribute__((aligned(16))) int16_t tiles[BPWG * Tile<N>::HALFWORDS];
+	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
+	__shared__ __attribute__((aligned(16))) uint32_t tiles[BPWG * T::DWORDS];
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t local = threadIdx.x / N, t = threadIdx.x % N;
 	uint32_t blk = wg * BPWG + local;
 	const bool live = blk < n_blocks;
 	if (!live) blk = n_blocks - 1;
-	int16_t *tile = tiles + local * Tile<N>::HALFWORDS;
+	uint32_t *p1 = tiles + local * T::DWORDS;
+	uint32_t *p2 = p1 + T::P1_DWORDS;
+	const uint32_t my_pair_bytes = kPairBytes.at[LOG2 - 2][t];   // where row / column t sits in a pair-ordered row
 
 	int v[N], w[N];
+	uint32_t p[N / 2];
 
-	// row t of the coefficient block -> LDS row t (dequantised on the way when fused)
+	// row t of the coefficient block -> column-major pairs in P1 (dequantised on the way when fused)
 	global_row_load<N>(coeffs + (size_t)blk * (N * N) + t * N, v);
 	if (DEQUANT)
 	{
@@ -229,34 +304,64 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 #pragma unroll
 		for (int k = 0; k < N; ++k) v[k] = clip3(-32768, 32767, (v[k] * scale + round) >> shift);  // quantize.c:53-62
 	}
-	regs_to_row<N>(tile + t * S, v);
+	{
+		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
+		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
+#pragma unroll
+		for (int x = 0; x < N; ++x) row[2 * x] = (int16_t)v[x];
+	}
 	__syncthreads();
 
-	// first stage: column t, shift 7, clip to int16, written back in place (column t is this lane's)
+	// first stage: column t, shift 7, clip to int16; result row y, column t -> P2[y][pair_of(t)], half_of(t)
 #pragma unroll
-	for (int k = 0; k < N; ++k) v[k] = tile[k * S + t];
-	inverse_1d<N, DST>(v, w);
+	for (int q = 0; q < N / 2; ++q) p[q] = p1[q * T::S1 + t];
+	inverse_packed<N, DST>(p, 64, w);
+	{
+		int16_t *col = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p2) + my_pair_bytes);
 #pragma unroll
-	for (int y = 0; y < N; ++y) tile[y * S + t] = (int16_t)clip3(-32768, 32767, (w[y] + 64) >> 7);
+		for (int y = 0; y < N; ++y) col[y * (T::S2 * 2)] = (int16_t)clip3(-32768, 32767, w[y] >> 7);
+	}
 	__syncthreads();
 
-	// second stage: row t, shift 12, clip to int16
-	row_to_regs<N>(tile + t * S, v);
-	inverse_1d<N, DST>(v, w);
+	// Second stage + add.  The lanes are re-dealt so that consecutive lanes hold the SAME row of
+	// consecutive blocks: with blocks in raster order their prediction / destination rows are then
+	// contiguous in memory (one 64..256-byte run per row instead of N-byte pieces a stride apart).
+	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
+	uint32_t blk2 = wg * BPWG + local2;
+	const bool live2 = blk2 < n_blocks;
+	if (!live2) blk2 = n_blocks - 1;
+	{
+		const uint32_t *row = tiles + local2 * T::DWORDS + T::P1_DWORDS + t2 * T::S2;
+		if constexpr (N >= 8)
+		{
+#pragma unroll
+			for (int q = 0; q < N / 8; ++q)
+			{
+				const u32x4 d = *reinterpret_cast<const u32x4 *>(row + 4 * q);
+				p[4 * q + 0] = d.x; p[4 * q + 1] = d.y; p[4 * q + 2] = d.z; p[4 * q + 3] = d.w;
+			}
+		}
+		else
+		{
+			const u32x2 d = *reinterpret_cast<const u32x2 *>(row);
+			p[0] = d.x; p[1] = d.y;
+		}
+	}
+	inverse_packed<N, DST>(p, 2048, w);
 
 	// add to prediction row t.  The reference narrows pred + residual to int16 before clipping
 	// to 8 bits (residual_decode.c:350-368); the sum of a byte and a clipped int16 wraps only
 	// above 32767, which the narrowing cast reproduces.
-	const uint8_t *p = pred + pred_off[blk] + t * stride_pred;
-	uint8_t *d = dst + dst_off[blk] + t * stride_dst;
+	const uint8_t *pp = pred + pred_off[blk2] + t2 * stride_pred;
+	uint8_t *d = dst + dst_off[blk2] + t2 * stride_dst;
 	constexpr int CB = N >= 16 ? 16 : N;
-	if (live)
+	if (live2)
 	{
 #pragma unroll
 		for (int q = 0; q < N / CB; ++q)
 		{
 			Chunk<CB> c;
-			c.load(p + q * CB);
+			c.load(pp + q * CB);
 #pragma unroll
 			for (int k = 0; k < CB / 4; ++k)
 			{
@@ -264,9 +369,9 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 #pragma unroll
 				for (int b = 0; b < 4; ++b)
 				{
-					const int r = clip3(-32768, 32767, (w[q * CB + 4 * k + b] + 2048) >> 12);
-					const int s = (int)(short)((int)((c.d[k] >> (8 * b)) & 0xff) + r);
-					o |= (uint32_t)clip3(0, 255, s) << (8 * b);
+					const int r = clip3(-32768, 32767, w[q * CB + 4 * k + b] >> 12);
+					const int sum = (int)(short)((int)((c.d[k] >> (8 * b)) & 0xff) + r);
+					o |= (uint32_t)clip3(0, 255, sum) << (8 * b);
 				}
 				c.d[k] = o;
 			}
@@ -297,11 +402,21 @@ __global__ __launch_bounds__(kThreads) void forward_transform_kernel(
 
 	int v[N], w[N];
 
-	// first stage: row t of the residual; result (truncated to int16) stored transposed
-	global_row_load<N>(src + src_off[blk] + (ptrdiff_t)t * src_stride, v);
-	forward_1d<N, DST>(v, w);
+	// first stage: one residual row per lane; result (truncated to int16) stored transposed.  Lanes
+	// are dealt row-major across blocks here (same row of consecutive blocks in consecutive lanes)
+	// so that raster-ordered blocks read contiguous runs of the residual plane.
+	{
+		// (measured: the re-deal pays at N = 4 and 32; at 8 and 16 the transposed LDS store it implies conflicts more than the loads gain)
+		constexpr bool REDEAL = N == 4 || N == 32;
+		const uint32_t local1 = REDEAL ? threadIdx.x % BPWG : local, t1 = REDEAL ? threadIdx.x / BPWG : t;
+		uint32_t blk1 = wg * BPWG + local1;
+		if (blk1 >= n_blocks) blk1 = n_blocks - 1;
+		int16_t *tile1 = tiles + local1 * Tile<N>::HALFWORDS;
+		global_row_load<N>(src + src_off[blk1] + (ptrdiff_t)t1 * src_stride, v);
+		forward_1d<N, DST>(v, w);
 #pragma unroll
-	for (int k = 0; k < N; ++k) tile[k * S + t] = (int16_t)((w[k] + (1 << (S1 - 1))) >> S1);
+		for (int k = 0; k < N; ++k) tile1[k * S + t1] = (int16_t)((w[k] + (1 << (S1 - 1))) >> S1);
+	}
 	__syncthreads();
 
 	// second stage: lane t holds horizontal frequency t across all rows; output column t
