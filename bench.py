@@ -46,11 +46,12 @@ def algorithmic_bytes(w, h, ways):
              In this workload they all lie within +-7 pixels of one position, so they overlap and a
              cache serves most of the re-reads; pricing them separately lets "achieved" exceed the
              HBM peak.  We therefore price the 4-way kernel at its COMPULSORY footprint: the source
-             block plus the (W + 14) x (H + 14) window that contains every candidate.  The measured
-             HBM traffic (profiles/traffic.json) is slightly below even that."""
+             block plus the smaller of (a) four disjoint candidates and (b) the (W + 14) x (H + 14)
+             window that contains every candidate.  The measured HBM traffic (profiles/traffic.json)
+             is slightly below even that."""
     if ways == 1:
         return 2 * w * h + 4 + 8
-    return w * h + (w + 2 * MAX_DISP) * (h + 2 * MAX_DISP) + 4 * ways + 4 * (1 + ways)
+    return w * h + min(ways * w * h, (w + 2 * MAX_DISP) * (h + 2 * MAX_DISP)) + 4 * ways + 4 * (1 + ways)
 
 
 def max_over_ranks(seconds, device=None):

@@ -109,6 +109,42 @@ template <int LPR, int R> __device__ __forceinline__ uint32_t reduce_block(uint3
 	return t;
 }
 
+// Reference rows of the 4-way kernel, loaded dword-ALIGNED.  A byte-misaligned 16-byte lane load
+// costs the vector L1 about a quarter more than a dword-aligned one (measured: 4-way 64x64,
+// 1.41 ms with arbitrary dx, 1.11 ms with dx a multiple of 4; tools/explore_sad4_align.py), so the
+// lane loads the aligned dwords that contain its chunk and realigns in registers with
+// v_alignbyte_b32.  The one extra dword comes from the next lane of the row (DPP) or, for the
+// row's last lane, from a 4-byte load that is issued only when the row really is misaligned.
+// Every address touched lies in an aligned dword that holds at least one byte of the block row,
+// so no access can fault even at the very edges of a plane.
+template <int C, int LPR> struct AlignedRefChunk
+{
+	uint32_t d[C / 4];
+	uint32_t tail;
+	__device__ __forceinline__ void load(const uint8_t *p, uint32_t sh, bool last_lane_of_row)
+	{
+		const uint8_t *pa = p - sh;
+		Chunk<C> c;
+		c.load(pa);
+#pragma unroll
+		for (int i = 0; i < C / 4; ++i) d[i] = c.d[i];
+		tail = 0;
+		if (last_lane_of_row && sh) tail = *reinterpret_cast<const uint32_t *>(pa + C);
+	}
+	__device__ __forceinline__ void finish(uint32_t sh, bool last_lane_of_row, Chunk<C> &out) const
+	{
+		uint32_t next = tail;
+		if (LPR > 1)
+		{
+			const uint32_t from_neighbour = (uint32_t)__builtin_amdgcn_mov_dpp((int)d[0], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+			next = last_lane_of_row ? tail : from_neighbour;
+		}
+#pragma unroll
+		for (int i = 0; i < C / 4; ++i)
+			out.d[i] = __builtin_amdgcn_alignbyte(i + 1 < C / 4 ? d[i + 1] : next, d[i], sh);
+	}
+};
+
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 template <int W, int C, int R, int U, int WAYS, int OP>
 __global__ __launch_bounds__(kThreads) void block_cost_kernel(
@@ -146,6 +182,41 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 
 	Acc<C, OP> acc[WAYS];
 
+	if constexpr (WAYS == 4 && C == 16 && LPR >= 2)   // 8-byte chunks were measured too: slower (half the lanes issue the tail load)
+	{
+		// wide 4-way blocks: dword-aligned reference loads + register funnel shift
+		const bool last = chunk == LPR - 1;
+		for (int y = 0; y < H; y += R * U)
+		{
+			Chunk<C> s[U];
+			AlignedRefChunk<C, LPR> ra[U][WAYS];
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+			{
+				s[u].load(ps + u * step_src);
+#pragma unroll
+				for (int k = 0; k < WAYS; ++k)
+				{
+					const uint8_t *p = pr[k] + u * step_ref;
+					ra[u][k].load(p, (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), last);
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < U; ++u)
+#pragma unroll
+				for (int k = 0; k < WAYS; ++k)
+				{
+					const uint8_t *p = pr[k] + u * step_ref;
+					Chunk<C> r;
+					ra[u][k].finish((uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), last, r);
+					acc[k].add(s[u], r);
+				}
+			ps += U * step_src;
+#pragma unroll
+			for (int k = 0; k < WAYS; ++k) pr[k] += U * step_ref;
+		}
+	}
+	else
 	for (int y = 0; y < H; y += R * U)
 	{
 		Chunk<C> s[U], r[U][WAYS];

@@ -27,5 +27,15 @@ elif kind in ("inverse", "forward"):
         else:
             f = wl.forward_case(0, lg, n, 80 + i, frame=(wl.FRAME_W, wl.FRAME_H))
             B.transform(B.i16(f["src"]), f["src_stride"], B.off32(f["src_off"]), 0, lg)
+elif kind == "sad":
+    w, h, ways = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    n = (1 << 20) if w * h < 4096 else (1 << 19)
+    for i in range(3):
+        c = wl.sad_case(w, h, n, 100 + i, ways=4, frame=(wl.FRAME_W, wl.FRAME_H), device="cuda")
+        ro4 = B.off32(c["ref_off"])
+        if ways == 4:
+            B.sad_multiref(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4, w, h)
+        else:
+            B.sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4.view(n, 4)[:, 0].contiguous(), w, h)
 torch.cuda.synchronize()
 print("done")
