@@ -64,6 +64,14 @@ def ssd(a, stride_a, b, stride_b, a_off, b_off, w, h, out=None):
     return out
 
 
+def hadamard_satd(a, stride_a, b, stride_b, a_off, b_off, log2n, out=None):
+    n = a_off.numel()
+    out = torch.empty(n, dtype=torch.int32, device=a.device) if out is None else out
+    check(lib().hevcasm_hip_hadamard_satd_batch(a.data_ptr(), stride_a, b.data_ptr(), stride_b, a_off.data_ptr(), b_off.data_ptr(),
+                                                out.data_ptr(), log2n, n, _stream()), "hadamard_satd_batch")
+    return out
+
+
 def pred_uni(dst, stride_dst, ref, stride_ref, dst_off, ref_off, frac, taps, w, h):
     n = dst_off.numel()
     check(lib().hevcasm_hip_pred_uni_8to8_batch(dst.data_ptr(), stride_dst, ref.data_ptr(), stride_ref, dst_off.data_ptr(),

@@ -27,6 +27,7 @@ HIP_API = {
     "hevcasm_hip_sad_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _sz, _vp]),
     "hevcasm_hip_sad_multiref_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _sz, _vp]),
     "hevcasm_hip_ssd_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
+    "hevcasm_hip_hadamard_satd_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_pred_uni_8to8_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_bi_8to8_batch": (_i, [_vp, _pd, _vp, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_inverse_transform_add_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
@@ -49,6 +50,7 @@ HOST_API = {
     "hevcasm_populate_sad": (None, [_vp, _i]),
     "hevcasm_populate_sad_multiref": (None, [_vp, _i]),
     "hevcasm_populate_ssd": (None, [_vp, _i]),
+    "hevcasm_populate_hadamard_satd": (None, [_vp, _i]),
     "hevcasm_populate_pred_uni_8to8": (None, [_vp, _i]),
     "hevcasm_populate_pred_bi_8to8": (None, [_vp, _i]),
     "hevcasm_populate_inverse_transform_add": (None, [_vp, _i, _i]),
@@ -59,6 +61,7 @@ HOST_API = {
     "hevcasm_test_sad": _test_fn,
     "hevcasm_test_sad_multiref": _test_fn,
     "hevcasm_test_ssd": _test_fn,
+    "hevcasm_test_hadamard_satd": _test_fn,
     "hevcasm_test_pred_uni": _test_fn,
     "hevcasm_test_pred_bi": _test_fn,
     "hevcasm_test_inverse_transform_add": _test_fn,

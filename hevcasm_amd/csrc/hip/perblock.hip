@@ -207,6 +207,24 @@ int hevcasm_hip1_ssd(const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *
 	return *a.h<int>(out);
 }
 
+static int satd1(int log2n, const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB)
+{
+	const int n = 1 << log2n;
+	Arena &a = g_arena;
+	a.reset();
+	ptrdiff_t sa, sb;
+	const size_t pa = stage_plane(a, srcA, stride_srcA, n, n, 0, 0, &sa);
+	const size_t pb = stage_plane(a, srcB, stride_srcB, n, n, 0, 0, &sb);
+	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
+	const size_t out = a.take(16);
+	Arena::check_call(hevcasm_hip_hadamard_satd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), log2n, 1, a.stream), "hadamard_satd");
+	a.wait();
+	return *a.h<int>(out);
+}
+int hevcasm_hip1_satd_2(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd1(1, a, sa, b, sb); }
+int hevcasm_hip1_satd_4(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd1(2, a, sa, b, sb); }
+int hevcasm_hip1_satd_8(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd1(3, a, sa, b, sb); }
+
 void hevcasm_hip1_pred_uni_8tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref, ptrdiff_t sr, int w, int h, int xf, int yf) { pred_uni(8, dst, sd, ref, sr, w, h, xf, yf); }
 void hevcasm_hip1_pred_uni_4tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref, ptrdiff_t sr, int w, int h, int xf, int yf) { pred_uni(4, dst, sd, ref, sr, w, h, xf, yf); }
 void hevcasm_hip1_pred_bi_8tap(uint8_t *dst, ptrdiff_t sd, const uint8_t *r0, const uint8_t *r1, ptrdiff_t sr, int w, int h, int x0, int y0, int x1, int y1) { pred_bi(8, dst, sd, r0, r1, sr, w, h, x0, y0, x1, y1); }

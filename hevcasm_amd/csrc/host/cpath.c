@@ -47,6 +47,36 @@ int hevcasm_c_ssd(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdif
 	return total;
 }
 
+/* SATD by the definition: T = H D H with the (unnormalised, natural-order) Hadamard matrix
+ * H[i][j] = (-1)^popcount(i & j).  The sum of magnitudes does not depend on the row order of H,
+ * so it equals the reference's butterfly result (hadamard.c:76-111). */
+static int satd(int n, const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b)
+{
+	int d[8][8], t[8][8];
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x) d[y][x] = a[y * stride_a + x] - b[y * stride_b + x];
+	for (int y = 0; y < n; ++y)
+		for (int u = 0; u < n; ++u)
+		{
+			int s = 0;
+			for (int x = 0; x < n; ++x) s += __builtin_parity((unsigned)(u & x)) ? -d[y][x] : d[y][x];
+			t[y][u] = s;
+		}
+	int total = n / 4;
+	for (int v = 0; v < n; ++v)
+		for (int u = 0; u < n; ++u)
+		{
+			int s = 0;
+			for (int y = 0; y < n; ++y) s += __builtin_parity((unsigned)(v & y)) ? -t[y][u] : t[y][u];
+			total += s < 0 ? -s : s;
+		}
+	return total / (n / 2);
+}
+
+int hevcasm_c_satd_2(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd(2, a, sa, b, sb); }
+int hevcasm_c_satd_4(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd(4, a, sa, b, sb); }
+int hevcasm_c_satd_8(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd(8, a, sa, b, sb); }
+
 /* -------------------------------------------------------------------------- inter prediction */
 
 int hevcasm_c_filter_tap(int n, int frac, int k)

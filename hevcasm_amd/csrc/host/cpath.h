@@ -13,10 +13,12 @@
 #include "pred_inter.h"
 #include "residual_decode.h"
 #include "quantize.h"
+#include "hadamard.h"
 
 hevcasm_sad hevcasm_c_sad;
 hevcasm_sad_multiref hevcasm_c_sad_multiref_4;
 hevcasm_ssd hevcasm_c_ssd;
+hevcasm_hadamard_satd hevcasm_c_satd_2, hevcasm_c_satd_4, hevcasm_c_satd_8;
 hevcasm_pred_uni_8to8 hevcasm_c_pred_uni_8tap, hevcasm_c_pred_uni_4tap;
 hevcasm_pred_bi_8to8 hevcasm_c_pred_bi_8tap, hevcasm_c_pred_bi_4tap;
 hevcasm_inverse_transform_add hevcasm_c_idst_4, hevcasm_c_idct_4, hevcasm_c_idct_8, hevcasm_c_idct_16, hevcasm_c_idct_32;

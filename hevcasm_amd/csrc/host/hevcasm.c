@@ -3,9 +3,9 @@
  *
  * Counterpart of the reference's src/lib/hevcasm.c.  hevcasm_instruction_set_support()
  * (:99-138 there) additionally reports HEVCASM_HIP when the HIP side finds a gfx950 device.
- * hevcasm_main() (:152-186 there) runs the ten hot-path self-tests in the reference's order;
- * the reference's intra-DC and Hadamard tests belong to families this library does not
- * implement (out of scope) and are not run.
+ * hevcasm_main() (:152-186 there) runs the ten hot-path self-tests and the Hadamard SATD test
+ * in the reference's order; the reference's intra-DC test belongs to a family this library
+ * does not implement (out of scope) and is not run.
  */
 #include "hevcasm.h"
 #include "sad.h"
@@ -13,6 +13,7 @@
 #include "pred_inter.h"
 #include "residual_decode.h"
 #include "quantize.h"
+#include "hadamard.h"
 #include "hevcasm_hip.h"
 
 #include <stdlib.h>
@@ -79,6 +80,7 @@ int hevcasm_main(int argc, const char *argv[])
 	hevcasm_test_sad_multiref(&error_count, mask);
 	hevcasm_test_sad(&error_count, mask);
 	hevcasm_test_ssd(&error_count, mask);
+	hevcasm_test_hadamard_satd(&error_count, mask);
 	hevcasm_test_quantize_inverse(&error_count, mask);
 	hevcasm_test_quantize(&error_count, mask);
 	hevcasm_test_quantize_reconstruct(&error_count, mask);

@@ -17,6 +17,7 @@
 #include "pred_inter.h"
 #include "residual_decode.h"
 #include "quantize.h"
+#include "hadamard.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -25,6 +26,7 @@ extern "C" {
 hevcasm_sad hevcasm_hip1_sad;
 hevcasm_sad_multiref hevcasm_hip1_sad_multiref_4;
 hevcasm_ssd hevcasm_hip1_ssd;
+hevcasm_hadamard_satd hevcasm_hip1_satd_2, hevcasm_hip1_satd_4, hevcasm_hip1_satd_8;
 hevcasm_pred_uni_8to8 hevcasm_hip1_pred_uni_8tap, hevcasm_hip1_pred_uni_4tap;
 hevcasm_pred_bi_8to8 hevcasm_hip1_pred_bi_8tap, hevcasm_hip1_pred_bi_4tap;
 hevcasm_inverse_transform_add hevcasm_hip1_idst_4, hevcasm_hip1_idct_4, hevcasm_hip1_idct_8, hevcasm_hip1_idct_16, hevcasm_hip1_idct_32;

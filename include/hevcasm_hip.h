@@ -86,6 +86,13 @@ int hevcasm_hip_ssd_batch(
 	const uint32_t *offA, const uint32_t *offB, int *ssd,
 	int w, int h, size_t n_blocks, void *stream);
 
+/* Batched hevcasm_hadamard_satd (reference hadamard.h:53; C body hadamard.c:76-111):
+ * log2TrafoSize 1, 2 or 3 (2x2, 4x4, 8x8 blocks). */
+int hevcasm_hip_hadamard_satd_batch(
+	const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB,
+	const uint32_t *offA, const uint32_t *offB, int *satd,
+	int log2TrafoSize, size_t n_blocks, void *stream);
+
 /* ---- inter prediction ----------------------------------------------------------------- */
 
 /* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).

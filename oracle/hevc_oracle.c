@@ -50,6 +50,49 @@ int orc_ssd(const uint8_t *pA, ptrdiff_t strideA, const uint8_t *pB, ptrdiff_t s
 	return acc;
 }
 
+/* ---------------------------------------------------------------- Hadamard SATD */
+
+/* hadamard.c:45-58: one butterfly stage of span n over m values read at `stride` */
+static void hadamard_stage(int m, int n, int *dst, const int *src, ptrdiff_t stride)
+{
+	for (int i = 0; i < m; i += 2 * n)
+		for (int j = 0; j < n; ++j)
+		{
+			const int a = src[(i + j) * stride], b = src[(i + n + j) * stride];
+			dst[i + j] = a + b;
+			dst[i + n + j] = a - b;
+		}
+}
+
+/* hadamard.c:60-73: stages of span n, n/2, ..., 1 */
+static void hadamard_1d(int m, int n, int *dst, const int *src, ptrdiff_t stride)
+{
+	if (n == 1) { hadamard_stage(m, n, dst, src, stride); return; }
+	int tmp[8];
+	hadamard_stage(m, n, tmp, src, stride);
+	hadamard_1d(m, n / 2, dst, tmp, 1);
+}
+
+/* hadamard.c:76-111: rows then columns, sum of magnitudes, (sum + n/4) / (n/2) */
+int orc_hadamard_satd(int n, const uint8_t *pA, ptrdiff_t strideA, const uint8_t *pB, ptrdiff_t strideB)
+{
+	int inter[8][8];
+	for (int y = 0; y < n; ++y)
+	{
+		int diff[8];
+		for (int x = 0; x < n; ++x) diff[x] = pA[x + y * strideA] - pB[x + y * strideB];
+		hadamard_1d(n, n / 2, inter[y], diff, 1);
+	}
+	int sum = n / 4;
+	for (int x = 0; x < n; ++x)
+	{
+		int col[8];
+		hadamard_1d(n, n / 2, col, &inter[0][x], 8);
+		for (int y = 0; y < n; ++y) sum += abs(col[y]);
+	}
+	return sum / (n / 2);
+}
+
 /* ------------------------------------------------------------ inter prediction */
 
 /* pred_inter.c:53-83: HEVC luma (8-tap, quarter-pel) and chroma (4-tap, eighth-pel) filters */
@@ -469,6 +512,14 @@ void orc_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t stride_rec, const ui
 #pragma omp parallel for schedule(static)
 	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
 		orc_quantize_reconstruct(rec + rec_off[i], stride_rec, pred + pred_off[i], stride_pred, res + (size_t)nCbS * nCbS * i, nCbS);
+}
+
+void orc_hadamard_satd_batch(int n, const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b,
+		const uint32_t *a_off, const uint32_t *b_off, int *satd, size_t count)
+{
+#pragma omp parallel for schedule(static)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)count; ++i)
+		satd[i] = orc_hadamard_satd(n, a + a_off[i], stride_a, b + b_off[i], stride_b);
 }
 
 void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,

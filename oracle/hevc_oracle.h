@@ -57,6 +57,9 @@ int orc_quantize(int16_t *dst, const int16_t *src, int scale, int shift, int off
 /* quantize.h:99; quantize.c:292-302 */
 void orc_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n);
 
+/* hadamard.h:53; hadamard.c:45-111: n = 2, 4 or 8 */
+int orc_hadamard_satd(int n, const uint8_t *pA, ptrdiff_t strideA, const uint8_t *pB, ptrdiff_t strideB);
+
 /* the transform matrix the oracle generates (checked against the literals at
  * residual_decode.c:254-288 through the refdrv parity tests) */
 int orc_dct_matrix(int n, int k, int i);
@@ -88,6 +91,9 @@ void orc_transform_batch(int trType, int log2TrafoSize, int16_t *coeffs, const i
 void orc_quantize_batch(int16_t *dst, const int16_t *src, int scale, int shift, int offset, int n_per_block, int *cbf, size_t n_blocks);
 void orc_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
 		const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res, int nCbS, size_t n);
+
+void orc_hadamard_satd_batch(int n, const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b,
+		const uint32_t *a_off, const uint32_t *b_off, int *satd, size_t count);
 
 /* Full search: for each block, SAD (sad.c:47-60) at every
  * displacement (dx,dy) in [-range,range]^2 around ref_off; best = minimum cost, ties broken by

@@ -79,6 +79,14 @@ def ssd_batch(a, stride_a, b, stride_b, a_off, b_off, w, h):
     return out
 
 
+def hadamard_satd_batch(n, a, stride_a, b, stride_b, a_off, b_off):
+    a, b, a_off, b_off = _u8(a), _u8(b), _u32(a_off), _u32(b_off)
+    out = np.empty(a_off.size, dtype=np.int32)
+    lib().orc_hadamard_satd_batch(C.c_int(n), _p(a), C.c_ssize_t(stride_a), _p(b), C.c_ssize_t(stride_b),
+                                  _p(a_off), _p(b_off), _p(out), C.c_size_t(a_off.size))
+    return out
+
+
 def pred_uni_batch(taps, dst_bytes, stride_dst, ref, stride_ref, dst_off, ref_off, frac, w, h):
     ref, dst_off, ref_off, frac = _u8(ref), _u32(dst_off), _u32(ref_off), _u8(frac)
     n = dst_off.size

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
-OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME = 8, 9, 10, 11, 12
+OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD = 8, 9, 10, 11, 12, 13
 OP_SELFTEST, OP_BENCH_SAD = 20, 30
 
 
@@ -88,6 +88,10 @@ class RefProc:
 
     def ssd_batch(self, a, stride_a, b, stride_b, a_off, b_off, w, h):
         o = self.call(OP_SSD, [stride_a, stride_b, w, h, len(a_off)], [_u8(a), _u8(b), _u32(a_off), _u32(b_off)])
+        return np.frombuffer(o[0], dtype=np.int32).copy()
+
+    def hadamard_satd_batch(self, n, a, stride_a, b, stride_b, a_off, b_off):
+        o = self.call(OP_SATD, [stride_a, stride_b, n, len(a_off)], [_u8(a), _u8(b), _u32(a_off), _u32(b_off)])
         return np.frombuffer(o[0], dtype=np.int32).copy()
 
     def pred_uni_batch(self, taps, dst_bytes, stride_dst, ref, stride_ref, dst_off, ref_off, frac, w, h):

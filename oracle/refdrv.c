@@ -24,6 +24,7 @@
 #include "pred_inter.h"
 #include "residual_decode.h"
 #include "quantize.h"
+#include "hadamard.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -48,6 +49,7 @@ static hevcasm_table_transform t_fwd;
 static hevcasm_table_quantize_inverse t_deq;
 static hevcasm_table_quantize t_q;
 static hevcasm_table_quantize_reconstruct t_rec;
+static hevcasm_table_hadamard_satd t_satd;
 
 static void populate_all(void)
 {
@@ -62,6 +64,7 @@ static void populate_all(void)
 	hevcasm_populate_quantize_inverse(&t_deq, m);
 	hevcasm_populate_quantize(&t_q, m);
 	hevcasm_populate_quantize_reconstruct(&t_rec, m);
+	hevcasm_populate_hadamard_satd(&t_satd, m);
 }
 
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
@@ -75,7 +78,7 @@ static double now_s(void)
 
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
-	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12,
+	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13,
 	OP_SELFTEST = 20, OP_BENCH_SAD = 30
 };
 
@@ -140,6 +143,16 @@ int main(void)
 			int *r = (int *)malloc(4 * n + 4);
 			for (size_t i = 0; i < n; ++i)
 				r[i] = f(in[0].p + ao[i], par[0], in[1].p + bo[i], par[1], (int)par[2], (int)par[3]);
+			out[0].p = (uint8_t *)r; out[0].bytes = 4 * n; nout = 1;
+			break;
+		}
+		case OP_SATD: /* par: stride_a, stride_b, n (2|4|8), count; bufs a, b, a_off, b_off */
+		{
+			const size_t n = (size_t)par[3];
+			const uint32_t *ao = (const uint32_t *)in[2].p, *bo = (const uint32_t *)in[3].p;
+			hevcasm_hadamard_satd *f = *hevcasm_get_hadamard_satd(&t_satd, ilog2((int)par[2]));
+			int *r = (int *)malloc(4 * n + 4);
+			for (size_t i = 0; i < n; ++i) r[i] = f(in[0].p + ao[i], par[0], in[1].p + bo[i], par[1]);
 			out[0].p = (uint8_t *)r; out[0].bytes = 4 * n; nout = 1;
 			break;
 		}
@@ -286,6 +299,7 @@ int main(void)
 			if (par[0] & 128) hevcasm_test_quantize_inverse(&errors, m);
 			if (par[0] & 256) hevcasm_test_quantize(&errors, m);
 			if (par[0] & 512) hevcasm_test_quantize_reconstruct(&errors, m);
+			if (par[0] & 1024) hevcasm_test_hadamard_satd(&errors, m);
 			fflush(f);
 			stdout = keep;
 			fclose(f);

@@ -52,6 +52,17 @@ def ssd_cases(n=64, seed=200):
     return out
 
 
+def satd_cases(n=80, seed=250):
+    out = []
+    for i, size in enumerate((2, 4, 8)):
+        out.append(("satd_%d" % size, "satd", wl.sad_case(size if size > 2 else 4, size if size > 2 else 4, n, seed + i, max_disp=7) | dict(size=size)))
+        out.append(("satd_%d_max" % size, "satd", wl.sad_case(4 if size == 2 else size, 4 if size == 2 else size, 6, seed + 10 + i, kind="max") | dict(size=size)))
+        out.append(("satd_%d_zero" % size, "satd", wl.sad_case(4 if size == 2 else size, 4 if size == 2 else size, 6, seed + 20 + i, kind="zeros") | dict(size=size)))
+    out.append(("satd_8_n1", "satd", wl.sad_case(8, 8, 1, seed + 30) | dict(size=8)))
+    out.append(("satd_4_n257", "satd", wl.sad_case(4, 4, 257, seed + 31) | dict(size=4)))
+    return out
+
+
 def pred_uni_cases(n=24, seed=300, sizes=None):
     out = []
     for taps in (8, 4):
@@ -194,7 +205,7 @@ def _me_case(w, h, r, n, seed):
                 ref_off=ref_off.astype(np.uint32), w=w, h=h, range=r, n=n)
 
 
-ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
+ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases)
 
 
@@ -208,6 +219,8 @@ def _run_cpu(api, family, c):
         return (api.sad_multiref_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
     if family == "ssd":
         return (api.ssd_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+    if family == "satd":
+        return (api.hadamard_satd_batch(c["size"], c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"]),)
     if family == "pred_uni":
         d = api.pred_uni_batch(c["taps"], c["dst_bytes"], c["stride_dst"], c["ref0"], c["stride_ref"], c["dst_off"], c["ref0_off"], c["frac0"], c["w"], c["h"])
         return (_dst_rows(d, c["stride_dst"], c["dst_off"], c["w"], c["h"]),)
@@ -267,6 +280,8 @@ def run_hip(family, c):
         return (cpu(B.sad_multiref(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
     if family == "ssd":
         return (cpu(B.ssd(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+    if family == "satd":
+        return (cpu(B.hadamard_satd(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), int(np.log2(c["size"])))),)
     if family == "pred_uni":
         d = B.pred_uni(plane(c["dst_bytes"]), c["stride_dst"], u8(c["ref0"]), c["stride_ref"], off(c["dst_off"]), off(c["ref0_off"]), u8(c["frac0"]), c["taps"], c["w"], c["h"])
         return _only_blocks(cpu(d), c["stride_dst"], c["dst_off"], c["w"], c["h"])

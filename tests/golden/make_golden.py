@@ -47,6 +47,7 @@ def small_cases():
         out.append(("sad4_%dx%d" % (w, h), "sad4", wl.sad_case(w, h, 6, 12 + w, ways=4, frame=(2 * w, 2 * h))))
     for s in (4, 8, 16, 32, 64):
         out.append(("ssd_%d" % s, "ssd", wl.sad_case(s, s, 6, 21 + s, frame=(2 * s, 2 * s))))
+    out += [x for x in cases.satd_cases(n=12) if x[0] in ("satd_2", "satd_4", "satd_8", "satd_8_max")]
     for taps, sizes in ((8, [(64, 64), (16, 16), (12, 16), (8, 4)]), (4, [(32, 32), (8, 8), (6, 8), (2, 4)])):
         for (w, h) in sizes:
             out.append(("uni%d_%dx%d" % (taps, w, h), "pred_uni", wl.pred_case(taps, w, h, 8, 31 + w, frame=(2 * w, 2 * h))))

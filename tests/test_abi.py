@@ -50,7 +50,7 @@ def test_table_layouts_match_reference_abi():
     """Field counts of the caller-owned tables: a codec compiled against the
     reference's headers indexes these structs directly."""
     from_header = {
-        "sad": 12, "sad_multiref": 16 * 16 + 1, "ssd": 5, "pred_uni_8to8": 2 * 9 * 2 * 2, "pred_bi_8to8": 2 * 5 * 2,
+        "sad": 12, "sad_multiref": 16 * 16 + 1, "ssd": 5, "hadamard_satd": 3, "pred_uni_8to8": 2 * 9 * 2 * 2, "pred_bi_8to8": 2 * 5 * 2,
         "inverse_transform_add": 5, "transform": 5, "quantize_inverse": 1, "quantize": 1, "quantize_reconstruct": 4}
     L = capi.lib()
     for name, slots in from_header.items():
@@ -68,7 +68,7 @@ def test_table_layouts_match_reference_abi():
         assert all(filled), "%s: C_REF must fill every slot" % name
 
 
-@pytest.mark.parametrize("name", ["sad", "sad_multiref", "ssd", "pred_uni_8to8", "pred_bi_8to8", "transform",
+@pytest.mark.parametrize("name", ["sad", "sad_multiref", "ssd", "hadamard_satd", "pred_uni_8to8", "pred_bi_8to8", "transform",
                                   "quantize_inverse", "quantize", "quantize_reconstruct"])
 def test_selector_masks(name):
     """NULL = unsupported (reference convention): x86 SIMD bits alone select nothing here;
@@ -99,6 +99,7 @@ def test_get_sad_multiref_ways():
 #include "residual_decode.h"
 #include "quantize.h"
 #include "ssd.h"
+#include "hadamard.h"
 int main(void) {
 	hevcasm_table_sad_multiref t; hevcasm_table_sad s; hevcasm_table_pred_uni_8to8 u; hevcasm_table_pred_bi_8to8 b;
 	if (hevcasm_get_sad_multiref(&t, 3, 16, 16)) return 1;
@@ -109,6 +110,7 @@ int main(void) {
 	if (hevcasm_get_pred_uni_8to8(&u, 4, 2, 4, 0, 7) != &u.p[0][1][0][1]) return 6;
 	if (hevcasm_get_pred_bi_8to8(&b, 8, 48, 64, 0, 0, 0, 2) != &b.p[1][3][1]) return 7;
 	if (HEVCASM_RECT(16, 8) != 0x1008) return 8;
+	{ hevcasm_table_hadamard_satd h; if (hevcasm_get_hadamard_satd(&h, 3) != &h.satd[2]) return 10; }
 	if (HEVCASM_HIP != 512 || HEVCASM_AVX2 != 256 || HEVCASM_INSTRUCTION_SET_COUNT != 10) return 9;
 	return 0;
 }'''

@@ -53,6 +53,15 @@ def test_sad_and_multiref_and_ssd(oracle_lib):
             assert np.array_equal(np.array(got), want), name
 
 
+def test_hadamard_satd(oracle_lib):
+    for name, family, c in cases.satd_cases(n=20):
+        size = c["size"]
+        f = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD)(_slot("hevcasm_populate_hadamard_satd", 3, int(np.log2(size)) - 1))
+        src, ref = np.ascontiguousarray(c["src"]), np.ascontiguousarray(c["ref"])
+        got = [f(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, c["ref_off"][i]), c["stride_ref"]) for i in range(c["n"])]
+        assert np.array_equal(np.array(got), cases.run_oracle(family, c)[0]), name
+
+
 def test_pred_uni_and_bi(oracle_lib):
     for name, family, c in cases.pred_uni_cases(n=6) + cases.pred_bi_cases(n=4):
         taps, w, h, n = c["taps"], c["w"], c["h"], c["n"]

@@ -184,7 +184,7 @@ def test_selftest_hip_column():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import ctypes as C, sys; sys.path.insert(0, %r); from hevcasm_amd import capi; L = capi.lib(); e = C.c_int(0);\n"
             "m = capi.C_REF | capi.HIP\n"
-            "for f in ('sad', 'sad_multiref', 'ssd', 'quantize_inverse', 'quantize', 'quantize_reconstruct', 'pred_uni', 'pred_bi', 'inverse_transform_add', 'transform'):\n"
+            "for f in ('sad', 'sad_multiref', 'ssd', 'hadamard_satd', 'quantize_inverse', 'quantize', 'quantize_reconstruct', 'pred_uni', 'pred_bi', 'inverse_transform_add', 'transform'):\n"
             "    getattr(L, 'hevcasm_test_' + f)(C.byref(e), m)\n"
             "print('ERRORS', e.value)\n") % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)

@@ -39,9 +39,9 @@ def test_sad_selftest_grammar_and_zero_errors():
 
 
 def test_quick_families_zero_errors():
-    out = _run(["sad_multiref", "ssd", "quantize_inverse", "quantize", "quantize_reconstruct", "pred_uni", "pred_bi"])
+    out = _run(["sad_multiref", "ssd", "hadamard_satd", "quantize_inverse", "quantize", "quantize_reconstruct", "pred_uni", "pred_bi"])
     assert "MISMATCH" not in out and "ERRORS 0" in out
-    assert out.count("C_OPT:") == 23 + 5 + 4 + 4 + 4 + 24 * 8 + 22 * 4
+    assert out.count("C_OPT:") == 23 + 5 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4
 
 
 def test_same_rows_as_the_reference_selftest(tmp_path, refproc):
