@@ -193,7 +193,7 @@ template <int TAPS, int NDW> struct RefStream
 	}
 };
 
-template <int TAPS, int NDW, bool BI>
+template <int TAPS, int NDW, bool BI, bool PREFETCH>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
@@ -250,19 +250,24 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 #pragma unroll
 		for (int i = 0; i < TAPS; ++i)
 		{
+			if (!PREFETCH) break;
 			if (TAPS - 1 + i < rows) rs[r].next_row(rs[r].cur[i]); else rs[r].zero_row(rs[r].cur[i]);
 		}
 	}
 
 	for (int y0 = 0; y0 < H; y0 += TAPS)
 	{
-		// next group's rows: issued now, consumed one group later
+		// PREFETCH: next group's rows are issued now and consumed one group later (two row buffers);
+		// otherwise this group's rows are issued here and other waves cover the latency (one buffer,
+		// fewer registers, more waves per SIMD).
 #pragma unroll
 		for (int r = 0; r < NREF; ++r)
 #pragma unroll
 			for (int i = 0; i < TAPS; ++i)
 			{
-				if (y0 + 2 * TAPS - 1 + i < rows) rs[r].next_row(rs[r].nxt[i]); else rs[r].zero_row(rs[r].nxt[i]);
+				const int q = y0 + (PREFETCH ? 2 : 1) * TAPS - 1 + i;
+				uint32_t (&slot)[NDW] = PREFETCH ? rs[r].nxt[i] : rs[r].cur[i];
+				if (q < rows) rs[r].next_row(slot); else rs[r].zero_row(slot);
 			}
 
 #pragma unroll
@@ -313,14 +318,25 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 				out += stride_dst;
 			}
 		}
+		if (PREFETCH)
+		{
 #pragma unroll
-		for (int r = 0; r < NREF; ++r)
+			for (int r = 0; r < NREF; ++r)
 #pragma unroll
-			for (int i = 0; i < TAPS; ++i)
+				for (int i = 0; i < TAPS; ++i)
 #pragma unroll
-				for (int m = 0; m < NDW; ++m) rs[r].cur[i][m] = rs[r].nxt[i][m];
+					for (int m = 0; m < NDW; ++m) rs[r].cur[i][m] = rs[r].nxt[i][m];
+		}
 	}
 }
+
+// Measured on MI355X: without the second row buffer the 8-tap kernel needs 80 instead of 97 VGPRs
+// (148 instead of 180 for bi-prediction), i.e. one more wave per SIMD, and runs 4-30 % faster; the
+// extra waves hide the load latency better than the software prefetch did.
+#ifndef HEVCASM_PRED_PREFETCH
+#define HEVCASM_PRED_PREFETCH 0
+#endif
+constexpr bool kPrefetch = HEVCASM_PRED_PREFETCH != 0;
 
 template <int TAPS, int NDW, bool BI>
 static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
@@ -330,7 +346,7 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
 	const int ppw = kWave / lw;
 	const uint32_t grid = ceil_div(n, (size_t)ppw * (kThreads / kWave));
-	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI>), dim3(grid), dim3(kThreads), 0, st,
+	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, kPrefetch>), dim3(grid), dim3(kThreads), 0, st,
 			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n);
 	return launch_status("pred_stream_kernel");
 }
@@ -343,6 +359,7 @@ static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const ui
 	// 8 bytes per lane per row halves the load instructions (the texture-address unit handles 4 lanes
 	// per cycle whatever their width); PUs narrower than 8 keep 4 bytes so that no lane is half idle.
 	// The window must hold at least one full lane load: W + T - 1 >= 8 for the wide variant.
+	// (4 bytes per lane for bi-prediction, 95 VGPRs, was measured too: 10 % slower at 16x16, equal at 64x64.)
 	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
 	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
 }
