@@ -102,7 +102,7 @@ template <int TAPS, int NDW> struct RefStream
 {
 	static constexpr int NX = NDW + (TAPS == 8 ? 2 : 1);   // column groups the horizontal pass reads
 	uint32_t e[TAPS][NDW], o[TAPS][NDW];   // window slots: even / odd columns of each dword as int16 pairs
-	uint32_t cur[TAPS][NDW], nxt[TAPS][NDW];
+	uint32_t pending[NDW];       // the row whose load is in flight
 	const uint8_t *p;            // this lane's bytes of the next window row to load
 	ptrdiff_t stride;
 	uint32_t shift;              // 8 * bytes the last lane's load was moved left to stay inside the window
@@ -193,7 +193,7 @@ template <int TAPS, int NDW> struct RefStream
 	}
 };
 
-template <int TAPS, int NDW, bool BI, bool PREFETCH>
+template <int TAPS, int NDW, bool BI>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
@@ -236,40 +236,28 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *out = dst + dst_off[pu] + CPL * j;
 	const int rows = H + TAPS - 1;                    // window rows
 
-	// prologue: window rows 0 .. T-2 into slots 0 .. T-2; rows T-1 .. 2T-2 are group 0's stream
+	// prologue: window rows 0 .. T-2 into slots 0 .. T-2, and the load of row T-1 in flight
 #pragma unroll
 	for (int r = 0; r < NREF; ++r)
 	{
+		uint32_t first[TAPS - 1][NDW];
 #pragma unroll
 		for (int q = 0; q < TAPS - 1; ++q)
 		{
-			if (q < rows) rs[r].next_row(rs[r].cur[q]); else rs[r].zero_row(rs[r].cur[q]);
+			if (q < rows) rs[r].next_row(first[q]); else rs[r].zero_row(first[q]);
 		}
 #pragma unroll
-		for (int q = 0; q < TAPS - 1; ++q) rs[r].unpack(q, rs[r].cur[q]);
-#pragma unroll
-		for (int i = 0; i < TAPS; ++i)
-		{
-			if (!PREFETCH) break;
-			if (TAPS - 1 + i < rows) rs[r].next_row(rs[r].cur[i]); else rs[r].zero_row(rs[r].cur[i]);
-		}
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].unpack(q, first[q]);
+		if (TAPS - 1 < rows) rs[r].next_row(rs[r].pending); else rs[r].zero_row(rs[r].pending);
 	}
 
+	// One row of output per trip; the loop is unrolled by T so that window slots are static.  The
+	// load of the NEXT row's newest window row is issued before this row is computed: one row of
+	// look-ahead costs NDW registers, and the other waves of the SIMD cover the rest of the latency
+	// (a software prefetch one whole group of T rows ahead was measured: +17 VGPRs, one wave fewer
+	// per SIMD, 4-30 % slower).
 	for (int y0 = 0; y0 < H; y0 += TAPS)
 	{
-		// PREFETCH: next group's rows are issued now and consumed one group later (two row buffers);
-		// otherwise this group's rows are issued here and other waves cover the latency (one buffer,
-		// fewer registers, more waves per SIMD).
-#pragma unroll
-		for (int r = 0; r < NREF; ++r)
-#pragma unroll
-			for (int i = 0; i < TAPS; ++i)
-			{
-				const int q = y0 + (PREFETCH ? 2 : 1) * TAPS - 1 + i;
-				uint32_t (&slot)[NDW] = PREFETCH ? rs[r].nxt[i] : rs[r].cur[i];
-				if (q < rows) rs[r].next_row(slot); else rs[r].zero_row(slot);
-			}
-
 #pragma unroll
 		for (int i = 0; i < TAPS; ++i)
 		{
@@ -280,7 +268,11 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 #pragma unroll
 				for (int r = 0; r < NREF; ++r)
 				{
-					rs[r].unpack((i + TAPS - 1) % TAPS, rs[r].cur[i]);   // window row y + T - 1
+					uint32_t newest[NDW];
+#pragma unroll
+					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[m];
+					if (y + TAPS < rows) rs[r].next_row(rs[r].pending);     // window row (y + 1) + T - 1
+					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
 					uint32_t ve[Stream::NX], vo[Stream::NX];
 					rs[r].vertical(i, ve, vo);
 					rs[r].horizontal(ve, vo, BI ? 0 : 2048, s[r]);
@@ -318,25 +310,8 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 				out += stride_dst;
 			}
 		}
-		if (PREFETCH)
-		{
-#pragma unroll
-			for (int r = 0; r < NREF; ++r)
-#pragma unroll
-				for (int i = 0; i < TAPS; ++i)
-#pragma unroll
-					for (int m = 0; m < NDW; ++m) rs[r].cur[i][m] = rs[r].nxt[i][m];
-		}
 	}
 }
-
-// Measured on MI355X: without the second row buffer the 8-tap kernel needs 80 instead of 97 VGPRs
-// (148 instead of 180 for bi-prediction), i.e. one more wave per SIMD, and runs 4-30 % faster; the
-// extra waves hide the load latency better than the software prefetch did.
-#ifndef HEVCASM_PRED_PREFETCH
-#define HEVCASM_PRED_PREFETCH 0
-#endif
-constexpr bool kPrefetch = HEVCASM_PRED_PREFETCH != 0;
 
 template <int TAPS, int NDW, bool BI>
 static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
@@ -346,7 +321,7 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
 	const int ppw = kWave / lw;
 	const uint32_t grid = ceil_div(n, (size_t)ppw * (kThreads / kWave));
-	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, kPrefetch>), dim3(grid), dim3(kThreads), 0, st,
+	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI>), dim3(grid), dim3(kThreads), 0, st,
 			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n);
 	return launch_status("pred_stream_kernel");
 }
