@@ -270,7 +270,9 @@ template <int N> struct InverseTiles
 	static constexpr int S2 = N / 2 + (N >= 16 ? 4 : 0);
 	static constexpr int P1_DWORDS = (N / 2) * S1;
 	static constexpr int P2_DWORDS = N * S2;
-	static constexpr int DWORDS = (P1_DWORDS + P2_DWORDS + 3) & ~3;
+	// P2 overlays P1: every lane has read its P1 column into registers (and a barrier has passed)
+	// before anyone writes P2, which halves the LDS footprint and doubles the resident workgroups.
+	static constexpr int DWORDS = ((P1_DWORDS > P2_DWORDS ? P1_DWORDS : P2_DWORDS) + 3) & ~3;
 };
 
 template <int N, bool DST, bool DEQUANT>
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	const bool live = blk < n_blocks;
 	if (!live) blk = n_blocks - 1;
 	uint32_t *p1 = tiles + local * T::DWORDS;
-	uint32_t *p2 = p1 + T::P1_DWORDS;
+	uint32_t *p2 = p1;
 	const uint32_t my_pair_bytes = kPairBytes.at[LOG2 - 2][t];   // where row / column t sits in a pair-ordered row
 
 	int v[N], w[N];
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// first stage: column t, shift 7, clip to int16; result row y, column t -> P2[y][pair_of(t)], half_of(t)
 #pragma unroll
 	for (int q = 0; q < N / 2; ++q) p[q] = p1[q * T::S1 + t];
+	__syncthreads();   // P1 fully consumed: its storage becomes P2
 	inverse_packed<N, DST>(p, 64, w);
 	{
 		int16_t *col = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p2) + my_pair_bytes);
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	const bool live2 = blk2 < n_blocks;
 	if (!live2) blk2 = n_blocks - 1;
 	{
-		const uint32_t *row = tiles + local2 * T::DWORDS + T::P1_DWORDS + t2 * T::S2;
+		const uint32_t *row = tiles + local2 * T::DWORDS + t2 * T::S2;
 		if constexpr (N >= 8)
 		{
 #pragma unroll
@@ -349,9 +352,13 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	}
 	inverse_packed<N, DST>(p, 2048, w);
 
-	// add to prediction row t.  The reference narrows pred + residual to int16 before clipping
-	// to 8 bits (residual_decode.c:350-368); the sum of a byte and a clipped int16 wraps only
-	// above 32767, which the narrowing cast reproduces.
+	// Add to the prediction row and saturate to 8 bits.  The reference clips the second-stage result
+	// to int16 and narrows pred + residual to int16 before the 8-bit clip (residual_decode.c:350-368).
+	// Neither can ever act here: the second stage's inputs are int16 and every column of the
+	// transform matrix has sum |M| <= 64 + 31 * 90 = 2854, so |(sum + 2048) >> 12| <= 22834 and
+	// pred + residual stays inside int16.  Hence clip8(pred + ((w) >> 12)) == sat_u8((w + (pred << 12)) >> 12)
+	// (w already carries the rounding constant; adding a multiple of 4096 commutes with the shift),
+	// which is one v_lshl_add per pixel and one v_ashr_pk_u8_i32 per two pixels.
 	const uint8_t *pp = pred + pred_off[blk2] + t2 * stride_pred;
 	uint8_t *d = dst + dst_off[blk2] + t2 * stride_dst;
 	constexpr int CB = N >= 16 ? 16 : N;
@@ -365,18 +372,87 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 #pragma unroll
 			for (int k = 0; k < CB / 4; ++k)
 			{
-				uint32_t o = 0;
+				int tt[4];
 #pragma unroll
-				for (int b = 0; b < 4; ++b)
-				{
-					const int r = clip3(-32768, 32767, w[q * CB + 4 * k + b] >> 12);
-					const int sum = (int)(short)((int)((c.d[k] >> (8 * b)) & 0xff) + r);
-					o |= (uint32_t)clip3(0, 255, sum) << (8 * b);
-				}
-				c.d[k] = o;
+				for (int b = 0; b < 4; ++b) tt[b] = w[q * CB + 4 * k + b] + (int)(((c.d[k] >> (8 * b)) & 0xff) << 12);
+				const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
+				const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
+				c.d[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
 			}
 			c.store(d + q * CB);
 		}
+	}
+}
+
+// ---- 4x4 inverse transform + add, one lane per block ------------------------------------------
+//
+// A 4x4 block is 32 bytes of coefficients: small enough for one lane to hold and transform
+// entirely in registers, with no LDS tile and no barrier.  Lane = block, so consecutive lanes read
+// consecutive 32-byte coefficient blocks, and for raster-ordered blocks the four lanes of a quad
+// read / write one contiguous 16-byte run of each prediction / destination row.
+// Pairs for the column pass are picked out of the row-major dwords with v_perm_b32; the first
+// pass's int16 clip and the re-pairing for the row pass are one v_cvt_pk_i16_i32 (saturating).
+template <bool DST, bool DEQUANT>
+__global__ __launch_bounds__(kThreads) void inverse4_lane_kernel(
+	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
+{
+	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+	if (blk >= n_blocks) return;
+
+	// r[2k], r[2k+1] = row k as (c[k][0], c[k][1]), (c[k][2], c[k][3])
+	uint32_t r[8];
+	{
+		Chunk<16> a, b;
+		const uint8_t *p = reinterpret_cast<const uint8_t *>(coeffs + (size_t)blk * 16);
+		a.load(p);
+		b.load(p + 16);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { r[i] = a.d[i]; r[4 + i] = b.d[i]; }
+	}
+	if (DEQUANT)
+	{
+		const int round = 1 << (shift - 1);
+#pragma unroll
+		for (int i = 0; i < 8; ++i)
+		{
+			const int lo = clip3(-32768, 32767, ((int)(short)(r[i] & 0xffff) * scale + round) >> shift);   // quantize.c:53-62
+			const int hi = clip3(-32768, 32767, (((int)r[i] >> 16) * scale + round) >> shift);
+			r[i] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+		}
+	}
+
+	// column pass: column x needs (c[1][x], c[3][x]) and (c[0][x], c[2][x])
+	int w1[4][4];   // w1[x][y] = first-stage sum for column x, output row y
+#pragma unroll
+	for (int x = 0; x < 4; ++x)
+	{
+		const uint32_t sel = (x & 1) ? 0x07060302u : 0x05040100u;    // high / low halves of (second, first)
+		uint32_t p[2];
+		p[0] = __builtin_amdgcn_perm(r[6 + (x >> 1)], r[2 + (x >> 1)], sel);   // rows 1, 3
+		p[1] = __builtin_amdgcn_perm(r[4 + (x >> 1)], r[0 + (x >> 1)], sel);   // rows 0, 2
+		inverse_packed<4, DST>(p, 64, w1[x]);
+	}
+	// row pass: row y needs (e[y][1], e[y][3]) and (e[y][0], e[y][2]); e = clip16(w >> 7)
+	const uint8_t *pp = pred + pred_off[blk];
+	uint8_t *d = dst + dst_off[blk];
+#pragma unroll
+	for (int y = 0; y < 4; ++y)
+	{
+		typedef short s16x2v __attribute__((ext_vector_type(2)));
+		uint32_t p[2];
+		p[0] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w1[1][y] >> 7, w1[3][y] >> 7));
+		p[1] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w1[0][y] >> 7, w1[2][y] >> 7));
+		int w2[4];
+		inverse_packed<4, DST>(p, 2048, w2);
+		const uint32_t pd = reinterpret_cast<const U1 *>(pp + y * stride_pred)->v;
+		int tt[4];
+#pragma unroll
+		for (int b = 0; b < 4; ++b) tt[b] = w2[b] + (int)(((pd >> (8 * b)) & 0xff) << 12);   // see the N x N kernel: exact
+		const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
+		const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
+		reinterpret_cast<U1 *>(d + y * stride_dst)->v = __builtin_amdgcn_perm(hi, lo, 0x05040100);
 	}
 }
 
@@ -453,10 +529,15 @@ static int inverse_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdif
 	if (n > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!dst || !pred || !dof || !pof || !c) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	hipStream_t st = as_stream(stream);
-	if (trType) return launch_inverse<4, true, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
+	if (log2n == 2)
+	{
+		const uint32_t grid = ceil_div(n, kThreads);
+		if (trType) hipLaunchKernelGGL((inverse4_lane_kernel<true, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
+		else hipLaunchKernelGGL((inverse4_lane_kernel<false, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
+		return launch_status("inverse4_lane_kernel");
+	}
 	switch (log2n)
 	{
-	case 2: return launch_inverse<4, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	case 3: return launch_inverse<8, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	case 4: return launch_inverse<16, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	default: return launch_inverse<32, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
