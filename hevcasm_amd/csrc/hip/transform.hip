@@ -384,75 +384,99 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	}
 }
 
-// ---- 4x4 inverse transform + add, one lane per block ------------------------------------------
+// ---- 4x4 / 8x8 inverse transform + add, one lane per block ------------------------------------
 //
-// A 4x4 block is 32 bytes of coefficients: small enough for one lane to hold and transform
-// entirely in registers, with no LDS tile and no barrier.  Lane = block, so consecutive lanes read
-// consecutive 32-byte coefficient blocks, and for raster-ordered blocks the four lanes of a quad
-// read / write one contiguous 16-byte run of each prediction / destination row.
+// A 4x4 block is 32 bytes of coefficients and an 8x8 block 128: small enough for one lane to hold
+// and transform entirely in registers, with no LDS tile and no barrier.  Lane = block, so
+// consecutive lanes read consecutive coefficient blocks, and for raster-ordered blocks
+// neighbouring lanes read / write one contiguous run of each prediction / destination row.
 // Pairs for the column pass are picked out of the row-major dwords with v_perm_b32; the first
 // pass's int16 clip and the re-pairing for the row pass are one v_cvt_pk_i16_i32 (saturating).
-template <bool DST, bool DEQUANT>
-__global__ __launch_bounds__(kThreads) void inverse4_lane_kernel(
+// Columns are processed two at a time in pair order so that only 2N first-pass sums are live.
+template <int N, bool DST, bool DEQUANT>
+__global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {
+	typedef short s16x2v __attribute__((ext_vector_type(2)));
+	constexpr PairOrder<N> order = make_pair_order<N>();
+	constexpr int RD = N / 2;   // dwords per coefficient row
 	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
 	if (blk >= n_blocks) return;
 
-	// r[2k], r[2k+1] = row k as (c[k][0], c[k][1]), (c[k][2], c[k][3])
-	uint32_t r[8];
+	// r[k * RD + j] = (c[k][2j], c[k][2j + 1])
+	uint32_t r[N * RD];
 	{
-		Chunk<16> a, b;
-		const uint8_t *p = reinterpret_cast<const uint8_t *>(coeffs + (size_t)blk * 16);
-		a.load(p);
-		b.load(p + 16);
+		const uint8_t *p = reinterpret_cast<const uint8_t *>(coeffs + (size_t)blk * (N * N));
 #pragma unroll
-		for (int i = 0; i < 4; ++i) { r[i] = a.d[i]; r[4 + i] = b.d[i]; }
+		for (int i = 0; i < N * RD / 4; ++i)
+		{
+			Chunk<16> c;
+			c.load(p + 16 * i);
+#pragma unroll
+			for (int j = 0; j < 4; ++j) r[4 * i + j] = c.d[j];
+		}
 	}
 	if (DEQUANT)
 	{
 		const int round = 1 << (shift - 1);
 #pragma unroll
-		for (int i = 0; i < 8; ++i)
+		for (int i = 0; i < N * RD; ++i)
 		{
-			const int lo = clip3(-32768, 32767, ((int)(short)(r[i] & 0xffff) * scale + round) >> shift);   // quantize.c:53-62
-			const int hi = clip3(-32768, 32767, (((int)r[i] >> 16) * scale + round) >> shift);
-			r[i] = ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16);
+			const int lo = ((int)(short)(r[i] & 0xffff) * scale + round) >> shift;   // quantize.c:53-62;
+			const int hi = (((int)r[i] >> 16) * scale + round) >> shift;             // v_cvt_pk_i16_i32 is the clip
+			r[i] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo, hi));
 		}
 	}
 
-	// column pass: column x needs (c[1][x], c[3][x]) and (c[0][x], c[2][x])
-	int w1[4][4];   // w1[x][y] = first-stage sum for column x, output row y
+	// column pass.  q[p * N + y] = (e[y][first[p]], e[y][second[p]]), e = clip16(sum >> 7): row y of the
+	// intermediate block, already in the pair order the row pass consumes.
+	uint32_t q[RD * N];
 #pragma unroll
-	for (int x = 0; x < 4; ++x)
+	for (int cp = 0; cp < RD; ++cp)
 	{
-		const uint32_t sel = (x & 1) ? 0x07060302u : 0x05040100u;    // high / low halves of (second, first)
-		uint32_t p[2];
-		p[0] = __builtin_amdgcn_perm(r[6 + (x >> 1)], r[2 + (x >> 1)], sel);   // rows 1, 3
-		p[1] = __builtin_amdgcn_perm(r[4 + (x >> 1)], r[0 + (x >> 1)], sel);   // rows 0, 2
-		inverse_packed<4, DST>(p, 64, w1[x]);
+		int w[2][N];
+#pragma unroll
+		for (int side = 0; side < 2; ++side)
+		{
+			const int x = side ? order.second[cp] : order.first[cp];
+			const uint32_t sel = (x & 1) ? 0x07060302u : 0x05040100u;    // high / low halves of (second, first)
+			uint32_t p[RD];
+#pragma unroll
+			for (int k = 0; k < RD; ++k)
+				p[k] = __builtin_amdgcn_perm(r[order.second[k] * RD + (x >> 1)], r[order.first[k] * RD + (x >> 1)], sel);
+			inverse_packed<N, DST>(p, 64, w[side]);
+		}
+#pragma unroll
+		for (int y = 0; y < N; ++y)
+			q[cp * N + y] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w[0][y] >> 7, w[1][y] >> 7));
 	}
-	// row pass: row y needs (e[y][1], e[y][3]) and (e[y][0], e[y][2]); e = clip16(w >> 7)
+
+	// row pass + prediction + saturate
 	const uint8_t *pp = pred + pred_off[blk];
 	uint8_t *d = dst + dst_off[blk];
 #pragma unroll
-	for (int y = 0; y < 4; ++y)
+	for (int y = 0; y < N; ++y)
 	{
-		typedef short s16x2v __attribute__((ext_vector_type(2)));
-		uint32_t p[2];
-		p[0] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w1[1][y] >> 7, w1[3][y] >> 7));
-		p[1] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w1[0][y] >> 7, w1[2][y] >> 7));
-		int w2[4];
-		inverse_packed<4, DST>(p, 2048, w2);
-		const uint32_t pd = reinterpret_cast<const U1 *>(pp + y * stride_pred)->v;
-		int tt[4];
+		uint32_t p[RD];
 #pragma unroll
-		for (int b = 0; b < 4; ++b) tt[b] = w2[b] + (int)(((pd >> (8 * b)) & 0xff) << 12);   // see the N x N kernel: exact
-		const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
-		const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
-		reinterpret_cast<U1 *>(d + y * stride_dst)->v = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+		for (int k = 0; k < RD; ++k) p[k] = q[k * N + y];
+		int w2[N];
+		inverse_packed<N, DST>(p, 2048, w2);
+		Chunk<N> c;
+		c.load(pp + y * stride_pred);
+#pragma unroll
+		for (int k = 0; k < N / 4; ++k)
+		{
+			int tt[4];
+#pragma unroll
+			for (int b = 0; b < 4; ++b) tt[b] = w2[4 * k + b] + (int)(((c.d[k] >> (8 * b)) & 0xff) << 12);   // exact: see the N x N kernel
+			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
+			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
+			c.d[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+		}
+		c.store(d + y * stride_dst);
 	}
 }
 
@@ -508,6 +532,42 @@ __global__ __launch_bounds__(kThreads) void forward_transform_kernel(
 	if (live) global_row_store<N>(coeffs + (size_t)blk * (N * N) + t * N, v);
 }
 
+// 4x4 forward transform, one lane per block: as inverse_lane_kernel, everything in registers.
+// The first stage's truncation to int16 (residual_decode.c: the intermediate array is int16) is a
+// sign-extension of the low half; 32-bit sums are exact for any int16 input.
+template <bool DST>
+__global__ __launch_bounds__(kThreads) void forward4_lane_kernel(
+	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride,
+	const uint32_t *__restrict__ src_off, uint32_t n_blocks)
+{
+	constexpr int N = 4, S1 = 1, S2 = 8;   // residual_decode.c:855-892
+	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+	if (blk >= n_blocks) return;
+	const int16_t *p = src + src_off[blk];
+
+	int a[N][N];   // a[k][y]: horizontal frequency k of residual row y
+#pragma unroll
+	for (int y = 0; y < N; ++y)
+	{
+		int v[N], w[N];
+		global_row_load<N>(p + (ptrdiff_t)y * src_stride, v);
+		forward_1d<N, DST>(v, w);
+#pragma unroll
+		for (int k = 0; k < N; ++k) a[k][y] = (int)(int16_t)((w[k] + (1 << (S1 - 1))) >> S1);
+	}
+	int o[N][N];   // o[k][t]: vertical frequency k, horizontal frequency t
+#pragma unroll
+	for (int t = 0; t < N; ++t)
+	{
+		int w[N];
+		forward_1d<N, DST>(a[t], w);
+#pragma unroll
+		for (int k = 0; k < N; ++k) o[k][t] = (w[k] + (1 << (S2 - 1))) >> S2;
+	}
+#pragma unroll
+	for (int k = 0; k < N; ++k) global_row_store<N>(coeffs + (size_t)blk * (N * N) + k * N, o[k]);
+}
+
 template <int N, bool DST, bool DEQUANT>
 static int launch_inverse(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdiff_t sp, const uint32_t *dof, const uint32_t *pof,
 		const int16_t *c, int scale, int shift, size_t n, hipStream_t st)
@@ -529,16 +589,16 @@ static int inverse_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdif
 	if (n > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!dst || !pred || !dof || !pof || !c) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	hipStream_t st = as_stream(stream);
-	if (log2n == 2)
+	if (log2n <= 3)
 	{
 		const uint32_t grid = ceil_div(n, kThreads);
-		if (trType) hipLaunchKernelGGL((inverse4_lane_kernel<true, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
-		else hipLaunchKernelGGL((inverse4_lane_kernel<false, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
-		return launch_status("inverse4_lane_kernel");
+		if (trType) hipLaunchKernelGGL((inverse_lane_kernel<4, true, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
+		else if (log2n == 2) hipLaunchKernelGGL((inverse_lane_kernel<4, false, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
+		else hipLaunchKernelGGL((inverse_lane_kernel<8, false, DEQUANT>), dim3(grid), dim3(kThreads), 0, st, dst, sd, pred, sp, dof, pof, c, scale, shift, (uint32_t)n);
+		return launch_status("inverse_lane_kernel");
 	}
 	switch (log2n)
 	{
-	case 3: return launch_inverse<8, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	case 4: return launch_inverse<16, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	default: return launch_inverse<32, false, DEQUANT>(dst, sd, pred, sp, dof, pof, c, scale, shift, n, st);
 	}
@@ -583,10 +643,15 @@ extern "C" int hevcasm_hip_transform_batch(
 	if (n_blocks > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!coeffs || !src || !src_off) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	hipStream_t st = as_stream(stream);
-	if (trType) return launch_forward<4, true>(coeffs, src, src_stride, src_off, n_blocks, st);
+	if (log2TrafoSize == 2)
+	{
+		const uint32_t grid = ceil_div(n_blocks, kThreads);
+		if (trType) hipLaunchKernelGGL((forward4_lane_kernel<true>), dim3(grid), dim3(kThreads), 0, st, coeffs, src, src_stride, src_off, (uint32_t)n_blocks);
+		else hipLaunchKernelGGL((forward4_lane_kernel<false>), dim3(grid), dim3(kThreads), 0, st, coeffs, src, src_stride, src_off, (uint32_t)n_blocks);
+		return launch_status("forward4_lane_kernel");
+	}
 	switch (log2TrafoSize)
 	{
-	case 2: return launch_forward<4, false>(coeffs, src, src_stride, src_off, n_blocks, st);
 	case 3: return launch_forward<8, false>(coeffs, src, src_stride, src_off, n_blocks, st);
 	case 4: return launch_forward<16, false>(coeffs, src, src_stride, src_off, n_blocks, st);
 	default: return launch_forward<32, false>(coeffs, src, src_stride, src_off, n_blocks, st);
