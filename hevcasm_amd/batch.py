@@ -141,3 +141,13 @@ def me_full_search(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, sea
                                                  ref_off.data_ptr(), out.data_ptr(), rect(w, h), search_range, n, _stream()),
           "me_full_search_batch")
     return out
+
+
+def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0, out=None):
+    """Fused quarter-pel refinement: out[i] = (qx, qy, cost) of the best of the 49 displacements."""
+    n = src_off.numel()
+    out = torch.empty((n, 3), dtype=torch.int32, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_subpel_refine_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(),
+                                                ref_off.data_ptr(), out.data_ptr(), rect(w, h), metric, n, _stream()),
+          "subpel_refine_batch")
+    return out

@@ -166,6 +166,20 @@ int hevcasm_hip_me_full_search_batch(
 	const uint32_t *src_off, const uint32_t *ref_off, int *result,
 	uint32_t rect, int range, size_t n_blocks, void *stream);
 
+/* ---- fused quarter-pel refinement ------------------------------------- */
+
+/* For each block: the 49 luma quarter-pel displacements (qx, qy) in [-3, 3]^2 around the
+ * integer-pel position ref + ref_off[i].  Candidate prediction = hevcasm_pred_uni_8to8 with the
+ * 8-tap filter (reference pred_inter.h:56) at integer offset (qx >> 2, qy >> 2) and fraction
+ * (qx & 3, qy & 3); cost = hevcasm_sad (reference sad.h:50) of it against src + src_off[i].
+ * result[3i..3i+2] = { qx, qy, cost } of the minimum, ties resolved to the first candidate in
+ * raster order of (qy, qx).  The candidates are never written to memory.  metric: 0 = SAD.
+ * The reference plane must be readable 4 pixels around each block (the filter margins). */
+int hevcasm_hip_subpel_refine_batch(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	uint32_t rect, int metric, size_t n_blocks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -538,3 +538,24 @@ void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t 
 		out3[3 * i + 0] = bx; out3[3 * i + 1] = by; out3[3 * i + 2] = best;
 	}
 }
+
+void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, size_t n)
+{
+	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
+#pragma omp parallel for schedule(dynamic, 1)
+	for (ptrdiff_t i = 0; i < (ptrdiff_t)n; ++i)
+	{
+		uint8_t cand[64 * 64];
+		int best = 0x7fffffff, bx = 0, by = 0;
+		for (int qy = -3; qy <= 3; ++qy)
+			for (int qx = -3; qx <= 3; ++qx)
+			{
+				const uint8_t *origin = ref + (ptrdiff_t)ref_off[i] + (qy >> 2) * stride_ref + (qx >> 2);
+				orc_pred_uni_8to8(8, cand, 64, origin, stride_ref, w, h, qx & 3, qy & 3);
+				const int c = orc_sad(src + src_off[i], stride_src, cand, 64, rect);
+				if (c < best) { best = c; bx = qx; by = qy; }
+			}
+		out3[3 * i + 0] = bx; out3[3 * i + 1] = by; out3[3 * i + 2] = best;
+	}
+}

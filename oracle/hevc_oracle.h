@@ -101,6 +101,14 @@ void orc_hadamard_satd_batch(int n, const uint8_t *a, ptrdiff_t stride_a, const 
 void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, int range, size_t n);
 
+/* Quarter-pel refinement: a composition of the luma interpolation
+ * (pred_inter.h:56, bodies pred_inter.c:141-228) and SAD (sad.c:47-60).  For each block, every
+ * quarter-pel displacement (qx,qy) in [-3,3]^2 around ref_off is predicted with the 8-tap filter at
+ * integer offset (qx >> 2, qy >> 2), fraction (qx & 3, qy & 3), and costed against src.
+ * out[3*i] = qx, qy, cost of the minimum; ties go to the first in raster order of (qy,qx). */
+void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
-OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD = 8, 9, 10, 11, 12, 13
+OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL = 8, 9, 10, 11, 12, 13, 14
 OP_SELFTEST, OP_BENCH_SAD = 20, 30
 
 
@@ -136,6 +136,11 @@ class RefProc:
 
     def me_full_search(self, src, stride_src, ref, stride_ref, src_off, ref_off, w, h, search_range):
         o = self.call(OP_ME, [stride_src, stride_ref, (w << 8) | h, search_range, len(src_off)],
+                      [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
+        return np.frombuffer(o[0], dtype=np.int32).reshape(-1, 3).copy()
+
+    def subpel_refine(self, src, stride_src, ref, stride_ref, src_off, ref_off, w, h):
+        o = self.call(OP_SUBPEL, [stride_src, stride_ref, (w << 8) | h, len(src_off)],
                       [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
         return np.frombuffer(o[0], dtype=np.int32).reshape(-1, 3).copy()
 

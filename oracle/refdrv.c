@@ -78,7 +78,7 @@ static double now_s(void)
 
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
-	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13,
+	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14,
 	OP_SELFTEST = 20, OP_BENCH_SAD = 30
 };
 
@@ -274,6 +274,33 @@ int main(void)
 					}
 				r[3 * i] = bx; r[3 * i + 1] = by; r[3 * i + 2] = best;
 			}
+			out[0].p = (uint8_t *)r; out[0].bytes = 12 * n; nout = 1;
+			break;
+		}
+		case OP_SUBPEL: /* par: stride_src, stride_ref, rect, n; bufs src, ref, src_off, ref_off -> int[3n] (qx, qy, cost).
+		                   The reference's own luma interpolation and SAD, composed per quarter-pel candidate. */
+		{
+			const size_t n = (size_t)par[3];
+			const uint32_t *so = (const uint32_t *)in[2].p, *ro = (const uint32_t *)in[3].p;
+			const int w = (int)(par[2] >> 8), h = (int)(par[2] & 0xff);
+			hevcasm_sad *sad = *hevcasm_get_sad(&t_sad, w, h);
+			int *r = (int *)malloc(12 * n + 4);
+			uint8_t *cand = (uint8_t *)malloc(64 * 64 + 64);
+			for (size_t i = 0; i < n; ++i)
+			{
+				int best = 0x7fffffff, bx = 0, by = 0;
+				for (int qy = -3; qy <= 3; ++qy)
+					for (int qx = -3; qx <= 3; ++qx)
+					{
+						const int xf = qx & 3, yf = qy & 3;
+						hevcasm_pred_uni_8to8 *f = *hevcasm_get_pred_uni_8to8(&t_uni, 8, w, h, xf, yf);
+						f(cand, 64, in[1].p + (ptrdiff_t)ro[i] + (qy >> 2) * par[1] + (qx >> 2), par[1], w, h, xf, yf);
+						const int c = sad(in[0].p + so[i], par[0], cand, 64, (uint32_t)par[2]);
+						if (c < best) { best = c; bx = qx; by = qy; }
+					}
+				r[3 * i] = bx; r[3 * i + 1] = by; r[3 * i + 2] = best;
+			}
+			free(cand);
 			out[0].p = (uint8_t *)r; out[0].bytes = 12 * n; nout = 1;
 			break;
 		}

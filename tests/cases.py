@@ -205,8 +205,58 @@ def _me_case(w, h, r, n, seed):
                 ref_off=ref_off.astype(np.uint32), w=w, h=h, range=r, n=n)
 
 
+def subpel_cases(seed=1000):
+    """Quarter-pel refinement: noise (arbitrary cost landscape, every filter phase and the clip), a
+    smooth frame whose source is the reference moved by a fraction of a pixel (a real interior
+    minimum), a flat reference (49-way tie -> first candidate (-3,-3)) and 0/255 patterns."""
+    out = []
+    for (w, h, n) in ((8, 8, 7), (16, 16, 6), (8, 4, 5), (4, 8, 5), (12, 16, 3), (16, 4, 3), (32, 32, 3), (64, 64, 2), (24, 32, 2), (48, 64, 2), (64, 16, 2)):
+        out.append(("subpel_%dx%d" % (w, h), "subpel", _subpel_case(w, h, n, seed + w + h, "noise")))
+    out.append(("subpel_smooth_16x16", "subpel", _subpel_case(16, 16, 8, seed + 1, "smooth")))
+    out.append(("subpel_smooth_32x16", "subpel", _subpel_case(32, 16, 4, seed + 2, "smooth")))
+    c = _subpel_case(16, 16, 3, seed + 3, "noise")
+    c["ref"][:] = 9
+    out.append(("subpel_ties", "subpel", c))
+    c = _subpel_case(16, 8, 4, seed + 4, "noise")
+    c["ref"][:] = np.where(c["ref"] & 1, 255, 0)
+    c["src"][:] = np.where(c["src"] & 2, 255, 0)
+    out.append(("subpel_extremes", "subpel", c))
+    return out
+
+
+def _subpel_case(w, h, n, seed, kind):
+    fw, fh = wl.SMALL_W, wl.SMALL_H
+    frames = wl.Plane.frames_for(n, w, h, fw, fh)
+    sp = wl.Plane(fw, fh, frames)
+    rp = wl.Plane(fw, fh, frames, border_x=16, border_y=16)
+    src_off = sp.tile_offsets(n, w, h)
+    ref_off = rp.tile_offsets(n, w, h)
+    if kind == "noise":
+        src = wl.fill_u8(sp.size, seed)
+        ref = wl.fill_u8(rp.size, seed + 1)
+    else:
+        # smooth content; the source is the reference sampled a fraction of a pixel away (bilinear)
+        rng = np.random.default_rng(seed)
+        rows = rp.size // rp.stride
+        yy, xx = np.mgrid[0:rows, 0:rp.stride].astype(np.float64)
+        f = 128 + 50 * np.sin(xx * 0.21 + yy * 0.13) + 40 * np.cos(xx * 0.07 - yy * 0.19) + 20 * np.sin(yy * 0.45)
+        ref = np.clip(np.rint(f), 0, 255).astype(np.uint8).reshape(-1)
+        src = np.zeros(sp.size, dtype=np.uint8)
+        for i in range(n):
+            fx, fy = rng.integers(-3, 4, 2) / 4.0
+            y0, x0 = divmod(int(ref_off[i]), rp.stride)
+            ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+            g = (128 + 50 * np.sin((xs + x0 + fx) * 0.21 + (ys + y0 + fy) * 0.13) + 40 * np.cos((xs + x0 + fx) * 0.07 - (ys + y0 + fy) * 0.19)
+                 + 20 * np.sin((ys + y0 + fy) * 0.45))
+            blk = np.clip(np.rint(g), 0, 255).astype(np.uint8)
+            for y in range(h):
+                src[int(src_off[i]) + y * sp.stride: int(src_off[i]) + y * sp.stride + w] = blk[y]
+    return dict(src=src, stride_src=sp.stride, ref=ref, stride_ref=rp.stride, src_off=src_off.astype(np.uint32),
+                ref_off=ref_off.astype(np.uint32), w=w, h=h, n=n)
+
+
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
-                      dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases)
+                      dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases)
 
 
 # ------------------------------------------------------------------------------------- runners
@@ -249,6 +299,8 @@ def _run_cpu(api, family, c):
         return (_dst_rows(d, c["stride_rec"], c["rec_off"], c["ncbs"], c["ncbs"]),)
     if family == "me":
         return (api.me_full_search(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"], c["range"]),)
+    if family == "subpel":
+        return (api.subpel_refine(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
     raise ValueError(family)
 
 
@@ -310,6 +362,8 @@ def run_hip(family, c):
         return _only_blocks(cpu(d), c["stride_rec"], c["rec_off"], c["ncbs"], c["ncbs"])
     if family == "me":
         return (cpu(B.me_full_search(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"], c["range"])),)
+    if family == "subpel":
+        return (cpu(B.subpel_refine(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
     raise ValueError(family)
 
 

@@ -159,6 +159,35 @@ def test_full_search_finds_planted_block():
     assert hits >= len(planted) // 2
 
 
+def test_subpel_refine_equals_unfused_composition():
+    """Full 1080p frame of 16x16 blocks: the fused kernel's (qx, qy, cost) must be the raster-first
+    arg-min of the 49 costs obtained the long way round -- pred_uni_8to8_batch into a scratch plane,
+    then sad_batch -- through kernels that are themselves parity-tested against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    fw, fh, w, h, m = 1920, 1088, 16, 16, 16
+    stride_r = fw + 2 * m
+    src = wl.fill_u8(fw * fh, 21, device="cuda")
+    ref = wl.fill_u8(stride_r * (fh + 2 * m), 22, device="cuda")
+    by, bx = np.meshgrid(np.arange(fh // h), np.arange(fw // w), indexing="ij")
+    so = (by * h * fw + bx * w).reshape(-1).astype(np.uint32)
+    ro = ((by * h + m) * stride_r + bx * w + m).reshape(-1).astype(np.int64)
+    n = so.size
+    so_d = B.off32(so)
+    got = B.subpel_refine(src, fw, ref, stride_r, so_d, B.off32(ro.astype(np.uint32)), w, h).cpu().numpy()
+    scratch = torch.zeros(fw * fh, dtype=torch.uint8, device="cuda")
+    costs = np.empty((49, n), dtype=np.int64)
+    for qy in range(-3, 4):
+        for qx in range(-3, 4):
+            off = B.off32((ro + (qy >> 2) * stride_r + (qx >> 2)).astype(np.uint32))
+            frac = torch.full((n,), (qx & 3) | ((qy & 3) << 4), dtype=torch.uint8, device="cuda")
+            B.pred_uni(scratch, fw, ref, stride_r, so_d, off, frac, 8, w, h)
+            costs[(qy + 3) * 7 + qx + 3] = B.sad(src, fw, scratch, fw, so_d, so_d, w, h).cpu().numpy()
+    best = costs.argmin(axis=0)       # numpy returns the first minimum: raster order of (qy, qx)
+    assert np.array_equal(got[:, 2], costs.min(axis=0))
+    assert np.array_equal(got[:, 0], best % 7 - 3) and np.array_equal(got[:, 1], best // 7 - 3)
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch

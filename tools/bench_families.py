@@ -123,8 +123,38 @@ def bench_me():
                           gsad_evals_per_s=round(total_sads / total_ms / 1e6, 2))), flush=True)
 
 
+def bench_subpel():
+    """quarter-pel refinement of every block of a 3840x2160 luma frame, fused kernel vs
+    the unfused composition (49 x pred_uni_8to8_batch into a scratch frame + sad_batch)."""
+    fw, fh, m = 3840, 2160, 16
+    stride_r = fw + 2 * m
+    src = wl.fill_u8(fw * fh, 7, device="cuda")
+    ref = wl.fill_u8(stride_r * (fh + 2 * m), 8, device="cuda")
+    scratch = torch.zeros(fw * fh, dtype=torch.uint8, device="cuda")
+    for (w, h) in ((8, 8), (16, 16), (32, 32), (64, 64), (64, 32), (16, 8)):
+        by, bx = np.meshgrid(np.arange(fh // h), np.arange(fw // w), indexing="ij")
+        so = (by * h * fw + bx * w).reshape(-1).astype(np.uint32)
+        ro = ((by * h + m) * stride_r + bx * w + m).reshape(-1).astype(np.int64)
+        n = so.size
+        so_d, ro_d = B.off32(so), B.off32(ro.astype(np.uint32))
+        out = torch.empty((n, 3), dtype=torch.int32, device="cuda")
+        ms = timed(lambda i: B.subpel_refine(src, fw, ref, stride_r, so_d, ro_d, w, h, out=out), reps=5)
+        offs = [B.off32((ro + (qy >> 2) * stride_r + (qx >> 2)).astype(np.uint32)) for qy in range(-3, 4) for qx in range(-3, 4)]
+        fracs = [torch.full((n,), (qx & 3) | ((qy & 3) << 4), dtype=torch.uint8, device="cuda") for qy in range(-3, 4) for qx in range(-3, 4)]
+        cost = torch.empty(n, dtype=torch.int32, device="cuda")
+
+        def unfused(i):
+            for k in range(49):
+                B.pred_uni(scratch, fw, ref, stride_r, so_d, offs[k], fracs[k], 8, w, h)
+                B.sad(src, fw, scratch, fw, so_d, so_d, w, h, out=cost)
+        ms_unfused = timed(unfused, reps=2)
+        report("subpel_refine", n, (w + 8) * (h + 8) + w * h + 8 + 12, ms, size="%dx%d" % (w, h),
+               candidates_per_s_g=round(49 * n / ms / 1e6, 2), unfused_ms=round(ms_unfused, 3), fused_speedup=round(ms_unfused / ms, 2),
+               frames_per_s=round(1e3 / ms, 1))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["quant", "transform", "pred", "me"]
+    what = sys.argv[1:] or ["quant", "transform", "pred", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
-        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me)[w]()
+        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel)[w]()
