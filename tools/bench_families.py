@@ -123,6 +123,23 @@ def bench_me():
                           gsad_evals_per_s=round(total_sads / total_ms / 1e6, 2))), flush=True)
 
 
+def bench_satd():
+    """Hadamard SATD 2x2 / 4x4 / 8x8 over 2^26 pixels per launch, displaced reference."""
+    for n in (2, 4, 8):
+        nb = (1 << 26) // (n * n)
+        c = wl.sad_case(n, n, nb, 300 + n, frame=(wl.FRAME_W, wl.FRAME_H), device="cuda") if n >= 4 else None
+        if c is None:   # 2x2 tiles: the SAD workload generator needs multiples of 4; tile by hand
+            sp = wl.Plane(wl.FRAME_W, wl.FRAME_H, wl.Plane.frames_for(nb, n, n, wl.FRAME_W, wl.FRAME_H))
+            c = dict(src=wl.fill_u8(sp.size, 1, device="cuda"), ref=wl.fill_u8(sp.size, 2, device="cuda"), stride_src=sp.stride, stride_ref=sp.stride,
+                     src_off=sp.tile_offsets(nb, n, n).astype(np.uint32), ref_off=sp.tile_offsets(nb, n, n).astype(np.uint32))
+        so, ro = B.off32(c["src_off"]), B.off32(c["ref_off"])
+        out = torch.empty(nb, dtype=torch.int32, device="cuda")
+        ms = timed(lambda i: B.hadamard_satd(c["src"], c["stride_src"], c["ref"], c["stride_ref"], so, ro, n.bit_length() - 1, out=out))
+        report("hadamard_satd", nb, 2 * n * n + 4 + 8, ms, size="%dx%d" % (n, n))
+        del c
+        torch.cuda.empty_cache()
+
+
 def bench_subpel():
     """quarter-pel refinement of every block of a 3840x2160 luma frame, fused kernel vs
     the unfused composition (49 x pred_uni_8to8_batch into a scratch frame + sad_batch)."""
@@ -154,7 +171,7 @@ def bench_subpel():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["quant", "transform", "pred", "me", "subpel"]
+    what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
-        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel)[w]()
+        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd)[w]()
