@@ -151,3 +151,17 @@ def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metr
                                                 ref_off.data_ptr(), out.data_ptr(), rect(w, h), metric, n, _stream()),
           "subpel_refine_batch")
     return out
+
+
+def pred_intra(dst, neighbours, neighbour_stride, mode, packed, n):
+    """Batched hevcasm_pred_intra (INTRA_DC): block i reads neighbours + i * neighbour_stride, writes dst[i * N * N ...]."""
+    check(lib().hevcasm_hip_pred_intra_batch(dst.data_ptr(), neighbours.data_ptr(), neighbour_stride, mode, packed, n, _stream()), "pred_intra_batch")
+    return dst
+
+
+def ssd_linear(src0, src1, off0, off1, size, out=None):
+    n = off0.numel()
+    out = torch.empty(n, dtype=torch.int32, device=src0.device) if out is None else out
+    check(lib().hevcasm_hip_ssd_linear_batch(src0.data_ptr(), src1.data_ptr(), off0.data_ptr(), off1.data_ptr(), out.data_ptr(), size, n, _stream()),
+          "ssd_linear_batch")
+    return out

@@ -38,6 +38,8 @@ HIP_API = {
     "hevcasm_hip_quantize_reconstruct_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_me_full_search_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),
     "hevcasm_hip_subpel_refine_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),
+    "hevcasm_hip_pred_intra_batch": (_i, [_vp, _vp, _pd, _i, _i, _sz, _vp]),
+    "hevcasm_hip_ssd_linear_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
 }
 
 # the reference's exported API, re-exported by this library
@@ -59,6 +61,8 @@ HOST_API = {
     "hevcasm_populate_quantize_inverse": (None, [_vp, _i]),
     "hevcasm_populate_quantize": (None, [_vp, _i]),
     "hevcasm_populate_quantize_reconstruct": (None, [_vp, _i]),
+    "hevcasm_populate_pred_intra": (None, [_vp, _i]),
+    "hevcasm_get_ssd_linear": (_vp, [_i, _i]),
     "hevcasm_test_sad": _test_fn,
     "hevcasm_test_sad_multiref": _test_fn,
     "hevcasm_test_ssd": _test_fn,
@@ -70,6 +74,8 @@ HOST_API = {
     "hevcasm_test_quantize_inverse": _test_fn,
     "hevcasm_test_quantize": _test_fn,
     "hevcasm_test_quantize_reconstruct": _test_fn,
+    "hevcasm_test_pred_intra": _test_fn,
+    "hevcasm_test_ssd_linear": _test_fn,
 }
 
 # instruction-set bits (include/hevcasm.h)

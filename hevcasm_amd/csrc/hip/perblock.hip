@@ -296,4 +296,40 @@ void hevcasm_hip1_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const
 	for (int y = 0; y < n; ++y) std::memcpy(rec + y * stride_rec, a.h<uint8_t>(d) + y * sd, (size_t)n);
 }
 
+void hevcasm_hip1_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int intraPredMode, hevcasm_pred_intra_packed packed)
+{
+	const int n = 1 << ((packed >> 1) & 0x7f);
+	Arena &a = g_arena;
+	a.reset();
+	// stage bytes [64 - n, 64 + n) of the caller's array at the same indices of a 128-byte record
+	const size_t nb = a.take(128), d = a.take((size_t)n * n);
+	std::memcpy(a.h<uint8_t>(nb) + 64 - n, neighbours + 64 - n, 2 * (size_t)n);
+	Arena::check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 128, intraPredMode, packed, 1, a.stream), "pred_intra");
+	a.wait();
+	std::memcpy(dst, a.h<uint8_t>(d), (size_t)n * n);
+}
+
+int hevcasm_hip1_ssd_linear(const uint8_t *src0, const uint8_t *src1, int size)
+{
+	Arena &a = g_arena;
+	unsigned total = 0;
+	// runs longer than the staging arena go through it in pieces; 32-bit sums add up exactly (mod 2^32)
+	const int piece_max = 96 * 1024;
+	for (int done = 0; done < size || (size == 0 && done == 0); done += piece_max)
+	{
+		const int piece = size - done < piece_max ? size - done : piece_max;
+		a.reset();
+		const size_t p0 = a.take((size_t)piece + 16), p1 = a.take((size_t)piece + 16);
+		std::memcpy(a.h<uint8_t>(p0), src0 + done, (size_t)piece);
+		std::memcpy(a.h<uint8_t>(p1), src1 + done, (size_t)piece);
+		const size_t offs = stage_u32(a, (uint32_t)p0, (uint32_t)p1);
+		const size_t out = a.take(16);
+		Arena::check_call(hevcasm_hip_ssd_linear_batch(a.dev, a.dev, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), piece, 1, a.stream), "ssd_linear");
+		a.wait();
+		total += (unsigned)*a.h<int>(out);
+		if (size == 0) break;
+	}
+	return (int)total;
+}
+
 }  // extern "C"

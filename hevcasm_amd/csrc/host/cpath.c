@@ -328,3 +328,40 @@ void hevcasm_c_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const ui
 		for (int x = 0; x < n; ++x)
 			rec[y * stride_rec + x] = (uint8_t)clampi(pred[y * stride_pred + x] + res[y * n + x], 0, 255);
 }
+
+/* ---- intra DC (pred_intra.c:61-101), written from the HEVC text 8.4.4.2.5 ------------------ */
+
+void hevcasm_c_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int intraPredMode, hevcasm_pred_intra_packed packed)
+{
+	(void)intraPredMode;
+	const int log2n = (packed >> 1) & 0x7f, n = 1 << log2n;
+	const uint8_t *top = neighbours + 64;       /* top[x]  = sample (x, -1) */
+	const uint8_t *left = neighbours + 63;      /* left[-y] = sample (-1, y) */
+	int sum = n;
+	for (int i = 0; i < n; ++i) sum += top[i] + left[-i];
+	const int dc = sum >> (log2n + 1);
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x) dst[y * n + x] = (uint8_t)dc;
+	if (packed & 1)
+	{
+		dst[0] = (uint8_t)((left[0] + 2 * dc + top[0] + 2) >> 2);
+		for (int i = 1; i < n; ++i)
+		{
+			dst[i] = (uint8_t)((top[i] + 3 * dc + 2) >> 2);
+			dst[i * n] = (uint8_t)((left[-i] + 3 * dc + 2) >> 2);
+		}
+	}
+}
+
+/* ---- linear SSD (diff.c:45-54) ------------------------------------------------------------ */
+
+int hevcasm_c_ssd_linear(const uint8_t *src0, const uint8_t *src1, int size)
+{
+	unsigned total = 0;   /* wraps like the reference's int on two's-complement targets, without the UB */
+	for (int i = 0; i < size; ++i)
+	{
+		const int d = src0[i] - src1[i];
+		total += (unsigned)(d * d);
+	}
+	return (int)total;
+}

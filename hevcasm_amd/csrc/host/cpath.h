@@ -14,6 +14,8 @@
 #include "residual_decode.h"
 #include "quantize.h"
 #include "hadamard.h"
+#include "pred_intra.h"
+#include "diff.h"
 
 hevcasm_sad hevcasm_c_sad;
 hevcasm_sad_multiref hevcasm_c_sad_multiref_4;
@@ -26,6 +28,8 @@ hevcasm_transform hevcasm_c_dst_4, hevcasm_c_dct_4, hevcasm_c_dct_8, hevcasm_c_d
 hevcasm_quantize_inverse hevcasm_c_quantize_inverse;
 hevcasm_quantize hevcasm_c_quantize;
 hevcasm_quantize_reconstruct hevcasm_c_quantize_reconstruct;
+hevcasm_pred_intra hevcasm_c_pred_intra_dc;
+hevcasm_ssd_linear hevcasm_c_ssd_linear;
 
 /* HEVC interpolation filter tap k of an n-tap filter at fractional position frac. */
 int hevcasm_c_filter_tap(int n, int frac, int k);

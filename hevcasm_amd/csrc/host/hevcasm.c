@@ -14,6 +14,8 @@
 #include "residual_decode.h"
 #include "quantize.h"
 #include "hadamard.h"
+#include "pred_intra.h"
+#include "diff.h"
 #include "hevcasm_hip.h"
 
 #include <stdlib.h>
@@ -80,6 +82,7 @@ int hevcasm_main(int argc, const char *argv[])
 	hevcasm_test_sad_multiref(&error_count, mask);
 	hevcasm_test_sad(&error_count, mask);
 	hevcasm_test_ssd(&error_count, mask);
+	hevcasm_test_pred_intra(&error_count, mask);
 	hevcasm_test_hadamard_satd(&error_count, mask);
 	hevcasm_test_quantize_inverse(&error_count, mask);
 	hevcasm_test_quantize(&error_count, mask);
@@ -88,6 +91,7 @@ int hevcasm_main(int argc, const char *argv[])
 	hevcasm_test_pred_bi(&error_count, mask);
 	hevcasm_test_inverse_transform_add(&error_count, mask);
 	hevcasm_test_transform(&error_count, mask);
+	hevcasm_test_ssd_linear(&error_count, mask);   /* not in the reference's main (hevcasm.c:168-180); its test exists (diff.c:113) */
 
 	printf("\nHEVCasm self test: %d errors\n", error_count);
 	return error_count;

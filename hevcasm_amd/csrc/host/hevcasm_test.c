@@ -13,9 +13,13 @@
  *  - the outlier filter gives up (and averages everything) after 16 x `iterations` attempts instead of
  *    looping for ever on functions shorter than the timer's jitter;
  *  - a per-block call through the HIP column costs a kernel launch (jittery, tens of microseconds), so
- *    that column is a plain mean over at most HEVCASM_TEST_HIP_MAX_CALLS calls, without the outlier filter.
+ *    that column is a plain mean over at most HEVCASM_TEST_HIP_MAX_CALLS calls, without the outlier filter;
+ *  - the environment variable HEVCASM_TEST_MAX_ITERATIONS caps `iterations` (and the warm-up with it) for
+ *    quick functional runs of the self-tests, e.g. under pytest; unset, the reference's counts apply.
  */
 #include "hevcasm_test.h"
+
+#include <stdlib.h>
 
 #define HEVCASM_TEST_HIP_MAX_CALLS 400
 
@@ -31,7 +35,7 @@ int hevcasm_count_average_cycles(
 	 * lies within 7/8 .. 8/7 of the running mean; a much faster one restarts the statistics,
 	 * a much slower one (an interrupt, a migration) only restarts the warm-up. */
 	const int calls_per_sample = 4;
-	const int warmup_samples = (set == HEVCASM_HIP) ? 4 : 100;
+	const int warmup_samples = (set == HEVCASM_HIP) ? 4 : (iterations >= 400 ? 100 : (iterations / 4 > 4 ? iterations / 4 : 4));
 	hevcasm_timestamp total = 0;
 	int calls = 0, cooling = warmup_samples;
 
@@ -114,6 +118,9 @@ int hevcasm_test(
 	int iterations)
 {
 	int errors = 0;
+
+	const char *cap = getenv("HEVCASM_TEST_MAX_ITERATIONS");
+	if (cap && atoi(cap) > 0 && iterations > atoi(cap)) iterations = atoi(cap);
 
 	if (!get(ref, HEVCASM_C_REF)) return 0;
 	invoke(ref, 1);

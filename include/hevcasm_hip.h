@@ -93,6 +93,24 @@ int hevcasm_hip_hadamard_satd_batch(
 	const uint32_t *offA, const uint32_t *offB, int *satd,
 	int log2TrafoSize, size_t n_blocks, void *stream);
 
+/* Batched hevcasm_ssd_linear (reference diff.h:52; C body diff.c:45-54): run i = `size`
+ * contiguous bytes at src0 + off0[i] against src1 + off1[i]; any size >= 0.  The sum is kept in
+ * 32 bits like the reference's int (runs longer than 33 024 bytes can wrap). */
+int hevcasm_hip_ssd_linear_batch(
+	const uint8_t *src0, const uint8_t *src1, const uint32_t *off0, const uint32_t *off1, int *ssd,
+	int size, size_t n_blocks, void *stream);
+
+/* ---- intra prediction ----------------------------------------------------------------- */
+
+/* Batched hevcasm_pred_intra (reference pred_intra.h:55; C body pred_intra.c:61-101).  Block i
+ * receives neighbours + i * neighbour_stride as its `neighbours` argument (left column ending at
+ * [63], top row starting at [64]; DC reads bytes [64 - N, 64 + N)) and writes the N x N bytes at
+ * dst + i * N * N.  intraPredMode must be 1 (INTRA_DC: the only mode the reference implements);
+ * packed as hevcasm_pred_intra_pack(): log2 size 2..5, bit 0 = edge filter (sizes below 32). */
+int hevcasm_hip_pred_intra_batch(
+	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
+	int intraPredMode, int packed, size_t n_blocks, void *stream);
+
 /* ---- inter prediction ----------------------------------------------------------------- */
 
 /* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).

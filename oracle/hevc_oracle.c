@@ -559,3 +559,55 @@ void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *
 		out3[3 * i + 0] = bx; out3[3 * i + 1] = by; out3[3 * i + 2] = best;
 	}
 }
+
+/* pred_intra.c:52-58: sample (dx, dy) with dx == -1 (left column) or dy == -1 (top row) */
+static int intra_sample(const uint8_t *neighbours, int dx, int dy)
+{
+	return neighbours[dy < 0 ? 64 + dx : 63 - dy];
+}
+
+/* pred_intra.c:61-101 */
+void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed)
+{
+	const int k = (packed >> 1) & 0x7f;
+	const int nTbS = 1 << k;
+	int dcVal = nTbS;
+	for (int x = 0; x < nTbS; ++x) dcVal += intra_sample(neighbours, x, -1);
+	for (int y = 0; y < nTbS; ++y) dcVal += intra_sample(neighbours, -1, y);
+	dcVal >>= k + 1;
+
+	int start = 0;
+	if (packed & 1)
+	{
+		start = 1;
+		dst[0] = (uint8_t)((intra_sample(neighbours, -1, 0) + 2 * dcVal + intra_sample(neighbours, 0, -1) + 2) >> 2);
+		for (int x = 1; x < nTbS; ++x) dst[x] = (uint8_t)((intra_sample(neighbours, x, -1) + 3 * dcVal + 2) >> 2);
+		for (int y = 1; y < nTbS; ++y) dst[y * nTbS] = (uint8_t)((intra_sample(neighbours, -1, y) + 3 * dcVal + 2) >> 2);
+	}
+	for (int y = start; y < nTbS; ++y)
+		for (int x = start; x < nTbS; ++x) dst[x + y * nTbS] = (uint8_t)dcVal;
+}
+
+void orc_pred_intra_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int intraPredMode, int packed, size_t n)
+{
+	const int size = 1 << ((packed >> 1) & 0x7f);
+	if (intraPredMode != 1) return;   /* pred_intra.c:113-139: no other mode is wired */
+	for (size_t i = 0; i < n; ++i) orc_pred_intra_dc(dst + i * size * size, neighbours + (ptrdiff_t)i * neighbour_stride, packed);
+}
+
+/* diff.c:45-54 (unsigned accumulation: same bits as the reference's int, no UB past 2^31) */
+int orc_ssd_linear(const uint8_t *p1, const uint8_t *p2, int n)
+{
+	unsigned sum = 0;
+	for (int i = 0; i < n; ++i)
+	{
+		const int diff = p1[i] - p2[i];
+		sum += (unsigned)(diff * diff);
+	}
+	return (int)sum;
+}
+
+void orc_ssd_linear_batch(const uint8_t *src0, const uint8_t *src1, const uint32_t *off0, const uint32_t *off1, int *ssd, int size, size_t n)
+{
+	for (size_t i = 0; i < n; ++i) ssd[i] = orc_ssd_linear(src0 + off0[i], src1 + off1[i], size);
+}

@@ -109,6 +109,14 @@ void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t 
 void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, size_t n);
 
+/* pred_intra.h:55; INTRA_DC body pred_intra.c:61-101 (sample addressing pred_intra.c:52-58) */
+void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed);
+void orc_pred_intra_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int intraPredMode, int packed, size_t n);
+
+/* diff.h:52; diff.c:45-54 */
+int orc_ssd_linear(const uint8_t *p1, const uint8_t *p2, int n);
+void orc_ssd_linear_batch(const uint8_t *src0, const uint8_t *src1, const uint32_t *off0, const uint32_t *off1, int *ssd, int size, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

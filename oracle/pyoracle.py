@@ -184,6 +184,21 @@ def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h):
     return out
 
 
+def pred_intra_batch(neighbours, neighbour_stride, mode, packed, n):
+    neighbours = _u8(neighbours)
+    size = 1 << ((packed >> 1) & 0x7f)
+    dst = np.zeros(n * size * size, dtype=np.uint8)
+    lib().orc_pred_intra_batch(_p(dst), _p(neighbours), C.c_ssize_t(neighbour_stride), C.c_int(mode), C.c_int(packed), C.c_size_t(n))
+    return dst
+
+
+def ssd_linear_batch(src0, src1, off0, off1, size):
+    src0, src1, off0, off1 = _u8(src0), _u8(src1), _u32(off0), _u32(off1)
+    out = np.empty(off0.size, dtype=np.int32)
+    lib().orc_ssd_linear_batch(_p(src0), _p(src1), _p(off0), _p(off1), _p(out), C.c_int(size), C.c_size_t(off0.size))
+    return out
+
+
 def dct_matrix(n):
     f = lib().orc_dct_matrix
     return np.array([[f(n, k, i) for i in range(n)] for k in range(n)], dtype=np.int32)

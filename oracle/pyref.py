@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
-OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL = 8, 9, 10, 11, 12, 13, 14
+OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL, OP_INTRA, OP_SSD_LINEAR = 8, 9, 10, 11, 12, 13, 14, 15, 16
 OP_SELFTEST, OP_BENCH_SAD = 20, 30
 
 
@@ -143,6 +143,14 @@ class RefProc:
         o = self.call(OP_SUBPEL, [stride_src, stride_ref, (w << 8) | h, len(src_off)],
                       [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
         return np.frombuffer(o[0], dtype=np.int32).reshape(-1, 3).copy()
+
+    def pred_intra_batch(self, neighbours, neighbour_stride, mode, packed, n):
+        o = self.call(OP_INTRA, [neighbour_stride, mode, packed, n], [_u8(neighbours)])
+        return np.frombuffer(o[0], dtype=np.uint8).copy()
+
+    def ssd_linear_batch(self, src0, src1, off0, off1, size):
+        o = self.call(OP_SSD_LINEAR, [size, len(off0)], [_u8(src0), _u8(src1), _u32(off0), _u32(off1)])
+        return np.frombuffer(o[0], dtype=np.int32).copy()
 
     def selftest(self, family_mask, out_path):
         o = self.call(OP_SELFTEST, [family_mask], [out_path.encode()])

@@ -25,6 +25,8 @@
 #include "residual_decode.h"
 #include "quantize.h"
 #include "hadamard.h"
+#include "pred_intra.h"
+#include "diff.h"
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -50,6 +52,7 @@ static hevcasm_table_quantize_inverse t_deq;
 static hevcasm_table_quantize t_q;
 static hevcasm_table_quantize_reconstruct t_rec;
 static hevcasm_table_hadamard_satd t_satd;
+static hevcasm_table_pred_intra t_intra;
 
 static void populate_all(void)
 {
@@ -65,6 +68,7 @@ static void populate_all(void)
 	hevcasm_populate_quantize(&t_q, m);
 	hevcasm_populate_quantize_reconstruct(&t_rec, m);
 	hevcasm_populate_hadamard_satd(&t_satd, m);
+	hevcasm_populate_pred_intra(&t_intra, m);
 }
 
 static int ilog2(int n) { int l = 0; while ((1 << l) < n) ++l; return l; }
@@ -78,7 +82,7 @@ static double now_s(void)
 
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
-	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14,
+	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14, OP_INTRA = 15, OP_SSD_LINEAR = 16,
 	OP_SELFTEST = 20, OP_BENCH_SAD = 30
 };
 
@@ -304,6 +308,27 @@ int main(void)
 			out[0].p = (uint8_t *)r; out[0].bytes = 12 * n; nout = 1;
 			break;
 		}
+		case OP_INTRA: /* par: neighbour_stride, intraPredMode, packed, n; bufs: neighbours -> dst[n * N * N] */
+		{
+			const size_t n = (size_t)par[3];
+			const int size = 1 << ((par[2] >> 1) & 0x7f);
+			hevcasm_pred_intra *f = *hevcasm_get_pred_intra(&t_intra, (int)par[1], (int)par[2]);
+			uint8_t *dst = (uint8_t *)calloc(n * size * size + 64, 1);
+			if (!f) { status = 4; free(dst); break; }
+			for (size_t i = 0; i < n; ++i) f(dst + i * size * size, in[0].p + i * par[0], (int)par[1], (int)par[2]);
+			out[0].p = dst; out[0].bytes = n * size * size; nout = 1;
+			break;
+		}
+		case OP_SSD_LINEAR: /* par: size, n; bufs: src0, src1, off0, off1 -> int[n] */
+		{
+			const size_t n = (size_t)par[1];
+			const uint32_t *o0 = (const uint32_t *)in[2].p, *o1 = (const uint32_t *)in[3].p;
+			hevcasm_ssd_linear *f = hevcasm_get_ssd_linear((int)par[0], HEVCASM_C_REF);
+			int *r = (int *)malloc(4 * n + 4);
+			for (size_t i = 0; i < n; ++i) r[i] = f(in[0].p + o0[i], in[1].p + o1[i], (int)par[0]);
+			out[0].p = (uint8_t *)r; out[0].bytes = 4 * n; nout = 1;
+			break;
+		}
 		case OP_SELFTEST: /* par[0] = bit mask of families; runs the reference's own self-tests on its C path. Output on stderr-free stdout is
 		                     not possible here (stdout carries the protocol) so the text goes to the file named by buf 0. */
 		{
@@ -327,6 +352,8 @@ int main(void)
 			if (par[0] & 256) hevcasm_test_quantize(&errors, m);
 			if (par[0] & 512) hevcasm_test_quantize_reconstruct(&errors, m);
 			if (par[0] & 1024) hevcasm_test_hadamard_satd(&errors, m);
+			if (par[0] & 2048) hevcasm_test_pred_intra(&errors, m);
+			if (par[0] & 4096) hevcasm_test_ssd_linear(&errors, m);
 			fflush(f);
 			stdout = keep;
 			fclose(f);

@@ -255,8 +255,47 @@ def _subpel_case(w, h, n, seed, kind):
                 ref_off=ref_off.astype(np.uint32), w=w, h=h, n=n)
 
 
+def intra_cases(seed=1100):
+    """INTRA_DC, all four sizes, plain and edge-filtered (luma packing, sizes below 32); records of
+    128 and of 160 bytes (any stride), extremes that saturate the sum."""
+    out = []
+    for log2 in (2, 3, 4, 5):
+        for c_idx in (1, 0):
+            if c_idx == 0 and log2 == 5:
+                continue
+            packed = (8 << 8) | (log2 << 1) | (1 if c_idx == 0 else 0)
+            for stride, n in ((128, 37), (160, 5)):
+                nb = wl.fill_u8(stride * n + 64, seed + 8 * log2 + c_idx)
+                out.append(("intra_dc_%d%s_s%d" % (1 << log2, "_edge" if packed & 1 else "", stride), "intra",
+                            dict(neighbours=nb, neighbour_stride=stride, mode=1, packed=packed, n=n)))
+            for tag, val in (("max", 255), ("zero", 0)):
+                out.append(("intra_dc_%d%s_%s" % (1 << log2, "_edge" if packed & 1 else "", tag), "intra",
+                            dict(neighbours=np.full(128 * 3, val, dtype=np.uint8), neighbour_stride=128, mode=1, packed=packed, n=3)))
+    return out
+
+
+def ssd_linear_cases(seed=1200):
+    """Run lengths on both sides of every kernel switch (4 / 16 / 64 lanes per run), tails that are
+    not multiples of 16, zero length, the reference's test length 0x200, byte-misaligned starts,
+    and a 64 KiB run of extremes whose sum wraps 32 bits."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for size, n in ((0, 3), (1, 5), (15, 9), (16, 9), (17, 9), (100, 21), (127, 7), (128, 7), (0x200, 33), (1000, 5), (1023, 4), (1024, 4), (4099, 3), (65536, 2)):
+        span = max(size, 1) + 7
+        a = wl.fill_u8(span * n + 16, seed + size)
+        b = wl.fill_u8(span * n + 16, seed + size + 1)
+        off0 = (np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32)
+        off1 = (np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32)
+        out.append(("ssdlin_%d" % size, "ssd_linear", dict(src0=a, src1=b, off0=off0, off1=off1, size=size)))
+    a = np.full(2 * 70000, 255, dtype=np.uint8)
+    b = np.zeros(2 * 70000, dtype=np.uint8)
+    out.append(("ssdlin_wrap", "ssd_linear", dict(src0=a, src1=b, off0=np.array([0, 70000], dtype=np.uint32), off1=np.array([3, 70001], dtype=np.uint32), size=69999)))
+    return out
+
+
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
-                      dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases)
+                      dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
+                      intra=intra_cases, ssd_linear=ssd_linear_cases)
 
 
 # ------------------------------------------------------------------------------------- runners
@@ -301,6 +340,10 @@ def _run_cpu(api, family, c):
         return (api.me_full_search(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"], c["range"]),)
     if family == "subpel":
         return (api.subpel_refine(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+    if family == "intra":
+        return (api.pred_intra_batch(c["neighbours"], c["neighbour_stride"], c["mode"], c["packed"], c["n"]),)
+    if family == "ssd_linear":
+        return (api.ssd_linear_batch(c["src0"], c["src1"], c["off0"], c["off1"], c["size"]),)
     raise ValueError(family)
 
 
@@ -364,6 +407,11 @@ def run_hip(family, c):
         return (cpu(B.me_full_search(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"], c["range"])),)
     if family == "subpel":
         return (cpu(B.subpel_refine(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+    if family == "intra":
+        size = 1 << ((c["packed"] >> 1) & 0x7f)
+        return (cpu(B.pred_intra(plane(c["n"] * size * size), u8(c["neighbours"]), c["neighbour_stride"], c["mode"], c["packed"], c["n"])),)
+    if family == "ssd_linear":
+        return (cpu(B.ssd_linear(u8(c["src0"]), u8(c["src1"]), off(c["off0"]), off(c["off1"]), c["size"])),)
     raise ValueError(family)
 
 

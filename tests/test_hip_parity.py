@@ -213,11 +213,11 @@ def test_selftest_hip_column():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = ("import ctypes as C, sys; sys.path.insert(0, %r); from hevcasm_amd import capi; L = capi.lib(); e = C.c_int(0);\n"
             "m = capi.C_REF | capi.HIP\n"
-            "for f in ('sad', 'sad_multiref', 'ssd', 'hadamard_satd', 'quantize_inverse', 'quantize', 'quantize_reconstruct', 'pred_uni', 'pred_bi', 'inverse_transform_add', 'transform'):\n"
+            "for f in ('sad', 'sad_multiref', 'ssd', 'hadamard_satd', 'quantize_inverse', 'quantize', 'quantize_reconstruct', 'pred_uni', 'pred_bi', 'inverse_transform_add', 'transform', 'pred_intra', 'ssd_linear'):\n"
             "    getattr(L, 'hevcasm_test_' + f)(C.byref(e), m)\n"
             "print('ERRORS', e.value)\n") % root
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "ERRORS 0" in r.stdout, r.stdout[-3000:]
     assert "MISMATCH" not in r.stdout
-    assert " HIP:" in r.stdout
+    assert r.stdout.count(" HIP:") == 23 + 23 + 5 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4 + 5 + 5 + 7 + 1

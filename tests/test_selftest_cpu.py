@@ -24,7 +24,9 @@ ROW = re.compile(r"^\t(\d+)x(\d+): C_OPT:(\d+)$")
 
 
 def _run(families):
-    r = subprocess.run([sys.executable, "-c", _DRIVER % (ROOT, tuple(families))], capture_output=True, text=True, timeout=600)
+    # functional run: the timing columns are not asserted, so cap the harness's iteration counts
+    r = subprocess.run([sys.executable, "-c", _DRIVER % (ROOT, tuple(families))], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HEVCASM_TEST_MAX_ITERATIONS="40"))
     assert r.returncode == 0, r.stderr[-2000:]
     return r.stdout
 
@@ -39,9 +41,10 @@ def test_sad_selftest_grammar_and_zero_errors():
 
 
 def test_quick_families_zero_errors():
-    out = _run(["sad_multiref", "ssd", "hadamard_satd", "quantize_inverse", "quantize", "quantize_reconstruct", "pred_uni", "pred_bi"])
+    out = _run(["sad_multiref", "ssd", "pred_intra", "hadamard_satd", "quantize_inverse", "quantize", "quantize_reconstruct", "pred_uni", "pred_bi", "ssd_linear",
+                "inverse_transform_add", "transform"])
     assert "MISMATCH" not in out and "ERRORS 0" in out
-    assert out.count("C_OPT:") == 23 + 5 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4
+    assert out.count("C_OPT:") == 23 + 5 + 7 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4 + 1 + 5 + 5
 
 
 def test_same_rows_as_the_reference_selftest(tmp_path, refproc):
