@@ -57,17 +57,26 @@ __global__ __launch_bounds__(kThreads) void pred_intra_dc_kernel(
 	for (int k = 0; k < 4; ++k) out.d[k] = (uint32_t)dc * 0x01010101u;
 	if (filter_edge)
 	{
-		// pred_intra.c:80-93: first row and first column blend the neighbours into the DC value
+		// pred_intra.c:80-93: first row and first column blend the neighbours into the DC value.
+		// A lane owns 16 consecutive output bytes = ROWS rows of min(N, 16) columns.
+		constexpr int ROWS = N >= 16 ? 1 : 16 / N, COLS = N >= 16 ? 16 : N;
+		const int y0 = 16 * (int)j / N, x0 = 16 * (int)j % N;
 		uint8_t px[16];
 #pragma unroll
-		for (int b = 0; b < 16; ++b)
+		for (int b = 0; b < 16; ++b) px[b] = (uint8_t)dc;
+		if (y0 == 0)
 		{
-			const int idx = 16 * (int)j + b, y = idx / N, x = idx % N;
-			int v = dc;
-			if (y == 0 && x == 0) v = (nb[63] + 2 * dc + nb[64] + 2) >> 2;
-			else if (y == 0) v = (nb[64 + x] + 3 * dc + 2) >> 2;
-			else if (x == 0) v = (nb[63 - y] + 3 * dc + 2) >> 2;
-			px[b] = (uint8_t)v;
+			Chunk<COLS> top;                       // samples (x0 .. x0 + COLS - 1, -1)
+			top.load(nb + 64 + x0);
+#pragma unroll
+			for (int b = 0; b < COLS; ++b) px[b] = (uint8_t)((((top.d[b / 4] >> (8 * (b % 4))) & 0xff) + 3 * dc + 2) >> 2);
+		}
+		if (x0 == 0)
+		{
+#pragma unroll
+			for (int r = 0; r < ROWS; ++r)
+				if (y0 + r > 0) px[r * COLS] = (uint8_t)((nb[63 - (y0 + r)] + 3 * dc + 2) >> 2);
+			if (y0 == 0) px[0] = (uint8_t)((nb[63] + 2 * dc + nb[64] + 2) >> 2);
 		}
 #pragma unroll
 		for (int k = 0; k < 4; ++k)

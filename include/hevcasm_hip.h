@@ -105,7 +105,8 @@ int hevcasm_hip_ssd_linear_batch(
 /* Batched hevcasm_pred_intra (reference pred_intra.h:55; C body pred_intra.c:61-101).  Block i
  * receives neighbours + i * neighbour_stride as its `neighbours` argument (left column ending at
  * [63], top row starting at [64]; DC reads bytes [64 - N, 64 + N)) and writes the N x N bytes at
- * dst + i * N * N.  intraPredMode must be 1 (INTRA_DC: the only mode the reference implements);
+ * dst + i * N * N.  Any neighbour_stride is legal; with 2N the records pack back to back (only the
+ * 2N bytes named above are ever read).  intraPredMode must be 1 (INTRA_DC: the only mode the reference implements);
  * packed as hevcasm_pred_intra_pack(): log2 size 2..5, bit 0 = edge filter (sizes below 32). */
 int hevcasm_hip_pred_intra_batch(
 	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,

@@ -264,8 +264,8 @@ def intra_cases(seed=1100):
             if c_idx == 0 and log2 == 5:
                 continue
             packed = (8 << 8) | (log2 << 1) | (1 if c_idx == 0 else 0)
-            for stride, n in ((128, 37), (160, 5)):
-                nb = wl.fill_u8(stride * n + 64, seed + 8 * log2 + c_idx)
+            for stride, n in ((128, 37), (160, 5), (2 << log2, 70)):
+                nb = wl.fill_u8(stride * n + 128, seed + 8 * log2 + c_idx)
                 out.append(("intra_dc_%d%s_s%d" % (1 << log2, "_edge" if packed & 1 else "", stride), "intra",
                             dict(neighbours=nb, neighbour_stride=stride, mode=1, packed=packed, n=n)))
             for tag, val in (("max", 255), ("zero", 0)):

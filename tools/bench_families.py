@@ -140,6 +140,34 @@ def bench_satd():
         torch.cuda.empty_cache()
 
 
+def bench_intra():
+    """INTRA_DC over 2^26 output pixels per launch, 128-byte neighbour records."""
+    for log2 in (2, 3, 4, 5):
+        for edge in ((0, 1) if log2 < 5 else (0,)):
+            for stride in (128, 2 << log2):     # the reference's 128-byte record, and records packed back to back
+                size = 1 << log2
+                nb = (1 << 26) >> (2 * log2)
+                neigh = wl.fill_u8(stride * nb + 128, 400 + log2, device="cuda")
+                dst = torch.empty(nb * size * size, dtype=torch.uint8, device="cuda")
+                packed = (8 << 8) | (log2 << 1) | edge
+                ms = timed(lambda i: B.pred_intra(dst, neigh, stride, 1, packed, nb))
+                report("pred_intra_dc", nb, size * size + 2 * size, ms, size="%dx%d%s" % (size, size, " edge" if edge else ""), neighbour_stride=stride)
+                del neigh, dst
+                torch.cuda.empty_cache()
+
+
+def bench_ssd_linear():
+    """linear SSD, 2 x 256 MiB per launch cut into runs of `size` bytes (whole-frame PSNR = sum of rows)."""
+    total = 1 << 28
+    a, b = wl.fill_u8(total, 500, device="cuda"), wl.fill_u8(total, 501, device="cuda")
+    for size in (64, 0x200, 1920, 4096, 65536):
+        n = total // size
+        off = B.off32((np.arange(n, dtype=np.int64) * size).astype(np.uint32))
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        ms = timed(lambda i: B.ssd_linear(a, b, off, off, size, out=out))
+        report("ssd_linear", n, 2 * size + 12, ms, size="%d bytes" % size)
+
+
 def bench_subpel():
     """quarter-pel refinement of every block of a 3840x2160 luma frame, fused kernel vs
     the unfused composition (49 x pred_uni_8to8_batch into a scratch frame + sad_batch)."""
@@ -171,7 +199,7 @@ def bench_subpel():
 
 
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "me", "subpel"]
+    what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
-        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd)[w]()
+        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, ssdlin=bench_ssd_linear)[w]()
