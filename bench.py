@@ -43,15 +43,20 @@ def algorithmic_bytes(w, h, ways):
     source offset and `ways` reference offsets).
       1-way: 2WH + 4 + 8.
       4-way: SURVEY prices it 5WH + 16, which counts the four candidates as if they were disjoint.
-             In this workload they all lie within +-7 pixels of one position, so they overlap and a
-             cache serves most of the re-reads; pricing them separately lets "achieved" exceed the
-             HBM peak.  We therefore price the 4-way kernel at its COMPULSORY footprint: the source
-             block plus the smaller of (a) four disjoint candidates and (b) the (W + 14) x (H + 14)
-             window that contains every candidate.  The measured HBM traffic (profiles/traffic.json)
-             is slightly below even that."""
+             In this workload they all lie within +-7 pixels of one position, so they overlap, and
+             because the blocks tile the frame the (W + 14) x (H + 14) windows of neighbouring
+             blocks overlap too: over a launch every byte of the reference plane is needed exactly
+             once.  Pricing candidates (or windows) separately lets "achieved" exceed the HBM peak
+             (8.2 TB/s at 32x8), so the 4-way kernel is priced at its COMPULSORY bytes: the source
+             block plus the block's share of the reference plane (frame + borders, 1.031 WH), never
+             more than the window or four disjoint candidates.  The measured HBM traffic
+             (profiles/traffic.json) is within 1-3 % of this."""
     if ways == 1:
         return 2 * w * h + 4 + 8
-    return w * h + min(ways * w * h, (w + 2 * MAX_DISP) * (h + 2 * MAX_DISP)) + 4 * ways + 4 * (1 + ways)
+    from hevcasm_amd import workload as wl
+    plane_share = w * h * ((wl.FRAME_W + 2 * 16) * (wl.FRAME_H + 2 * 8)) / float(wl.FRAME_W * wl.FRAME_H)
+    ref = min(ways * w * h, (w + 2 * MAX_DISP) * (h + 2 * MAX_DISP), int(round(plane_share)))
+    return w * h + ref + 4 * ways + 4 * (1 + ways)
 
 
 def max_over_ranks(seconds, device=None):

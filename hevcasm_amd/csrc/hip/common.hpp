@@ -14,12 +14,14 @@ constexpr int kXcds = 8;           // MI355X: 8 XCDs, each with a private L2
 constexpr int kThreads = 256;      // 4 waves per workgroup, one per SIMD
 
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Loads with no alignment promise.  gfx950 runs with unaligned access enabled, so these
 // compile to one global_load_dword{,x2,x4} whatever the address.
 struct __attribute__((packed, aligned(1))) U1 { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U2 { u32x2 v; };
+struct __attribute__((packed, aligned(1))) U3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) U4 { u32x4 v; };
 struct __attribute__((packed, aligned(1))) H1 { uint16_t v; };
 
@@ -42,6 +44,20 @@ template <> struct Chunk<8>
 	{
 		u32x2 v; v.x = d[0]; v.y = d[1];
 		reinterpret_cast<U2 *>(p)->v = v;
+	}
+};
+template <> struct Chunk<12>
+{
+	uint32_t d[3];
+	__device__ __forceinline__ void load(const uint8_t *p)
+	{
+		const U3 v = *reinterpret_cast<const U3 *>(p);   // one global_load_dwordx3
+		d[0] = v.a; d[1] = v.b; d[2] = v.c;
+	}
+	__device__ __forceinline__ void store(uint8_t *p) const
+	{
+		U3 v; v.a = d[0]; v.b = d[1]; v.c = d[2];
+		*reinterpret_cast<U3 *>(p) = v;
 	}
 };
 template <> struct Chunk<16>

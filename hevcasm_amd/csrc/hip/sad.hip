@@ -14,7 +14,8 @@
 // Arithmetic: v_sad_u8 accumulates 4 byte differences per instruction; SSD uses
 // sum(a-b)^2 = sum a^2 + sum b^2 - 2 sum ab with three v_dot4_u32_u8 (exact: every partial sum
 // is below 2^30 for blocks up to 64x64).  The LPB partial sums are combined with wave shuffles.
-// HBM-bound: algorithmic bytes per block = (1 + WAYS) * W * H + 4 * WAYS (+ 4 * (1 + WAYS) of offsets).
+// HBM-bound for one reference; with four overlapping candidates the vector L1 / L2 carry the re-reads
+// and HBM sees each plane byte about once (DESIGN.md section 4 has the byte accounting).
 
 #include "common.hpp"
 
@@ -58,7 +59,10 @@ constexpr int best_rows(int lpr, int max_r)
 }
 template <int W> struct Plan
 {
-	static constexpr int C = (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
+	// 48 = 4 lanes x 12 bytes (global_load_dwordx3): a row is exactly one quad of lanes, as at W = 64.
+	// With 3 x 16 bytes the quads of the address unit straddle rows: 1.64x the vector-L1 accesses per
+	// pixel of the 64-wide mapping, and 4-way 48x64 was the slowest kernel of the whole mix.
+	static constexpr int C = W == 48 ? 12 : (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
 	static constexpr int LPR = W / C;
 	static constexpr int R_PREF = best_rows(LPR, W >= 32 ? 8 : 4);   // used when it divides H
 	static constexpr int R_SAFE = best_rows(LPR, 4);                  // H is always a multiple of 4
@@ -121,15 +125,20 @@ template <int C, int LPR> struct AlignedRefChunk
 {
 	uint32_t d[C / 4];
 	uint32_t tail;
-	__device__ __forceinline__ void load(const uint8_t *p, uint32_t sh, bool last_lane_of_row)
+	// `base` is dword-aligned, so (off & 3) is the chunk's misalignment and (off & ~3) never underflows.
+	// The C aligned bytes that contain the chunk's first byte:
+	__device__ __forceinline__ void load_main(const uint8_t *base, uint32_t off)
 	{
-		const uint8_t *pa = p - sh;
 		Chunk<C> c;
-		c.load(pa);
+		c.load(base + (size_t)(off & ~3u));
 #pragma unroll
 		for (int i = 0; i < C / 4; ++i) d[i] = c.d[i];
-		tail = 0;
-		if (last_lane_of_row && sh) tail = *reinterpret_cast<const uint32_t *>(pa + C);
+	}
+	// the row's last lane only: the dword after them (when the row is aligned it is not needed and
+	// must not be touched -- it may lie outside the plane -- so an in-row dword is loaded instead)
+	__device__ __forceinline__ void load_tail(const uint8_t *base, uint32_t off)
+	{
+		tail = *reinterpret_cast<const uint32_t *>(base + (size_t)((off & ~3u) + ((off & 3u) ? C : 0)));
 	}
 	__device__ __forceinline__ void finish(uint32_t sh, bool last_lane_of_row, Chunk<C> &out) const
 	{
@@ -146,7 +155,8 @@ template <int C, int LPR> struct AlignedRefChunk
 };
 
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
-template <int W, int C, int R, int U, int WAYS, int OP>
+// LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
+template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP>
 __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
@@ -161,8 +171,6 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t sub = lane / LPB, j = lane - sub * LPB;
 	const uint32_t row0 = j / LPR, chunk = j - row0 * LPR;
-	const ptrdiff_t step_src = R * stride_src, step_ref = R * stride_ref;
-
 	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
 	// block so that every lane executes the same loads and shuffles; only real leaders store.
 	uint32_t blk = wave * BPW + (sub < (uint32_t)BPW ? sub : BPW - 1);
@@ -175,66 +183,97 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 #pragma unroll
 	for (int k = 0; k < WAYS; ++k) ro[k] = ref_off[(size_t)blk * WAYS + k];
 
-	const uint8_t *ps = src + so + (ptrdiff_t)row0 * stride_src + chunk * C;
-	const uint8_t *pr[WAYS];
+	// Addresses are a uniform base (SGPR pair) + a 32-bit per-lane offset (one VGPR per plane and
+	// candidate, one integer add per row step): every byte of every block lies within 4 GiB of its
+	// plane's base pointer (hevcasm_hip.h), so the offsets cannot wrap.  The reference base is
+	// rounded down to a dword so that (offset & 3) is the byte misalignment of the address itself.
+	const uint32_t ref_mis = (uint32_t)(reinterpret_cast<uintptr_t>(ref) & 3u);
+	const uint8_t *const ref_al = ref - ref_mis;
+	const uint32_t ss32 = (uint32_t)stride_src, sr32 = (uint32_t)stride_ref;
+	const uint32_t step_src = R * ss32, step_ref = R * sr32;
+	uint32_t os = so + row0 * ss32 + chunk * C;
+	uint32_t orf[WAYS];
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) pr[k] = ref + ro[k] + (ptrdiff_t)row0 * stride_ref + chunk * C;
+	for (int k = 0; k < WAYS; ++k) orf[k] = ro[k] + ref_mis + row0 * sr32 + chunk * C;
 
 	Acc<C, OP> acc[WAYS];
 
-	if constexpr (WAYS == 4 && C == 16 && LPR >= 2)   // 8-byte chunks were measured too: slower (half the lanes issue the tail load)
+	// Row loop.  A trip is U row slots per lane, U * (1 + WAYS) loads.  Written slot by slot -- consume
+	// slot u, reload slot u for the next trip -- with only a scheduling barrier in between, which lets
+	// the compiler hoist every reload above the consumption of the slot it replaces (into fresh
+	// registers, copied back once per trip): the next trip's loads go out interleaved with this trip's
+	// arithmetic and two trips are in flight per wave.  The alternatives were built and timed on one
+	// box (profiles/r01_sad_pipeline_ab.txt; 4-way 64x64, ms per 1 Mi blocks): consume a trip then
+	// load the next 2.09; reload each slot strictly in place (half the registers) 2.17; two explicit
+	// buffers trip by trip 1.94, slot by slot 2.11; this form 1.81.  Memory-level parallelism per
+	// wave outweighs the occupancy lost to the second register set.
+	const int trips = LOOP ? H / (R * U) : 1;
+	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;   // 8-byte chunks were measured too: slower (half the lanes issue the tail load)
+	const bool last = chunk == LPR - 1;
+
+	Chunk<C> s[U];
+	AlignedRefChunk<C, LPR> ra[ALIGNED ? U : 1][ALIGNED ? WAYS : 1];   // wide 4-way blocks: dword-aligned loads + funnel shift
+	Chunk<C> r[ALIGNED ? 1 : U][ALIGNED ? 1 : WAYS];                   // everything else: loads at the byte address
+
+	// slot u <- row u of the trip `ahead` trips below the current one
+	auto fill = [&](int u, int ahead)
 	{
-		// wide 4-way blocks: dword-aligned reference loads + register funnel shift
-		const bool last = chunk == LPR - 1;
-		for (int y = 0; y < H; y += R * U)
+		s[u].load(src + (size_t)(os + (ahead * U + u) * step_src));
+#pragma unroll
+		for (int k = 0; k < WAYS; ++k)
 		{
-			Chunk<C> s[U];
-			AlignedRefChunk<C, LPR> ra[U][WAYS];
+			const uint32_t o = orf[k] + (ahead * U + u) * step_ref;
+			if constexpr (ALIGNED) ra[u][k].load_main(ref_al, o);
+			else r[u][k].load(ref_al + (size_t)o);
+		}
+		if constexpr (ALIGNED)
+		{
+			if (last)      // one divergent region per slot, not one per load
+			{
+#pragma unroll
+				for (int k = 0; k < WAYS; ++k) ra[u][k].load_tail(ref_al, orf[k] + (ahead * U + u) * step_ref);
+			}
+		}
+	};
+	auto drain = [&](int u)
+	{
+#pragma unroll
+		for (int k = 0; k < WAYS; ++k)
+		{
+			if constexpr (ALIGNED)
+			{
+				Chunk<C> x;
+				ra[u][k].finish((orf[k] + u * step_ref) & 3u, last, x);
+				acc[k].add(s[u], x);
+			}
+			else
+			{
+				acc[k].add(s[u], r[u][k]);
+			}
+		}
+	};
+
+#pragma unroll
+	for (int u = 0; u < U; ++u) fill(u, 0);
+	if constexpr (LOOP)
+	{
+		for (int t = 1; t < trips; ++t)
+		{
 #pragma unroll
 			for (int u = 0; u < U; ++u)
 			{
-				s[u].load(ps + u * step_src);
-#pragma unroll
-				for (int k = 0; k < WAYS; ++k)
-				{
-					const uint8_t *p = pr[k] + u * step_ref;
-					ra[u][k].load(p, (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), last);
-				}
+				drain(u);
+				__builtin_amdgcn_sched_barrier(0);
+				fill(u, 1);
+				__builtin_amdgcn_sched_barrier(0);
 			}
+			os += U * step_src;
 #pragma unroll
-			for (int u = 0; u < U; ++u)
-#pragma unroll
-				for (int k = 0; k < WAYS; ++k)
-				{
-					const uint8_t *p = pr[k] + u * step_ref;
-					Chunk<C> r;
-					ra[u][k].finish((uint32_t)(reinterpret_cast<uintptr_t>(p) & 3u), last, r);
-					acc[k].add(s[u], r);
-				}
-			ps += U * step_src;
-#pragma unroll
-			for (int k = 0; k < WAYS; ++k) pr[k] += U * step_ref;
+			for (int k = 0; k < WAYS; ++k) orf[k] += U * step_ref;
 		}
 	}
-	else
-	for (int y = 0; y < H; y += R * U)
-	{
-		Chunk<C> s[U], r[U][WAYS];
 #pragma unroll
-		for (int u = 0; u < U; ++u)
-		{
-			s[u].load(ps + u * step_src);
-#pragma unroll
-			for (int k = 0; k < WAYS; ++k) r[u][k].load(pr[k] + u * step_ref);
-		}
-#pragma unroll
-		for (int u = 0; u < U; ++u)
-#pragma unroll
-			for (int k = 0; k < WAYS; ++k) acc[k].add(s[u], r[u][k]);
-		ps += U * step_src;
-#pragma unroll
-		for (int k = 0; k < WAYS; ++k) pr[k] += U * step_ref;
-	}
+	for (int u = 0; u < U; ++u) drain(u);
 
 	uint32_t total[WAYS];
 #pragma unroll
@@ -266,8 +305,12 @@ template <int W, int C, int R, int U, int WAYS, int OP> static int launch_cfg(co
 {
 	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
 	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
-	hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP>), dim3(grid), dim3(kThreads), 0, a.st,
-			a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
+	if (a.H == R * U)
+		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, false>), dim3(grid), dim3(kThreads), 0, a.st,
+				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
+	else
+		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, true>), dim3(grid), dim3(kThreads), 0, a.st,
+				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
 	return launch_status("block_cost_kernel");
 }
 

@@ -17,8 +17,9 @@
  *  - Every data pointer is a DEVICE pointer (hipMalloc or the helpers below); the caller keeps
  *    frames resident in HBM across calls.  Offsets are in bytes for uint8 planes and in
  *    elements for int16 planes; they must address memory inside the plane including the
- *    filter margins.  A plane larger than 4 GiB is handled by splitting the batch and
- *    advancing the base pointer.
+ *    filter margins, and every byte a block touches must lie less than 4 GiB - 64 above its
+ *    plane's base pointer (the kernels address with base + 32-bit offset).  A plane larger than
+ *    that is handled by splitting the batch and advancing the base pointer.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
  *    asynchronous: they return once the launch is queued.
  *  - Return value: 0 on success; HEVCASM_HIP_EINVAL for arguments outside the domain the

@@ -15,7 +15,7 @@ for size in ("64x64", "16x16"):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for p in glob.glob(os.path.join(prof, "pmc_%s_%s" % (size, counter), "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(p)):
-                m = re.search(r"hevc::block_cost_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>", r["Kernel_Name"])
+                m = re.search(r"hevc::block_cost_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)[,>]", r["Kernel_Name"])
                 if m and r["Counter_Name"] == counter:
                     ways = int(m.group(5))
                     vals.setdefault((ways, counter), []).append(float(r["Counter_Value"]))
