@@ -77,7 +77,7 @@ void hevcasm_test_inverse_transform_add(int *error_count, hevcasm_instruction_se
 
 	static HEVCASM_ALIGN(32, int16_t, coefficients[32 * 32]);
 	static HEVCASM_ALIGN(32, uint8_t, predicted[32 * 32]);
-	for (int i = 0; i < 32 * 32; ++i) coefficients[i] = (int16_t)(((rand() << 1) ^ rand()) & 0xffff);
+	for (int i = 0; i < 32 * 32; ++i) coefficients[i] = (int16_t)((((unsigned)rand() << 1) ^ (unsigned)rand()) & 0xffff);
 	for (int i = 0; i < 32 * 32; ++i) predicted[i] = (uint8_t)rand();
 
 	bound_inverse b[2];
