@@ -35,6 +35,14 @@ def sad_cases(n=96, sizes=None, seed=100):
     for (w, h) in [(4, 4), (20, 28), (36, 4), (44, 60), (52, 12), (60, 64), (28, 8), (40, 40), (56, 20)]:
         out.append(("sad_%dx%d" % (w, h), "sad", wl.sad_case(w, h, 40, seed + w + h)))
         out.append(("sad4_%dx%d" % (w, h), "sad4", wl.sad_case(w, h, 40, seed + w + h + 1, ways=4)))
+    # bottom-up planes: negative strides (the reference's strides are ptrdiff_t); offsets then point at
+    # the block's first row, which is the highest address
+    for (w, h, ways) in ((16, 16, 1), (64, 64, 4), (48, 64, 4), (32, 8, 4), (8, 8, 1), (24, 32, 4)):
+        c = wl.sad_case(w, h, 24, seed + 300 + w + h, ways=ways)
+        c["src_off"] = (c["src_off"].astype(np.int64) + (h - 1) * c["stride_src"]).astype(np.uint32)
+        c["ref_off"] = (c["ref_off"].astype(np.int64) + (h - 1) * c["stride_ref"]).astype(np.uint32)
+        c["stride_src"], c["stride_ref"] = -c["stride_src"], -c["stride_ref"]
+        out.append(("sad%s_%dx%d_negstride" % ("4" if ways == 4 else "", w, h), "sad4" if ways == 4 else "sad", c))
     # ragged batch sizes around the wave / workgroup granularity
     for n_odd in (1, 3, 63, 65, 257):
         out.append(("sad_16x16_n%d" % n_odd, "sad", wl.sad_case(16, 16, n_odd, seed + n_odd)))

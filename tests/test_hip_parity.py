@@ -188,6 +188,32 @@ def test_subpel_refine_equals_unfused_composition():
     assert np.array_equal(got[:, 0], best % 7 - 3) and np.array_equal(got[:, 1], best // 7 - 3)
 
 
+def test_sad_misaligned_plane_base():
+    """The 4-way kernel rounds the reference base down to a dword and works with offsets from there:
+    a plane pointer that is itself byte-misaligned (a view into a larger buffer) must give the same
+    sums as the aligned copy.  All three misalignments, 1-way and 4-way, wide and narrow blocks."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    for (w, h) in ((64, 64), (48, 64), (32, 32), (16, 16), (8, 8)):
+        c = wl.sad_case(w, h, 50, 700 + w, ways=4)
+        want4 = pyoracle.sad_multiref_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], w, h)
+        want1 = pyoracle.sad_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"].reshape(-1, 4)[:, 0].copy(), w, h)
+        so, ro4 = B.off32(c["src_off"]), B.off32(c["ref_off"])
+        ro1 = B.off32(c["ref_off"].reshape(-1, 4)[:, 0].copy())
+        for k in (1, 2, 3):
+            big_r = torch.zeros(c["ref"].size + 8, dtype=torch.uint8, device="cuda")
+            big_s = torch.zeros(c["src"].size + 8, dtype=torch.uint8, device="cuda")
+            big_r[k:k + c["ref"].size] = torch.from_numpy(c["ref"]).cuda()
+            big_s[k:k + c["src"].size] = torch.from_numpy(c["src"]).cuda()
+            ref_v, src_v = big_r[k:], big_s[k:]
+            assert ref_v.data_ptr() % 4 == k
+            got4 = B.sad_multiref(src_v, c["stride_src"], ref_v, c["stride_ref"], so, ro4, w, h).cpu().numpy().reshape(-1, 4)
+            got1 = B.sad(src_v, c["stride_src"], ref_v, c["stride_ref"], so, ro1, w, h).cpu().numpy()
+            assert np.array_equal(got4, want4), (w, h, k)
+            assert np.array_equal(got1, want1), (w, h, k)
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch
