@@ -31,7 +31,8 @@ namespace hevc {
 // the TCP accesses of the aligned case (profiles/r01_sad16_counters_R1_mapping.txt).  Keeping a block's
 // rows together (8-32 lanes per block) lets neighbouring lanes hit the same lines:
 // C = 8, R = 4 -> 4.7 TB/s at 16x16; C = 16, R = 8 -> 5.7 TB/s at 32x32 and 6.2 TB/s at 64x64
-// (gpurun sweep, tools/explore_tiling.py).  Coherent motion is within 10 % of its best mapping.
+// (on-GPU sweeps of an exploration build of this kernel: profiles/r01_sad_tiling_sweep_ways{1,4}.txt).
+// Coherent motion is within 10 % of its best mapping.
 template <int W, int C, int R> struct Tiling
 {
 	static constexpr int LPR = W / C;        // lanes per row
