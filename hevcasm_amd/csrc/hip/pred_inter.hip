@@ -255,7 +255,8 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	// load of the NEXT row's newest window row is issued before this row is computed: one row of
 	// look-ahead costs NDW registers, and the other waves of the SIMD cover the rest of the latency
 	// (a software prefetch one whole group of T rows ahead was measured: +17 VGPRs, one wave fewer
-	// per SIMD, 4-30 % slower).
+	// per SIMD, 4-30 % slower; a ring of 2 / 4 rows in flight: +2 / +6 VGPRs, 0 % / 3-10 % slower --
+	// the waits the counters show are not load latency).
 	for (int y0 = 0; y0 < H; y0 += TAPS)
 	{
 #pragma unroll
