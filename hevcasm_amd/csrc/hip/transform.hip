@@ -568,6 +568,159 @@ __global__ __launch_bounds__(kThreads) void forward4_lane_kernel(
 	for (int k = 0; k < N; ++k) global_row_store<N>(coeffs + (size_t)blk * (N * N) + k * N, o[k]);
 }
 
+// ---- 32x32 forward transform on the matrix cores ---------------------------------------------
+//
+// A 32-point transform of 32 rows IS a 32x32x32 integer matrix product, and with packed butterflies
+// ruled out (the even/odd sums need 17 bits) the VALU form above is issue-bound at 0.38 of the HBM
+// peak.  v_mfma_i32_32x32x32_i8 takes int8 operands; the coefficient matrix fits (|c| <= 90) and an
+// int16 operand is split exactly into bytes, x = 256 * hi + (lo - 128) + 128 with hi signed and
+// lo - 128 signed, so   X C' = 256 (Hi C') + (Lo' C') + 128 * rowsum(C)   in exact 32-bit arithmetic
+// (|Hi C'| <= 32 * 128 * 90, far below 2^31 / 256).  One wave per block, no LDS:
+//   stage 1  T = X C'   A operand = the residual rows as they lie in memory (lane = row r, half h:
+//            16 consecutive int16 = two 16-byte loads), B operand = C', a per-lane constant;
+//            rounding constant and the 128 * rowsum term ride in the accumulator;
+//   stage 2  Out = C A' where A' = trunc16(T >> 4).  T's accumulator tile has its column (k) on the
+//            lane and its 16 rows in registers, which is exactly a B operand that sums over the row
+//            index: no lane movement.  The k order inside the instruction is then the accumulator's
+//            row order (j&3) + 8 (j>>2) + 4 h, and the constant A operand is laid out to match.
+// Both operands of an MFMA only have to AGREE on which k a byte carries (tools/ubench/mfma_i8_layout.hip),
+// so stage 1 simply calls byte j of lane half h "k = 16 h + j".
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef int v16i32 __attribute__((ext_vector_type(16)));
+
+struct Forward32Tables
+{
+	uint32_t b1[64][4];    // stage 1 B operand: lane (k' = l & 31, h = l >> 5), byte j = C[k'][16 h + j]
+	uint32_t a2[64][4];    // stage 2 A operand: lane (m  = l & 31, h),          byte j = C[m][(j & 3) + 8 (j >> 2) + 4 h]
+	int rowsum[32];        // sum_n C[k][n]
+};
+constexpr Forward32Tables make_forward32_tables()
+{
+	Forward32Tables t = {};
+	for (int l = 0; l < 64; ++l)
+	{
+		const int r = l & 31, h = l >> 5;
+		for (int j = 0; j < 16; ++j)
+		{
+			const uint32_t c1 = (uint32_t)(unsigned char)kDct.m[r][16 * h + j];
+			const uint32_t c2 = (uint32_t)(unsigned char)kDct.m[r][(j & 3) + 8 * (j >> 2) + 4 * h];
+			t.b1[l][j / 4] |= c1 << (8 * (j % 4));
+			t.a2[l][j / 4] |= c2 << (8 * (j % 4));
+		}
+	}
+	for (int k = 0; k < 32; ++k)
+		for (int n = 0; n < 32; ++n) t.rowsum[k] += kDct.m[k][n];
+	return t;
+}
+__constant__ Forward32Tables kFwd32 = make_forward32_tables();
+
+// 8 int16 in 4 dwords -> their low bytes (minus 128, as int8) and high bytes, 2 dwords each
+__device__ __forceinline__ void split_bytes(const uint32_t (&w)[4], uint32_t (&lo)[2], uint32_t (&hi)[2])
+{
+	lo[0] = __builtin_amdgcn_perm(w[1], w[0], 0x06040200) ^ 0x80808080u;
+	lo[1] = __builtin_amdgcn_perm(w[3], w[2], 0x06040200) ^ 0x80808080u;
+	hi[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07050301);
+	hi[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07050301);
+}
+
+constexpr int kFwd32BlocksPerWave = 2;   // 1, 2, 4, 8 measured: within noise of each other (0.068-0.075 ms per 65 536 blocks)
+
+__global__ __launch_bounds__(kThreads) void forward32_mfma_kernel(
+	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride,
+	const uint32_t *__restrict__ src_off, uint32_t n_blocks)
+{
+	constexpr int S1 = 4, S2 = 11;   // residual_decode.c:855-892 for N = 32, 8-bit video
+	constexpr int BPW = kFwd32BlocksPerWave;
+	// a wave walks BPW consecutive blocks; the next block's residuals are in flight while this one is
+	// transformed, and the constant operands are fetched once
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(xcd_contiguous(blockIdx.x, gridDim.x) * (kThreads / kWave) + (threadIdx.x >> 6));
+	const uint32_t first = wave * BPW;
+	if (first >= n_blocks) return;
+	const int count = (int)min((uint32_t)BPW, n_blocks - first);
+	const int l = threadIdx.x & 63, r = l & 31, h = l >> 5;
+
+	const v4i32 b1 = { (int)kFwd32.b1[l][0], (int)kFwd32.b1[l][1], (int)kFwd32.b1[l][2], (int)kFwd32.b1[l][3] };
+	const v4i32 a2 = { (int)kFwd32.a2[l][0], (int)kFwd32.a2[l][1], (int)kFwd32.a2[l][2], (int)kFwd32.a2[l][3] };
+	const int bias1 = 128 * kFwd32.rowsum[r] + (1 << (S1 - 1));
+	int bias2[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) bias2[i] = 128 * kFwd32.rowsum[(i & 3) + 8 * (i >> 2) + 4 * h] + (1 << (S2 - 1));
+
+	// this lane's 16 residuals of a block: row r, columns 16 h .. 16 h + 15
+	const ptrdiff_t lane_off = (ptrdiff_t)r * src_stride + 16 * h;
+	auto load_block = [&](uint32_t blk, uint32_t (&x)[8])
+	{
+		const uint8_t *p = reinterpret_cast<const uint8_t *>(src + src_off[blk] + lane_off);
+		Chunk<16> c0, c1;
+		c0.load(p);
+		c1.load(p + 16);
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { x[i] = c0.d[i]; x[4 + i] = c1.d[i]; }
+	};
+	uint32_t x[8], xn[8];
+	load_block(first, x);
+
+	for (int b = 0; b < count; ++b)
+	{
+		const uint32_t blk = first + b;
+		if (b + 1 < count) load_block(blk + 1, xn);
+
+		v4i32 a_lo, a_hi;
+		{
+			uint32_t lo[2], hi[2];
+			split_bytes({ x[0], x[1], x[2], x[3] }, lo, hi);
+			a_lo.x = lo[0]; a_lo.y = lo[1]; a_hi.x = hi[0]; a_hi.y = hi[1];
+			split_bytes({ x[4], x[5], x[6], x[7] }, lo, hi);
+			a_lo.z = lo[0]; a_lo.w = lo[1]; a_hi.z = hi[0]; a_hi.w = hi[1];
+		}
+
+		// stage 1: this lane ends up with T[row][k = r] for its 16 rows
+		v16i32 t_lo, t_hi = { 0 };
+#pragma unroll
+		for (int i = 0; i < 16; ++i) t_lo[i] = bias1;
+		t_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b1, t_lo, 0, 0, 0);
+		t_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b1, t_hi, 0, 0, 0);
+
+		// intermediate, truncated to int16 as the reference's int16 array does; paired for the byte split
+		uint32_t pair[8];
+#pragma unroll
+		for (int i = 0; i < 16; i += 2)
+		{
+			const int v0 = ((t_hi[i] << 8) + t_lo[i]) >> S1, v1 = ((t_hi[i + 1] << 8) + t_lo[i + 1]) >> S1;
+			pair[i / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100);
+		}
+		v4i32 b_lo, b_hi;
+		{
+			uint32_t lo[2], hi[2];
+			split_bytes({ pair[0], pair[1], pair[2], pair[3] }, lo, hi);
+			b_lo.x = lo[0]; b_lo.y = lo[1]; b_hi.x = hi[0]; b_hi.y = hi[1];
+			split_bytes({ pair[4], pair[5], pair[6], pair[7] }, lo, hi);
+			b_lo.z = lo[0]; b_lo.w = lo[1]; b_hi.z = hi[0]; b_hi.w = hi[1];
+		}
+
+		// stage 2: Out[m][k = r] for this lane's 16 output rows m = (i & 3) + 8 (i >> 2) + 4 h
+		v16i32 o_lo, o_hi = { 0 };
+#pragma unroll
+		for (int i = 0; i < 16; ++i) o_lo[i] = bias2[i];
+		o_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_lo, o_lo, 0, 0, 0);
+		o_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_hi, o_hi, 0, 0, 0);
+
+		// two neighbouring columns per dword store: even lanes take the odd lane's value by DPP
+		int16_t *out = coeffs + (size_t)blk * 1024 + r;
+#pragma unroll
+		for (int i = 0; i < 16; ++i)
+		{
+			const int v = ((o_hi[i] << 8) + o_lo[i]) >> S2;
+			const int next = __builtin_amdgcn_mov_dpp(v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+			const uint32_t both = __builtin_amdgcn_perm((uint32_t)next, (uint32_t)v, 0x05040100);
+			const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
+			if (!(l & 1)) *reinterpret_cast<uint32_t *>(out + 32 * m) = both;
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) x[i] = xn[i];
+	}
+}
+
 template <int N, bool DST, bool DEQUANT>
 static int launch_inverse(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdiff_t sp, const uint32_t *dof, const uint32_t *pof,
 		const int16_t *c, int scale, int shift, size_t n, hipStream_t st)
@@ -654,6 +807,8 @@ extern "C" int hevcasm_hip_transform_batch(
 	{
 	case 3: return launch_forward<8, false>(coeffs, src, src_stride, src_off, n_blocks, st);
 	case 4: return launch_forward<16, false>(coeffs, src, src_stride, src_off, n_blocks, st);
-	default: return launch_forward<32, false>(coeffs, src, src_stride, src_off, n_blocks, st);
+	default:
+		hipLaunchKernelGGL(forward32_mfma_kernel, dim3(ceil_div(n_blocks, (size_t)(kThreads / kWave) * kFwd32BlocksPerWave)), dim3(kThreads), 0, st, coeffs, src, src_stride, src_off, (uint32_t)n_blocks);
+		return launch_status("forward32_mfma_kernel");
 	}
 }
