@@ -1,4 +1,4 @@
-// subpel.hip -- fused quarter-pel refinement: luma interpolation -> SAD -> arg-min, all 49
+// subpel.hip -- fused quarter-pel refinement: luma interpolation -> SAD or Hadamard SATD -> arg-min, all 49
 // displacements (qx, qy) in [-3, 3]^2 of a block in one pass.
 //
 // The composition it replaces is 49 x { hevcasm_pred_uni_8to8 (pred_inter.h:56, C bodies
@@ -83,6 +83,69 @@ template <int CTRL> __device__ __forceinline__ uint32_t add_dpp(uint32_t v)
 	return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
 }
 
+// ---- Hadamard SATD of the candidate (metric 1) ------------------------------------------------
+//
+// hevcasm_hadamard_satd (hadamard.c:76-111) over TILE x TILE tiles.  Lanes are dealt so that the four
+// rows of a 4x4 sub-block are the four lanes of a quad, and for 8x8 tiles the four 4x4 sub-blocks of
+// a tile are the four quads of one 16-lane DPP row.  A lane holds its row's 4 differences as two
+// packed int16 pairs (every Hadamard coefficient of an 8x8 block of byte differences is within
+// +-16320): horizontal 4-point butterflies in the lane, vertical ones across the quad by DPP, and --
+// H8 = H2 (x) H4 -- two more butterfly stages across the quads (ds_swizzle: lane ^ 4, lane ^ 8).
+// The sum of magnitudes does not depend on the order of the basis, so any complete set of
+// butterflies gives the reference's sum; its rounding (sum + n/4) / (n/2) is applied per tile.
+__device__ __forceinline__ uint32_t pk_add16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) + __builtin_bit_cast(s16x2, b))); }
+__device__ __forceinline__ uint32_t pk_sub16(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, (s16x2)(__builtin_bit_cast(s16x2, a) - __builtin_bit_cast(s16x2, b))); }
+// v * sign + p with sign = (+1, +1) or (-1, -1): one v_pk_mad_i16
+__device__ __forceinline__ uint32_t butterfly(uint32_t v, uint32_t sign, uint32_t p) { return pk_mad16(v, sign, p); }
+
+struct SatdLane
+{
+	uint32_t s02, s13;             // the source row's pixels (0, 2) and (1, 3) as int16 pairs
+	uint32_t sign1, sign2, sign4, sign8;   // (-1, -1) where the lane is the upper partner of a butterfly, else (+1, +1)
+	bool leader;                   // first lane of its tile
+};
+
+template <int QX, int TILE> __device__ __forceinline__ uint32_t candidate_satd(const uint32_t (&d)[6], const SatdLane &ln, uint32_t acc)
+{
+	constexpr int FX = QX & 3, IX = QX < 0 ? -1 : 0;
+	const int o0 = hsum<FX, 0 + IX + 1>(d, 2048), o1 = hsum<FX, 1 + IX + 1>(d, 2048);
+	const int o2 = hsum<FX, 2 + IX + 1>(d, 2048), o3 = hsum<FX, 3 + IX + 1>(d, 2048);
+	// predicted pixels (0, 2) and (1, 3), saturated to bytes, widened to int16 pairs
+	const uint32_t p02 = __builtin_amdgcn_perm(0, __builtin_amdgcn_ashr_pk_u8_i32(o0, o2, 12), 0x0c010c00);
+	const uint32_t p13 = __builtin_amdgcn_perm(0, __builtin_amdgcn_ashr_pk_u8_i32(o1, o3, 12), 0x0c010c00);
+	const uint32_t d02 = pk_sub16(ln.s02, p02), d13 = pk_sub16(ln.s13, p13);
+	// row transform: (d0+d1, d2+d3), (d0-d1, d2-d3) -> all four sign patterns
+	const uint32_t e = pk_add16(d02, d13), f = pk_sub16(d02, d13);
+	const uint32_t x = __builtin_amdgcn_perm(f, e, 0x05040100), y = __builtin_amdgcn_perm(f, e, 0x07060302);
+	uint32_t v[2] = { pk_add16(x, y), pk_sub16(x, y) };
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+	{
+		// column transform across the quad's four rows
+		v[k] = butterfly(v[k], ln.sign1, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[k], 0xB1, 0xf, 0xf, true));
+		v[k] = butterfly(v[k], ln.sign2, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v[k], 0x4E, 0xf, 0xf, true));
+		if (TILE == 8)
+		{
+			v[k] = butterfly(v[k], ln.sign4, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v[k], 0x101f));   // lane ^ 4
+			v[k] = butterfly(v[k], ln.sign8, (uint32_t)__builtin_amdgcn_ds_swizzle((int)v[k], 0x201f));   // lane ^ 8
+		}
+	}
+	int sum = 0;
+#pragma unroll
+	for (int k = 0; k < 2; ++k)
+	{
+		const s16x2 a = __builtin_bit_cast(s16x2, v[k]);
+		const s16x2 m = __builtin_elementwise_max(a, (s16x2)(-a));
+		sum = __builtin_amdgcn_sdot2(m, (s16x2){ 1, 1 }, sum, false);
+	}
+	uint32_t t = (uint32_t)sum;
+	t = add_dpp<0xB1>(t);
+	t = add_dpp<0x4E>(t);
+	if (TILE == 8) { t = add_dpp<0x141>(t); t = add_dpp<0x140>(t); }
+	const uint32_t cost = (t + TILE / 4) / (TILE / 2);
+	return acc + (ln.leader ? cost : 0u);
+}
+
 struct SubpelGeometry
 {
 	int W, H;
@@ -93,6 +156,8 @@ struct SubpelGeometry
 	int off_src, off_plane, off_cost;   // byte offsets inside a block's LDS
 };
 
+// METRIC 0 = SAD, 1 = Hadamard SATD over TILE x TILE tiles (TILE = 8 when both dimensions allow, else 4)
+template <int METRIC, int TILE>
 __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
@@ -167,19 +232,56 @@ __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 			uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
 			for (int it = l; it < H * w4; it += g.lpb)
 			{
-				const int y = it / w4, x = it - y * w4;
+				int y, x;
+				if (METRIC == 0)
+				{
+					y = it / w4; x = it - y * w4;
+				}
+				else if (TILE == 4)
+				{
+					// a quad of lanes = the four rows of one 4x4 tile
+					const int t = it >> 2, ty = t / w4;
+					y = 4 * ty + (it & 3); x = t - ty * w4;
+				}
+				else
+				{
+					// 16 lanes = one 8x8 tile: quad q = its 4x4 sub-block (q >> 1 down, q & 1 across)
+					const int t = it >> 4, q = (it >> 2) & 3, w8 = w4 / 2, ty = t / w8;
+					y = 8 * ty + 4 * (q >> 1) + (it & 3); x = 2 * (t - ty * w8) + (q & 1);
+				}
 				// plane columns 4x .. 4x + 11 = pixels 4x - 4 .. 4x + 7
 				const u32x2 *p = reinterpret_cast<const u32x2 *>(pl + 2 * (y * pitch + 4 * x));
 				const u32x2 a = p[0], b = p[1], c = p[2];
 				const uint32_t d[6] = { a.x, a.y, b.x, b.y, c.x, c.y };
-				const uint32_t s4 = srcT[it];
-				acc[0] = candidate_sad<-3>(d, s4, acc[0]);
-				acc[1] = candidate_sad<-2>(d, s4, acc[1]);
-				acc[2] = candidate_sad<-1>(d, s4, acc[2]);
-				acc[3] = candidate_sad<0>(d, s4, acc[3]);
-				acc[4] = candidate_sad<1>(d, s4, acc[4]);
-				acc[5] = candidate_sad<2>(d, s4, acc[5]);
-				acc[6] = candidate_sad<3>(d, s4, acc[6]);
+				const uint32_t s4 = srcT[y * w4 + x];
+				if (METRIC == 0)
+				{
+					acc[0] = candidate_sad<-3>(d, s4, acc[0]);
+					acc[1] = candidate_sad<-2>(d, s4, acc[1]);
+					acc[2] = candidate_sad<-1>(d, s4, acc[2]);
+					acc[3] = candidate_sad<0>(d, s4, acc[3]);
+					acc[4] = candidate_sad<1>(d, s4, acc[4]);
+					acc[5] = candidate_sad<2>(d, s4, acc[5]);
+					acc[6] = candidate_sad<3>(d, s4, acc[6]);
+				}
+				else
+				{
+					SatdLane ln;
+					ln.s02 = __builtin_amdgcn_perm(0, s4, 0x0c020c00);
+					ln.s13 = __builtin_amdgcn_perm(0, s4, 0x0c030c01);
+					ln.sign1 = (l & 1) ? 0xffffffffu : 0x00010001u;
+					ln.sign2 = (l & 2) ? 0xffffffffu : 0x00010001u;
+					ln.sign4 = (l & 4) ? 0xffffffffu : 0x00010001u;
+					ln.sign8 = (l & 8) ? 0xffffffffu : 0x00010001u;
+					ln.leader = (l & (TILE == 8 ? 15 : 3)) == 0;
+					acc[0] = candidate_satd<-3, TILE>(d, ln, acc[0]);
+					acc[1] = candidate_satd<-2, TILE>(d, ln, acc[1]);
+					acc[2] = candidate_satd<-1, TILE>(d, ln, acc[2]);
+					acc[3] = candidate_satd<0, TILE>(d, ln, acc[3]);
+					acc[4] = candidate_satd<1, TILE>(d, ln, acc[4]);
+					acc[5] = candidate_satd<2, TILE>(d, ln, acc[5]);
+					acc[6] = candidate_satd<3, TILE>(d, ln, acc[6]);
+				}
 			}
 #pragma unroll
 			for (int k = 0; k < 7; ++k)
@@ -197,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 	if (active && l == 0)
 	{
 		uint32_t best = 0xffffffffu;
-		for (int i = 0; i < 49; ++i) best = min(best, (cost[i] << 6) | (uint32_t)i);   // cost <= 64*64*255 < 2^20
+		for (int i = 0; i < 49; ++i) best = min(best, (cost[i] << 6) | (uint32_t)i);   // SAD <= 64*64*255 < 2^20; SATD <= 64 tiles * 2^18 = 2^24
 		const int i = (int)(best & 63);
 		result[3 * (size_t)blk + 0] = i % 7 - 3;
 		result[3 * (size_t)blk + 1] = i / 7 - 3;
@@ -217,7 +319,7 @@ extern "C" int hevcasm_hip_subpel_refine_batch(
 	if (int e = check_device()) return e;
 	const int W = (int)(rect >> 8), H = (int)(rect & 0xff);
 	if (W < 4 || W > 64 || H < 4 || H > 64 || (W & 3) || (H & 3)) return set_error(HEVCASM_HIP_EINVAL, "block size must be a multiple of 4 in 4..64");
-	if (metric != 0) return set_error(HEVCASM_HIP_EINVAL, "metric must be 0 (SAD)");
+	if (metric != 0 && metric != 1) return set_error(HEVCASM_HIP_EINVAL, "metric must be 0 (SAD) or 1 (Hadamard SATD)");
 	if (n_blocks == 0) return 0;
 	if (n_blocks > 0x7fffffffull / 3) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
@@ -236,7 +338,12 @@ extern "C" int hevcasm_hip_subpel_refine_batch(
 	const size_t shmem = (size_t)g.blk_bytes * g.bpw;
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "block does not fit in 64 KiB of LDS");
 	const uint32_t grid = ceil_div(n_blocks, g.bpw);
-	hipLaunchKernelGGL(subpel_refine_kernel, dim3(grid), dim3(kThreads), shmem, as_stream(stream),
-			src, stride_src, ref, stride_ref, src_off, ref_off, result, g, (uint32_t)n_blocks);
+	hipStream_t st = as_stream(stream);
+	if (metric == 0)
+		hipLaunchKernelGGL((subpel_refine_kernel<0, 4>), dim3(grid), dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, g, (uint32_t)n_blocks);
+	else if (W % 8 == 0 && H % 8 == 0)
+		hipLaunchKernelGGL((subpel_refine_kernel<1, 8>), dim3(grid), dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, g, (uint32_t)n_blocks);
+	else
+		hipLaunchKernelGGL((subpel_refine_kernel<1, 4>), dim3(grid), dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, g, (uint32_t)n_blocks);
 	return launch_status("subpel_refine_kernel");
 }

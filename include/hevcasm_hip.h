@@ -193,7 +193,9 @@ int hevcasm_hip_me_full_search_batch(
  * 8-tap filter (reference pred_inter.h:56) at integer offset (qx >> 2, qy >> 2) and fraction
  * (qx & 3, qy & 3); cost = hevcasm_sad (reference sad.h:50) of it against src + src_off[i].
  * result[3i..3i+2] = { qx, qy, cost } of the minimum, ties resolved to the first candidate in
- * raster order of (qy, qx).  The candidates are never written to memory.  metric: 0 = SAD.
+ * raster order of (qy, qx).  The candidates are never written to memory.  metric: 0 = SAD;
+ * 1 = hevcasm_hadamard_satd (reference hadamard.h:53) summed over the block's 8x8 tiles, or over its 4x4
+ * tiles when a dimension is not a multiple of 8.
  * The reference plane must be readable 4 pixels around each block (the filter margins). */
 int hevcasm_hip_subpel_refine_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,

@@ -539,8 +539,21 @@ void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t 
 	}
 }
 
+/* cost of a candidate block against the source: metric 0 = SAD (sad.c:47-60); metric 1 = Hadamard SATD
+ * (hadamard.c:76-111) summed over 8x8 tiles when both dimensions are multiples of 8, else over 4x4 tiles */
+static int block_cost(int metric, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *cand, ptrdiff_t stride_cand, int w, int h)
+{
+	if (metric == 0) return orc_sad(src, stride_src, cand, stride_cand, ((uint32_t)w << 8) | (uint32_t)h);
+	const int n = (w % 8 == 0 && h % 8 == 0) ? 8 : 4;
+	int total = 0;
+	for (int y = 0; y < h; y += n)
+		for (int x = 0; x < w; x += n)
+			total += orc_hadamard_satd(n, src + y * stride_src + x, stride_src, cand + y * stride_cand + x, stride_cand);
+	return total;
+}
+
 void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
-		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, size_t n)
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, int metric, size_t n)
 {
 	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
 #pragma omp parallel for schedule(dynamic, 1)
@@ -553,7 +566,7 @@ void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *
 			{
 				const uint8_t *origin = ref + (ptrdiff_t)ref_off[i] + (qy >> 2) * stride_ref + (qx >> 2);
 				orc_pred_uni_8to8(8, cand, 64, origin, stride_ref, w, h, qx & 3, qy & 3);
-				const int c = orc_sad(src + src_off[i], stride_src, cand, 64, rect);
+				const int c = block_cost(metric, src + src_off[i], stride_src, cand, 64, w, h);
 				if (c < best) { best = c; bx = qx; by = qy; }
 			}
 		out3[3 * i + 0] = bx; out3[3 * i + 1] = by; out3[3 * i + 2] = best;

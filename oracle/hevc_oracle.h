@@ -104,10 +104,12 @@ void orc_me_full_search(const uint8_t *src, ptrdiff_t stride_src, const uint8_t 
 /* Quarter-pel refinement: a composition of the luma interpolation
  * (pred_inter.h:56, bodies pred_inter.c:141-228) and SAD (sad.c:47-60).  For each block, every
  * quarter-pel displacement (qx,qy) in [-3,3]^2 around ref_off is predicted with the 8-tap filter at
- * integer offset (qx >> 2, qy >> 2), fraction (qx & 3, qy & 3), and costed against src.
+ * integer offset (qx >> 2, qy >> 2), fraction (qx & 3, qy & 3), and costed against src: metric 0 = SAD,
+ * metric 1 = Hadamard SATD (hadamard.c:76-111) summed over 8x8 tiles (4x4 tiles unless both dimensions are
+ * multiples of 8).
  * out[3*i] = qx, qy, cost of the minimum; ties go to the first in raster order of (qy,qx). */
 void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
-		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, size_t n);
+		const uint32_t *src_off, const uint32_t *ref_off, int *out3, uint32_t rect, int metric, size_t n);
 
 /* pred_intra.h:55; INTRA_DC body pred_intra.c:61-101 (sample addressing pred_intra.c:52-58) */
 void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed);

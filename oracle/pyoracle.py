@@ -175,12 +175,12 @@ def me_full_search(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, sea
     return out
 
 
-def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h):
+def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0):
     src, ref, src_off, ref_off = _u8(src), _u8(ref), _u32(src_off), _u32(ref_off)
     n = src_off.size
     out = np.empty((n, 3), dtype=np.int32)
     lib().orc_subpel_refine(_p(src), C.c_ssize_t(stride_src), _p(ref), C.c_ssize_t(stride_ref),
-                            _p(src_off), _p(ref_off), _p(out), C.c_uint32(rect(w, h)), C.c_size_t(n))
+                            _p(src_off), _p(ref_off), _p(out), C.c_uint32(rect(w, h)), C.c_int(metric), C.c_size_t(n))
     return out
 
 

@@ -139,8 +139,8 @@ class RefProc:
                       [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
         return np.frombuffer(o[0], dtype=np.int32).reshape(-1, 3).copy()
 
-    def subpel_refine(self, src, stride_src, ref, stride_ref, src_off, ref_off, w, h):
-        o = self.call(OP_SUBPEL, [stride_src, stride_ref, (w << 8) | h, len(src_off)],
+    def subpel_refine(self, src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0):
+        o = self.call(OP_SUBPEL, [stride_src, stride_ref, (w << 8) | h, len(src_off), metric],
                       [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
         return np.frombuffer(o[0], dtype=np.int32).reshape(-1, 3).copy()
 

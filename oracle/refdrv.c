@@ -281,7 +281,7 @@ int main(void)
 			out[0].p = (uint8_t *)r; out[0].bytes = 12 * n; nout = 1;
 			break;
 		}
-		case OP_SUBPEL: /* par: stride_src, stride_ref, rect, n; bufs src, ref, src_off, ref_off -> int[3n] (qx, qy, cost).
+		case OP_SUBPEL: /* par: stride_src, stride_ref, rect, n, metric; bufs src, ref, src_off, ref_off -> int[3n] (qx, qy, cost).
 		                   The reference's own luma interpolation and SAD, composed per quarter-pel candidate. */
 		{
 			const size_t n = (size_t)par[3];
@@ -299,7 +299,16 @@ int main(void)
 						const int xf = qx & 3, yf = qy & 3;
 						hevcasm_pred_uni_8to8 *f = *hevcasm_get_pred_uni_8to8(&t_uni, 8, w, h, xf, yf);
 						f(cand, 64, in[1].p + (ptrdiff_t)ro[i] + (qy >> 2) * par[1] + (qx >> 2), par[1], w, h, xf, yf);
-						const int c = sad(in[0].p + so[i], par[0], cand, 64, (uint32_t)par[2]);
+						int c = 0;
+						if (par[4] == 0) c = sad(in[0].p + so[i], par[0], cand, 64, (uint32_t)par[2]);
+						else
+						{
+							const int tn = (w % 8 == 0 && h % 8 == 0) ? 8 : 4;
+							hevcasm_hadamard_satd *satd = *hevcasm_get_hadamard_satd(&t_satd, tn == 8 ? 3 : 2);
+							for (int y = 0; y < h; y += tn)
+								for (int x = 0; x < w; x += tn)
+									c += satd(in[0].p + so[i] + y * par[0] + x, par[0], cand + y * 64 + x, 64);
+						}
 						if (c < best) { best = c; bx = qx; by = qy; }
 					}
 				r[3 * i] = bx; r[3 * i + 1] = by; r[3 * i + 2] = best;

@@ -229,6 +229,14 @@ def subpel_cases(seed=1000):
     c["ref"][:] = np.where(c["ref"] & 1, 255, 0)
     c["src"][:] = np.where(c["src"] & 2, 255, 0)
     out.append(("subpel_extremes", "subpel", c))
+    # Hadamard SATD as the cost (8x8 tiles, or 4x4 tiles when a dimension is not a multiple of 8)
+    for (w, h, n) in ((8, 8, 7), (16, 16, 5), (8, 4, 5), (4, 8, 5), (12, 16, 3), (16, 4, 3), (32, 32, 2), (64, 64, 2), (24, 32, 2), (64, 16, 2), (4, 4, 9)):
+        out.append(("subpel_satd_%dx%d" % (w, h), "subpel", _subpel_case(w, h, n, seed + 50 + w + h, "noise") | dict(metric=1)))
+    out.append(("subpel_satd_smooth_16x16", "subpel", _subpel_case(16, 16, 6, seed + 61, "smooth") | dict(metric=1)))
+    c = _subpel_case(16, 8, 4, seed + 62, "noise") | dict(metric=1)
+    c["ref"][:] = np.where(c["ref"] & 1, 255, 0)
+    c["src"][:] = np.where(c["src"] & 2, 255, 0)
+    out.append(("subpel_satd_extremes", "subpel", c))
     return out
 
 
@@ -347,7 +355,7 @@ def _run_cpu(api, family, c):
     if family == "me":
         return (api.me_full_search(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"], c["range"]),)
     if family == "subpel":
-        return (api.subpel_refine(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"]),)
+        return (api.subpel_refine(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], c["w"], c["h"], c.get("metric", 0)),)
     if family == "intra":
         return (api.pred_intra_batch(c["neighbours"], c["neighbour_stride"], c["mode"], c["packed"], c["n"]),)
     if family == "ssd_linear":
@@ -414,7 +422,7 @@ def run_hip(family, c):
     if family == "me":
         return (cpu(B.me_full_search(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"], c["range"])),)
     if family == "subpel":
-        return (cpu(B.subpel_refine(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"])),)
+        return (cpu(B.subpel_refine(u8(c["src"]), c["stride_src"], u8(c["ref"]), c["stride_ref"], off(c["src_off"]), off(c["ref_off"]), c["w"], c["h"], c.get("metric", 0))),)
     if family == "intra":
         size = 1 << ((c["packed"] >> 1) & 0x7f)
         return (cpu(B.pred_intra(plane(c["n"] * size * size), u8(c["neighbours"]), c["neighbour_stride"], c["mode"], c["packed"], c["n"])),)

@@ -196,6 +196,9 @@ def bench_subpel():
         report("subpel_refine", n, (w + 8) * (h + 8) + w * h + 8 + 12, ms, size="%dx%d" % (w, h),
                candidates_per_s_g=round(49 * n / ms / 1e6, 2), unfused_ms=round(ms_unfused, 3), fused_speedup=round(ms_unfused / ms, 2),
                frames_per_s=round(1e3 / ms, 1))
+        ms_satd = timed(lambda i: B.subpel_refine(src, fw, ref, stride_r, so_d, ro_d, w, h, metric=1, out=out), reps=5)
+        report("subpel_refine_satd", n, (w + 8) * (h + 8) + w * h + 8 + 12, ms_satd, size="%dx%d" % (w, h),
+               candidates_per_s_g=round(49 * n / ms_satd / 1e6, 2), frames_per_s=round(1e3 / ms_satd, 1))
 
 
 if __name__ == "__main__":
