@@ -214,6 +214,49 @@ def test_sad_misaligned_plane_base():
             assert np.array_equal(got1, want1), (w, h, k)
 
 
+def test_concurrent_host_threads_and_streams():
+    """hevcasm_hip.h promises that the entry points may be called from several host threads at once (one
+    stream per thread): four threads, each on its own stream, each a different family, many rounds."""
+    import threading
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    c_sad = wl.sad_case(16, 16, 4000, 801, ways=4)
+    c_inv = wl.inverse_case(0, 4, 500, 802, "natural")
+    c_pred = wl.pred_case(8, 16, 16, 400, 803)
+    want = dict(
+        sad4=pyoracle.sad_multiref_batch(c_sad["src"], c_sad["stride_src"], c_sad["ref"], c_sad["stride_ref"], c_sad["src_off"], c_sad["ref_off"], 16, 16),
+        inv=cases.run_oracle("inverse", c_inv)[0], pred=cases.run_oracle("pred_uni", c_pred)[0],
+        sub=cases.run_oracle("subpel", [x for x in cases.subpel_cases() if x[0] == "subpel_16x16"][0][2])[0])
+    errors = []
+
+    def worker(kind):
+        try:
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for _ in range(20):
+                    if kind == "sad4":
+                        got = cases.run_hip("sad4", c_sad)[0]
+                    elif kind == "inv":
+                        got = cases.run_hip("inverse", c_inv)[0]
+                    elif kind == "pred":
+                        got = cases.run_hip("pred_uni", c_pred)[0]
+                    else:
+                        got = cases.run_hip("subpel", [x for x in cases.subpel_cases() if x[0] == "subpel_16x16"][0][2])[0]
+                    if not np.array_equal(np.asarray(got).reshape(-1), np.asarray(want[kind]).reshape(-1)):
+                        errors.append(kind)
+                        return
+        except Exception as e:   # noqa: BLE001 -- reported through the list
+            errors.append("%s: %r" % (kind, e))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in ("sad4", "inv", "pred", "sub")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch
