@@ -6,7 +6,7 @@
 #include <cstdint>
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 #define ITER 2048
-enum { MAD24, MUL24, ADD3, DOT2, PKMAD, PERM, DPP, SAD, DOT4, MULLO, ALIGNBIT, MED3 };
+enum { MAD24, MUL24, ADD3, DOT2, PKMAD, PERM, DPP, SAD, DOT4, MULLO, ALIGNBIT, MED3, QSAD, SWIZZLE };
 
 template <int OP> __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed, unsigned long long *cycles)
 {
@@ -32,6 +32,8 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t *out, uint32
 			else if (OP == MULLO) a[i] = a[i] * y;
 			else if (OP == ALIGNBIT) a[i] = __builtin_amdgcn_alignbit(a[i], x, 16);
 			else if (OP == MED3) a[i] = (uint32_t)min(max((int)a[i], (int)x), (int)y);
+			else if (OP == QSAD) { unsigned long long r = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)y << 32) | x, x, ((unsigned long long)a[(i + 1) & 15] << 32) | a[i]); a[i] = (uint32_t)r ^ (uint32_t)(r >> 32); }
+			else if (OP == SWIZZLE) a[i] = (uint32_t)__builtin_amdgcn_ds_swizzle((int)a[i], 0x101f);
 		}
 	}
 	const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -64,6 +66,6 @@ template <int OP> void run(const char *name)
 int main()
 {
 	run<MAD24>("mad_i24"); run<MUL24>("mul_i24"); run<ADD3>("add3"); run<DOT2>("dot2_i16"); run<PKMAD>("pk_mad_u16");
-	run<PERM>("perm"); run<DPP>("dpp wave_shl"); run<SAD>("sad_u8"); run<DOT4>("dot4_u8"); run<MULLO>("mul_lo_u32"); run<ALIGNBIT>("alignbit"); run<MED3>("min/max");
+	run<PERM>("perm"); run<DPP>("dpp wave_shl"); run<SAD>("sad_u8"); run<DOT4>("dot4_u8"); run<MULLO>("mul_lo_u32"); run<ALIGNBIT>("alignbit"); run<MED3>("min/max"); run<QSAD>("qsad_pk_u16_u8"); run<SWIZZLE>("ds_swizzle");
 	return 0;
 }
