@@ -126,6 +126,36 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	o.store(rec + rec_off[blk] + y * stride_rec + x);
 }
 
+// 4x4 blocks: one lane per block (32 bytes of residual in two 16-byte loads, four row dwords in and
+// out); with one lane per ROW the address unit spent a full wave-instruction on 4 bytes per lane.
+__global__ __launch_bounds__(kThreads) void reconstruct4_lane_kernel(
+	uint8_t *__restrict__ rec, ptrdiff_t stride_rec, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ res, uint32_t n_blocks)
+{
+	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
+	if (blk >= n_blocks) return;
+	Chunk<16> r0, r1;
+	const uint8_t *rp = reinterpret_cast<const uint8_t *>(res + (size_t)blk * 16);
+	r0.load(rp);
+	r1.load(rp + 16);
+	const uint32_t r[8] = { r0.d[0], r0.d[1], r0.d[2], r0.d[3], r1.d[0], r1.d[1], r1.d[2], r1.d[3] };
+	const uint8_t *pp = pred + pred_off[blk];
+	uint8_t *out = rec + rec_off[blk];
+	uint32_t pd[4];
+#pragma unroll
+	for (int y = 0; y < 4; ++y) pd[y] = reinterpret_cast<const U1 *>(pp + y * stride_pred)->v;
+#pragma unroll
+	for (int y = 0; y < 4; ++y)
+	{
+		const int v0 = (int)(pd[y] & 0xff) + sext_lo(r[2 * y]), v1 = (int)((pd[y] >> 8) & 0xff) + sext_hi(r[2 * y]);
+		const int v2 = (int)((pd[y] >> 16) & 0xff) + sext_lo(r[2 * y + 1]), v3 = (int)(pd[y] >> 24) + sext_hi(r[2 * y + 1]);
+		const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(v0, v1, 0);   // saturates to [0, 255]: the clip of quantize.c:299
+		const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(v2, v3, 0);
+		reinterpret_cast<U1 *>(out + y * stride_rec)->v = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+	}
+}
+
 }  // namespace hevc
 
 using namespace hevc;
@@ -183,9 +213,13 @@ extern "C" int hevcasm_hip_quantize_reconstruct_batch(uint8_t *rec, ptrdiff_t st
 		const uint32_t grid = ceil_div(n_blocks, kThreads / lpb); \
 		hipLaunchKernelGGL((reconstruct_kernel<N>), dim3(grid), dim3(kThreads), 0, st, rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, (uint32_t)n_blocks); \
 		return launch_status("reconstruct_kernel"); }
+	if (nCbS == 4)
+	{
+		hipLaunchKernelGGL(reconstruct4_lane_kernel, dim3(ceil_div(n_blocks, kThreads)), dim3(kThreads), 0, st, rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, (uint32_t)n_blocks);
+		return launch_status("reconstruct4_lane_kernel");
+	}
 	switch (nCbS)
 	{
-	case 4: LAUNCH(4)
 	case 8: LAUNCH(8)
 	case 16: LAUNCH(16)
 	case 32: LAUNCH(32)
