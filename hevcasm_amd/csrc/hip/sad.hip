@@ -209,7 +209,11 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// buffers trip by trip 1.94, slot by slot 2.11; this form 1.81.  Memory-level parallelism per
 	// wave outweighs the occupancy lost to the second register set.
 	const int trips = LOOP ? H / (R * U) : 1;
-	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;   // 8-byte chunks were measured too: slower (half the lanes issue the tail load)
+	// (the vector L1 splits a load that is not dword-aligned into dwords -- profiles/r01_tcp_access_model.txt -- so the
+	// aligned form quarters the accesses of a 64-byte row; it pays for the 4-way kernel, which is bound by that rate.
+	// For one reference it was measured slower: 64x64 1.48 against 1.38 ms, 32x32 0.42 against 0.37 -- HBM-bound, and the
+	// extra tail loads and funnel shifts are pure cost.  8-byte chunks: slower too, half the lanes issue the tail load.)
+	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
 	Chunk<C> s[U];
