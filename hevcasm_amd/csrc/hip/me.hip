@@ -23,11 +23,16 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, int n_groups)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-	__shared__ unsigned long long best_of_wave[kThreads / kWave];
 
 	const uint32_t blk = blockIdx.x;
-	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds);                 // H rows of W / 4 dwords
-	uint8_t *s_win = lds + ((W * H + 15) & ~15);                           // (H + 2R) rows of win_stride bytes
+	// Window first, source tile behind it.  Rows are exactly as wide as the window (rounded to 16): the last
+	// dx group reads up to 16 * n_groups + W + 4 bytes of a row, i.e. into the next row -- and from the last
+	// row into the source tile -- but only for candidates past the window, which are never scored.  For 64x64
+	// blocks and +-64 that makes 36 864 + 4 096 = 40 960 bytes: FOUR workgroups per CU (160 KiB), and a 4K
+	// frame's 2040 CTUs are then two full rounds of 1024 instead of three of 768.
+	uint8_t *s_win = lds;                                                  // (H + 2R) rows of win_stride bytes
+	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds + (size_t)win_stride * (H + 2 * R));   // H rows of W / 4 dwords
+	unsigned long long *best_of_wave = reinterpret_cast<unsigned long long *>(lds);          // reused after the search
 	const int wd = W / 4;
 	const int win_w = W + 2 * R, win_h = H + 2 * R;
 
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		const int y = i / wd, x = i - y * wd;
 		s_src[i] = reinterpret_cast<const U1 *>(sp + (ptrdiff_t)y * stride_src + 4 * x)->v;
 	}
-	// window rows, zero-padded to win_stride so that the last dx group may read past the real window
+	// window rows, zero-padded to win_stride
 	const uint8_t *rp = ref + ref_off[blk] - (ptrdiff_t)R * stride_ref - R;
 	const int row_dwords = win_stride / 4;
 	for (int i = threadIdx.x; i < row_dwords * win_h; i += kThreads)
@@ -126,6 +131,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		const unsigned long long o = __shfl_xor(best, d, kWave);
 		best = o < best ? o : best;
 	}
+	__syncthreads();   // every wave is done reading the window: its first bytes become the per-wave results
 	if ((threadIdx.x & 63) == 0) best_of_wave[threadIdx.x >> 6] = best;
 	__syncthreads();
 	if (threadIdx.x == 0)
@@ -154,10 +160,12 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (n_blocks == 0) return 0;
 	if (n_blocks > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	// dx groups of 16; a group reads W + 16 (+16 of look-ahead) window bytes starting at 16 * g
+	// dx groups of 16; a group reads up to W + 20 window bytes starting at 16 * g (see the kernel's layout note)
 	const int n_groups = (2 * range + 1 + 15) / 16;
-	const int win_stride = (16 * n_groups + W + 32 + 15) & ~15;
-	const size_t shmem = (((size_t)W * H + 15) & ~(size_t)15) + (size_t)win_stride * (H + 2 * range);
+	const int win_stride = (W + 2 * range + 15) & ~15;
+	const int overread = 16 * n_groups + W + 4 - win_stride;         // bytes the last window row is read past its end
+	const int tail = W * H > overread ? W * H : overread;            // the source tile absorbs them
+	const size_t shmem = (size_t)win_stride * (H + 2 * range) + (size_t)((tail + 15) & ~15);
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
 	hipLaunchKernelGGL(me_full_search_kernel, dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
 			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups);

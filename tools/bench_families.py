@@ -121,6 +121,27 @@ def bench_me():
         report("me_full_search", so.size, w * h + (w + 2 * r) * (h + 2 * r) + 8 + 12, ms, size="%dx%d +-%d" % (w, h, r), gsad_evals_per_s=round(so.size * (2 * r + 1) ** 2 / ms / 1e6, 2))
     print(json.dumps(dict(kernel="me_full_search frame total", ms=round(total_ms, 3), ctus=total_blocks, frames_per_s=round(1e3 / total_ms, 1),
                           gsad_evals_per_s=round(total_sads / total_ms / 1e6, 2))), flush=True)
+    # the 64x48 bottom row is an independent call: issue it on a second stream so that it fills the main launch's tail
+    parts = []
+    for (w, h, y0, rows) in ((64, 64, 0, 33), (64, 48, 33 * 64, 1)):
+        by, bx = np.meshgrid(np.arange(rows), np.arange(fw // w), indexing="ij")
+        so = ((y0 + by * h) * stride_s + bx * w).reshape(-1).astype(np.uint32)
+        ro = ((y0 + by * h + r) * stride_r + bx * w + r).reshape(-1).astype(np.uint32)
+        parts.append((w, h, B.off32(so), B.off32(ro), torch.empty((so.size, 3), dtype=torch.int32, device="cuda")))
+    side = torch.cuda.Stream()
+
+    def frame(i):
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            w, h, so_d, ro_d, out = parts[1]
+            B.me_full_search(src, stride_s, ref, stride_r, so_d, ro_d, w, h, r, out=out)
+        w, h, so_d, ro_d, out = parts[0]
+        B.me_full_search(src, stride_s, ref, stride_r, so_d, ro_d, w, h, r, out=out)
+        main.wait_stream(side)
+    ms2 = timed(frame, reps=3)
+    print(json.dumps(dict(kernel="me_full_search frame total, bottom row on a second stream", ms=round(ms2, 3), ctus=total_blocks,
+                          frames_per_s=round(1e3 / ms2, 1), gsad_evals_per_s=round(total_sads / ms2 / 1e6, 2))), flush=True)
 
 
 def bench_satd():
