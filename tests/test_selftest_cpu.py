@@ -57,6 +57,26 @@ def test_same_rows_as_the_reference_selftest(tmp_path, refproc):
     assert ref_rows == ours
 
 
+def test_same_row_labels_as_the_reference_for_the_quick_families(tmp_path, refproc):
+    """Row labels (the text before the first column) of our self-tests equal the reference's own, family by
+    family, for the families whose reference self-test runs in seconds on the C path."""
+    path = str(tmp_path / "ref_selftest_more.txt")
+    mask = 4 | 1024 | 128 | 256 | 512 | 2048 | 4096   # ssd, hadamard_satd, quantize_inverse, quantize, quantize_reconstruct, pred_intra, ssd_linear
+    assert refproc.selftest(mask, path) == 0
+
+    def labels(text):
+        out = []
+        for line in text.splitlines():
+            if line.startswith("\t"):
+                out.append(re.split(r"\s*C_OPT:", line.strip())[0].rstrip(" :"))
+        return out
+    ours = _run(["ssd", "pred_intra", "hadamard_satd", "quantize_inverse", "quantize", "quantize_reconstruct", "ssd_linear"])
+    ref_rows, our_rows = labels(open(path).read()), labels(ours)
+    # the reference tests the unfiltered intra packing only; ours adds the three edge-filtered rows
+    our_rows = [r for r in our_rows if not r.endswith("edge")]
+    assert sorted(ref_rows) == sorted(our_rows), (ref_rows, our_rows)
+
+
 def test_executable_reports_instruction_sets():
     exe = os.path.join(ROOT, "hevcasm_amd", "lib", "hevcasm")
     assert os.path.exists(exe)
