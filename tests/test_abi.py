@@ -151,3 +151,31 @@ def test_product_never_touches_the_oracle():
     assert not bad, bad
     deps = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in deps
+
+
+def _build_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "batch_sad")
+    libdir = os.path.join(ROOT, "hevcasm_amd", "lib")
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "batch_sad.c"),
+                    "-L" + libdir, "-lhevcasm_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    return exe
+
+
+def test_c_example_compiles_against_the_headers_and_refuses_without_a_gpu(tmp_path):
+    """examples/batch_sad.c is plain C against include/*.h and the shared library: the boundary really is a C
+    ABI.  Without a gfx950 device the batched path must refuse (exit status 77), never compute on the CPU."""
+    import subprocess
+    import torch
+    exe = _build_example(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    assert subprocess.run([exe], capture_output=True).returncode == 77
+
+
+@pytest.mark.gpu
+def test_c_example_per_block_table_equals_batch_call(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_example(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 differ" in r.stdout
