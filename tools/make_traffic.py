@@ -10,7 +10,7 @@ import csv, glob, json, os, re, sys
 
 prof = sys.argv[1]
 out = {}
-for size in ("64x64", "16x16"):
+for size in ("64x64", "16x16", "64x48", "48x64"):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for p in glob.glob(os.path.join(prof, "pmc_%s_%s" % (size, counter), "*", "*_counter_collection.csv")):
