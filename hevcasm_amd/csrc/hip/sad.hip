@@ -324,6 +324,7 @@ template <int W, int C, int R, int WAYS, int OP> static int launch_rows(const Ar
 {
 	const int rows_per_lane = a.H / R;
 	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP>(a);
+	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP>(a);   // heights 12, 24, 48
 	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP>(a);
 	return launch_cfg<W, C, R, 1, WAYS, OP>(a);
 }
