@@ -27,6 +27,7 @@ __global__ __launch_bounds__(kThreads) void quantize_inverse_kernel(
 	int16_t *__restrict__ dst, const int16_t *__restrict__ src, int scale, int shift, size_t n)
 {
 	const int round = 1 << (shift - 1);
+	scale = (scale << 8) >> 8;   // |scale| < 2^15 (entry point): 24-bit operands let the multiply be a full-rate v_mad_i32_i24
 	const size_t n8 = n / 8;
 	const size_t step = (size_t)gridDim.x * kThreads;
 	for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < n8; i += step)
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(kThreads) void quantize_kernel(
 	constexpr int LPB = NPB / 8 < kWave ? NPB / 8 : kWave;  // lanes per block
 	constexpr int TRIPS = NPB / (8 * LPB);
 	const int round = offset << (shift - 16);
+	scale = (scale << 8) >> 8;   // 0 <= scale < 2^15 (entry point): v_mad_u32_u24 instead of v_mul_lo_u32
 
 	const size_t lane_global = (size_t)blockIdx.x * kThreads + threadIdx.x;
 	size_t blk = lane_global / LPB;
@@ -164,6 +166,7 @@ extern "C" int hevcasm_hip_quantize_inverse(int16_t *dst, const int16_t *src, in
 {
 	if (int e = check_device()) return e;
 	if (shift < 1 || shift > 31) return set_error(HEVCASM_HIP_EINVAL, "shift out of range");
+	if (scale < -32768 || scale > 32767) return set_error(HEVCASM_HIP_EINVAL, "scale must fit int16 (the reference's SIMD path multiplies with pmaddwd, quantize_a.asm:53-109)");
 	if (n == 0) return 0;
 	if (!dst || !src) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	// memory-bound: cap the grid at 8 workgroups per CU and grid-stride the rest

@@ -302,15 +302,31 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	global_row_load<N>(coeffs + (size_t)blk * (N * N) + t * N, v);
 	if (DEQUANT)
 	{
-		const int round = 1 << (shift - 1);
+		// quantize.c:53-62.  scale < 2^15 (checked by the entry point) and the levels are int16: telling the
+		// compiler so turns a quarter-rate v_mul_lo_u32 per coefficient into a full-rate v_mad_i32_i24
+		const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;
 #pragma unroll
-		for (int k = 0; k < N; ++k) v[k] = clip3(-32768, 32767, (v[k] * scale + round) >> shift);  // quantize.c:53-62
+		for (int k = 0; k < N; ++k) v[k] = (v[k] * scale24 + round) >> shift;   // the clip to int16 is the saturating pack below
 	}
 	{
 		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
 		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
+		if (DEQUANT)
+		{
+			typedef short s16x2v __attribute__((ext_vector_type(2)));
 #pragma unroll
-		for (int x = 0; x < N; ++x) row[2 * x] = (int16_t)v[x];
+			for (int x = 0; x < N; x += 2)
+			{
+				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(v[x], v[x + 1]));   // v_cvt_pk_i16_i32 saturates
+				row[2 * x] = (int16_t)two;                 // ds_write_b16
+				row[2 * x + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
+			}
+		}
+		else
+		{
+#pragma unroll
+			for (int x = 0; x < N; ++x) row[2 * x] = (int16_t)v[x];
+		}
 	}
 	__syncthreads();
 
@@ -420,12 +436,12 @@ __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 	}
 	if (DEQUANT)
 	{
-		const int round = 1 << (shift - 1);
+		const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;   // 24-bit operands: v_mad_i32_i24, not v_mul_lo_u32
 #pragma unroll
 		for (int i = 0; i < N * RD; ++i)
 		{
-			const int lo = ((int)(short)(r[i] & 0xffff) * scale + round) >> shift;   // quantize.c:53-62;
-			const int hi = (((int)r[i] >> 16) * scale + round) >> shift;             // v_cvt_pk_i16_i32 is the clip
+			const int lo = ((int)(short)(r[i] & 0xffff) * scale24 + round) >> shift;   // quantize.c:53-62;
+			const int hi = (((int)r[i] >> 16) * scale24 + round) >> shift;             // v_cvt_pk_i16_i32 is the clip
 			r[i] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo, hi));
 		}
 	}
@@ -738,6 +754,7 @@ static int inverse_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdif
 	if (int e = check_device()) return e;
 	if (log2n < 2 || log2n > 5 || (trType && log2n != 2)) return set_error(HEVCASM_HIP_EINVAL, "transform size/type not supported by the reference");
 	if (DEQUANT && (shift < 1 || shift > 31)) return set_error(HEVCASM_HIP_EINVAL, "shift out of range");
+	if (DEQUANT && (scale < -32768 || scale > 32767)) return set_error(HEVCASM_HIP_EINVAL, "scale must fit int16 (the reference's SIMD path multiplies with pmaddwd, quantize_a.asm:53-109)");
 	if (n == 0) return 0;
 	if (n > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!dst || !pred || !dof || !pof || !c) return set_error(HEVCASM_HIP_EINVAL, "null pointer");

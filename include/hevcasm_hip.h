@@ -159,7 +159,8 @@ int hevcasm_hip_transform_batch(
 /* ---- quantisation ----------------------------------------------------------------------- */
 
 /* hevcasm_quantize_inverse over n coefficients (reference quantize.h:57; quantize.c:53-62).
- * Already a flat array operation: a batch of blocks is one call with n = blocks * N * N. */
+ * Already a flat array operation: a batch of blocks is one call with n = blocks * N * N.
+ * scale must fit int16 (as the reference's SIMD path requires), shift in 1..31. */
 int hevcasm_hip_quantize_inverse(
 	int16_t *dst, const int16_t *src, int scale, int shift, size_t n, void *stream);
 
