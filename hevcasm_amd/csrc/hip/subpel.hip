@@ -146,6 +146,20 @@ template <int QX, int TILE> __device__ __forceinline__ uint32_t candidate_satd(c
 	return acc + (ln.leader ? cost : 0u);
 }
 
+// (row, column) of item `it` in a grid `w` items wide, walked with a fixed stride: one division when the
+// walk starts, additions afterwards (an integer division per item is a dozen quarter-rate instructions --
+// a fifth of an item's work in the H pass)
+struct Walk
+{
+	int y, x, dy, dx, w;
+	__device__ __forceinline__ Walk(int first, int stride, int width) : y(first / width), x(first % width), dy(stride / width), dx(stride % width), w(width) {}
+	__device__ __forceinline__ void next()
+	{
+		y += dy; x += dx;
+		if (x >= w) { x -= w; ++y; }
+	}
+};
+
 struct SubpelGeometry
 {
 	int W, H;
@@ -209,9 +223,10 @@ __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 			uint32_t cv[8];
 #pragma unroll
 			for (int t = 0; t < 8; ++t) cv[t] = kLumaPairs.v[qy & 3][t];
-			for (int it = l; it < H * wd; it += g.lpb)
+			Walk vw(l, g.lpb, wd);
+			for (int it = l; it < H * wd; it += g.lpb, vw.next())
 			{
-				const int y = it / wd, x = it - y * wd;
+				const int y = vw.y, x = vw.x;
 				uint32_t even = 0, odd = 0;           // (v0, v2), (v1, v3)
 #pragma unroll
 				for (int t = 0; t < 8; ++t)
@@ -230,24 +245,27 @@ __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 		if (active)
 		{
 			uint32_t acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
-			for (int it = l; it < H * w4; it += g.lpb)
+			// METRIC 0: item = (row, dword column).  SATD: item = (tile, lane in tile); tiles are walked, the
+			// lane's place inside its tile is fixed (lpb is a multiple of the tile's lanes)
+			constexpr int TL = METRIC == 0 ? 1 : TILE == 4 ? 4 : 16;      // lanes per tile
+			Walk hw(l / TL, g.lpb / TL, METRIC == 0 ? w4 : TILE == 4 ? w4 : w4 / 2);
+			for (int it = l; it < H * w4; it += g.lpb, hw.next())
 			{
 				int y, x;
 				if (METRIC == 0)
 				{
-					y = it / w4; x = it - y * w4;
+					y = hw.y; x = hw.x;
 				}
 				else if (TILE == 4)
 				{
 					// a quad of lanes = the four rows of one 4x4 tile
-					const int t = it >> 2, ty = t / w4;
-					y = 4 * ty + (it & 3); x = t - ty * w4;
+					y = 4 * hw.y + (l & 3); x = hw.x;
 				}
 				else
 				{
 					// 16 lanes = one 8x8 tile: quad q = its 4x4 sub-block (q >> 1 down, q & 1 across)
-					const int t = it >> 4, q = (it >> 2) & 3, w8 = w4 / 2, ty = t / w8;
-					y = 8 * ty + 4 * (q >> 1) + (it & 3); x = 2 * (t - ty * w8) + (q & 1);
+					const int q = (l >> 2) & 3;
+					y = 8 * hw.y + 4 * (q >> 1) + (l & 3); x = 2 * hw.x + (q & 1);
 				}
 				// plane columns 4x .. 4x + 11 = pixels 4x - 4 .. 4x + 7
 				const u32x2 *p = reinterpret_cast<const u32x2 *>(pl + 2 * (y * pitch + 4 * x));
