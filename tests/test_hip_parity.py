@@ -214,6 +214,48 @@ def test_sad_misaligned_plane_base():
             assert np.array_equal(got1, want1), (w, h, k)
 
 
+def test_sad_offsets_at_the_top_of_the_4gib_window():
+    """The SAD kernels address with base + 32-bit offset: blocks whose bytes end just below 4 GiB - 64 must come out
+    right (no wrap), both planes, 1-way and 4-way, negative stride included."""
+    import torch
+    from oracle import pyoracle
+    from hevcasm_amd import batch as B
+    size = (1 << 32) - 64
+    tail = 1 << 20                                   # the last MiB of each plane carries the data
+    rng = np.random.default_rng(77)
+    src_t, ref_t = rng.integers(0, 256, tail, dtype=np.uint8), rng.integers(0, 256, tail, dtype=np.uint8)
+    src = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    ref = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    src[size - tail:] = torch.from_numpy(src_t).cuda()
+    ref[size - tail:] = torch.from_numpy(ref_t).cuda()
+    stride = 2048
+    for (w, h) in ((64, 64), (16, 16), (48, 64)):
+        n = 64
+        rows_avail = tail // stride - h - 16
+        so_t = (rng.integers(8, rows_avail, n) * stride + rng.integers(0, stride - w - 16, n)).astype(np.int64)
+        ro_t = (so_t[:, None] + rng.integers(-7, 8, (n, 4)) * stride + rng.integers(-7, 8, (n, 4))).astype(np.int64)
+        # the very last block ends at the plane's last byte
+        so_t[0] = tail - (h - 1) * stride - w
+        ro_t[0, :] = tail - (h - 1) * stride - w - np.array([0, 1, stride, stride + 3])
+        want4 = pyoracle.sad_multiref_batch(src_t, stride, ref_t, stride, so_t.astype(np.uint32), ro_t.reshape(-1).astype(np.uint32), w, h)
+        base = size - tail
+        so_d = B.off32((so_t + base).astype(np.uint32))
+        ro_d = B.off32((ro_t + base).reshape(-1).astype(np.uint32))
+        got4 = B.sad_multiref(src, stride, ref, stride, so_d, ro_d, w, h).cpu().numpy().reshape(-1, 4)
+        assert np.array_equal(got4, want4), (w, h)
+        got1 = B.sad(src, stride, ref, stride, so_d, B.off32((ro_t[:, 1] + base).astype(np.uint32)), w, h).cpu().numpy()
+        assert np.array_equal(got1, want4[:, 1]), (w, h)
+        # bottom-up: offsets name the first row, which is the highest address
+        so_n = (so_t + (h - 1) * stride + base).astype(np.uint32)
+        ro_n = (ro_t + (h - 1) * stride + base).reshape(-1).astype(np.uint32)
+        want_n = pyoracle.sad_multiref_batch(src_t, -stride, ref_t, -stride, (so_t + (h - 1) * stride).astype(np.uint32),
+                                             (ro_t + (h - 1) * stride).reshape(-1).astype(np.uint32), w, h)
+        got_n = B.sad_multiref(src, -stride, ref, -stride, B.off32(so_n), B.off32(ro_n), w, h).cpu().numpy().reshape(-1, 4)
+        assert np.array_equal(got_n, want_n), (w, h)
+    del src, ref
+    torch.cuda.empty_cache()
+
+
 def test_concurrent_host_threads_and_streams():
     """hevcasm_hip.h promises that the entry points may be called from several host threads at once (one
     stream per thread): four threads, each on its own stream, each a different family, many rounds."""
