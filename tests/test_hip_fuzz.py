@@ -1,0 +1,64 @@
+"""Seeded random sweep of the batch API against the oracle: sizes the fixed case lists do not name (every multiple
+of 4 for the block costs, odd prediction sizes, odd batch lengths), random frame geometry, random parameters.
+Deterministic (fixed seed) so that a failure reproduces; about 250 small cases."""
+import numpy as np
+import pytest
+
+import cases
+from hevcasm_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _frame(rng, w, h):
+    # frames that the block size tiles, of random extent
+    return (w * int(rng.integers(1, 5)), h * int(rng.integers(1, 4)))
+
+
+def test_block_costs_random_geometry():
+    rng = np.random.default_rng(20261004)
+    for i in range(90):
+        w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
+        n = int(rng.integers(1, 70))
+        ways = int(rng.choice([1, 4]))
+        c = wl.sad_case(w, h, n, 5000 + i, ways=ways, max_disp=int(rng.integers(0, 8)), frame=_frame(rng, w, h))
+        fam = rng.choice(["sad", "ssd"]) if ways == 1 else "sad4"
+        cases.assert_same("fuzz %s %dx%d n=%d" % (fam, w, h, n), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+
+
+def test_prediction_random_sizes_and_fractions():
+    rng = np.random.default_rng(20261005)
+    for i in range(70):
+        taps = int(rng.choice([8, 4]))
+        lim = 64 if taps == 8 else 32
+        w, h = int(rng.integers(1, lim + 1)), int(rng.integers(1, lim + 1))   # the C bodies take any size up to the limit
+        n = int(rng.integers(1, 40))
+        bi = bool(rng.integers(0, 2))
+        c = wl.pred_case(taps, w, h, n, 6000 + i, bi=bi, frame=(w * int(rng.integers(1, 4)), h * int(rng.integers(1, 4))))
+        fam = "pred_bi" if bi else "pred_uni"
+        cases.assert_same("fuzz %s taps=%d %dx%d n=%d" % (fam, taps, w, h, n), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+
+
+def test_transforms_and_quantisers_random_parameters():
+    rng = np.random.default_rng(20261006)
+    for i in range(60):
+        tr, lg = wl.TRANSFORMS[int(rng.integers(0, len(wl.TRANSFORMS)))]
+        n = int(rng.integers(1, 50))
+        size = 1 << lg
+        frame = (size * int(rng.integers(1, 6)), size * int(rng.integers(1, 6)))
+        kind = str(rng.choice(["full", "natural"]))
+        c = wl.inverse_case(tr, lg, n, 7000 + i, kind, frame=frame)
+        cases.assert_same("fuzz inverse %d/%d n=%d" % (tr, lg, n), cases.run_hip("inverse", c), cases.run_oracle("inverse", c))
+        c["scale"], c["shift"] = int(rng.integers(-300, 20000)), int(rng.integers(1, 16))
+        cases.assert_same("fuzz dequant_inverse %d/%d scale=%d shift=%d" % (tr, lg, c["scale"], c["shift"]),
+                          cases.run_hip("dequant_inverse", c), cases.run_oracle("dequant_inverse", c))
+        f = wl.forward_case(tr, lg, n, 7100 + i, str(rng.choice(["residual9", "full"])), frame=frame)
+        cases.assert_same("fuzz forward %d/%d n=%d" % (tr, lg, n), cases.run_hip("forward", f), cases.run_oracle("forward", f))
+    for i in range(30):
+        npb = int(rng.choice([16, 64, 256, 1024]))
+        nb = int(rng.integers(1, 20))
+        src = wl.fill_i16(npb * nb, 7200 + i, "full")
+        q = dict(src=src, scale=int(rng.integers(1, 0x8000)), shift=int(rng.integers(16, 28)), offset=int(rng.integers(0, 0x8000)), n_per_block=npb)
+        cases.assert_same("fuzz quant %d x %d" % (npb, nb), cases.run_hip("quant", q), cases.run_oracle("quant", q))
+        d = dict(src=wl.fill_i16(int(rng.integers(1, 3000)), 7300 + i, "full"), scale=int(rng.integers(-32768, 32768)), shift=int(rng.integers(1, 20)))
+        cases.assert_same("fuzz dequant n=%d" % d["src"].size, cases.run_hip("dequant", d), cases.run_oracle("dequant", d))
