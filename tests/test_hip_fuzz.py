@@ -62,3 +62,31 @@ def test_transforms_and_quantisers_random_parameters():
         cases.assert_same("fuzz quant %d x %d" % (npb, nb), cases.run_hip("quant", q), cases.run_oracle("quant", q))
         d = dict(src=wl.fill_i16(int(rng.integers(1, 3000)), 7300 + i, "full"), scale=int(rng.integers(-32768, 32768)), shift=int(rng.integers(1, 20)))
         cases.assert_same("fuzz dequant n=%d" % d["src"].size, cases.run_hip("dequant", d), cases.run_oracle("dequant", d))
+
+
+def test_search_operators_and_small_families_random_parameters():
+    rng = np.random.default_rng(20261007)
+    for i in range(24):
+        w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
+        c = cases._subpel_case(w, h, int(rng.integers(1, 6)), 8000 + i, "noise") | dict(metric=int(rng.integers(0, 2)))
+        cases.assert_same("fuzz subpel %dx%d metric=%d" % (w, h, c["metric"]), cases.run_hip("subpel", c), cases.run_oracle("subpel", c))
+    for i in range(12):
+        w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
+        c = cases._me_case(w, h, int(rng.integers(0, 17)), int(rng.integers(1, 5)), 8100 + i)
+        cases.assert_same("fuzz me %dx%d +-%d" % (w, h, c["range"]), cases.run_hip("me", c), cases.run_oracle("me", c))
+    for i in range(12):
+        size = int(rng.choice([2, 4, 8]))
+        c = wl.sad_case(max(size, 4), max(size, 4), int(rng.integers(1, 300)), 8200 + i) | dict(size=size)
+        cases.assert_same("fuzz satd %d" % size, cases.run_hip("satd", c), cases.run_oracle("satd", c))
+    for i in range(20):
+        size, n = int(rng.integers(0, 5000)), int(rng.integers(1, 12))
+        span = max(size, 1) + 5
+        c = dict(src0=wl.fill_u8(span * n + 8, 8300 + i), src1=wl.fill_u8(span * n + 8, 8400 + i),
+                 off0=(np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32), off1=(np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32), size=size)
+        cases.assert_same("fuzz ssd_linear %d" % size, cases.run_hip("ssd_linear", c), cases.run_oracle("ssd_linear", c))
+    for i in range(16):
+        log2 = int(rng.integers(2, 6))
+        edge = int(rng.integers(0, 2)) if log2 < 5 else 0
+        stride, n = int(rng.integers(2 << log2, 300)), int(rng.integers(1, 90))
+        c = dict(neighbours=wl.fill_u8(stride * n + 128, 8500 + i), neighbour_stride=stride, mode=1, packed=(8 << 8) | (log2 << 1) | edge, n=n)
+        cases.assert_same("fuzz intra %d edge=%d stride=%d" % (1 << log2, edge, stride), cases.run_hip("intra", c), cases.run_oracle("intra", c))
