@@ -108,21 +108,36 @@ template <int TAPS, int NDW> struct RefStream
 	uint32_t shift;              // 8 * bytes the last lane's load was moved left to stay inside the window
 	Coefs<TAPS> c;
 
-	// next window row of the stream (rows are consumed strictly in order)
+	// Issue the load of the next window row of the stream (rows are consumed strictly in order).  The
+	// registers are left exactly as loaded: touching them here -- even the realigning shift -- would make
+	// the wave wait for the load here and throw the look-ahead away (realign() is applied on use).
 	__device__ __forceinline__ void next_row(uint32_t (&d)[NDW])
 	{
 		if (NDW == 1)
 		{
-			d[0] = reinterpret_cast<const U1 *>(p)->v >> shift;
+			d[0] = reinterpret_cast<const U1 *>(p)->v;
 		}
 		else
 		{
 			const u32x2 v = reinterpret_cast<const U2 *>(p)->v;
-			const unsigned long long q = (((unsigned long long)v.y << 32) | v.x) >> shift;
+			d[0] = v.x;
+			d[NDW - 1] = v.y;
+		}
+		p += stride;
+	}
+	// the last lane's load was moved left to stay inside the window: move its bytes back
+	__device__ __forceinline__ void realign(uint32_t (&d)[NDW]) const
+	{
+		if (NDW == 1)
+		{
+			d[0] >>= shift;
+		}
+		else
+		{
+			const unsigned long long q = (((unsigned long long)d[NDW - 1] << 32) | d[0]) >> shift;
 			d[0] = (uint32_t)q;
 			d[NDW - 1] = (uint32_t)(q >> 32);
 		}
-		p += stride;
 	}
 	__device__ __forceinline__ void zero_row(uint32_t (&d)[NDW])
 	{
@@ -247,7 +262,11 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 			if (q < rows) rs[r].next_row(first[q]); else rs[r].zero_row(first[q]);
 		}
 #pragma unroll
-		for (int q = 0; q < TAPS - 1; ++q) rs[r].unpack(q, first[q]);
+		for (int q = 0; q < TAPS - 1; ++q)
+		{
+			rs[r].realign(first[q]);
+			rs[r].unpack(q, first[q]);
+		}
 		if (TAPS - 1 < rows) rs[r].next_row(rs[r].pending); else rs[r].zero_row(rs[r].pending);
 	}
 
@@ -273,6 +292,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 #pragma unroll
 					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[m];
 					if (y + TAPS < rows) rs[r].next_row(rs[r].pending);     // window row (y + 1) + T - 1
+					rs[r].realign(newest);
 					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
 					uint32_t ve[Stream::NX], vo[Stream::NX];
 					rs[r].vertical(i, ve, vo);
