@@ -98,11 +98,11 @@ template <int TAPS> struct Coefs
 
 // One reference's state: the sliding window of unpacked rows, and the row stream.
 // NDW = dwords (4 window columns each) per lane per row.
-template <int TAPS, int NDW> struct RefStream
+template <int TAPS, int NDW, int AHEAD> struct RefStream
 {
 	static constexpr int NX = NDW + (TAPS == 8 ? 2 : 1);   // column groups the horizontal pass reads
 	uint32_t e[TAPS][NDW], o[TAPS][NDW];   // window slots: even / odd columns of each dword as int16 pairs
-	uint32_t pending[NDW];       // the row whose load is in flight
+	uint32_t pending[AHEAD][NDW];   // the AHEAD window rows whose loads are in flight (ring, slot = row % AHEAD)
 	const uint8_t *p;            // this lane's bytes of the next window row to load
 	ptrdiff_t stride;
 	uint32_t shift;              // 8 * bytes the last lane's load was moved left to stay inside the window
@@ -208,7 +208,7 @@ template <int TAPS, int NDW> struct RefStream
 	}
 };
 
-template <int TAPS, int NDW, bool BI>
+template <int TAPS, int NDW, bool BI, int AHEAD>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
@@ -219,7 +219,8 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
 	constexpr int CPL = 4 * NDW;            // window / output columns per lane
-	typedef RefStream<TAPS, NDW> Stream;
+	typedef RefStream<TAPS, NDW, AHEAD> Stream;
+	static_assert(TAPS % AHEAD == 0, "the look-ahead ring must divide the unroll");
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
@@ -267,15 +268,20 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 			rs[r].realign(first[q]);
 			rs[r].unpack(q, first[q]);
 		}
-		if (TAPS - 1 < rows) rs[r].next_row(rs[r].pending); else rs[r].zero_row(rs[r].pending);
+#pragma unroll
+		for (int a = 0; a < AHEAD; ++a)      // window rows T-1 .. T-2+AHEAD; row T-1+a has ring slot a (output row a consumes it)
+		{
+			if (TAPS - 1 + a < rows) rs[r].next_row(rs[r].pending[a]); else rs[r].zero_row(rs[r].pending[a]);
+		}
 	}
 
-	// One row of output per trip; the loop is unrolled by T so that window slots are static.  The
-	// load of the NEXT row's newest window row is issued before this row is computed: one row of
-	// look-ahead costs NDW registers, and the other waves of the SIMD cover the rest of the latency
-	// (a software prefetch one whole group of T rows ahead was measured: +17 VGPRs, one wave fewer
-	// per SIMD, 4-30 % slower; a ring of 2 / 4 rows in flight: +2 / +6 VGPRs, 0 % / 3-10 % slower --
-	// the waits the counters show are not load latency).
+	// One row of output per trip; the loop is unrolled by T so that window slots are static.  The loads
+	// of the next AHEAD window rows are in flight while a row is computed (a ring of AHEAD * NDW registers
+	// per reference; nothing may touch them before their turn, see next_row()).  Measured on one box, mean
+	// algorithmic GB/s over all PU sizes, AHEAD = 1 / 2 / 4 / 8: luma uni 3075 / 3155 / 3260 / 3365, luma bi
+	// 2985 / 3085 / 3105 / 3155, chroma uni 2460 / 2560 / 2600, chroma bi 2120 / 2195 / 2285 -- the kernel
+	// was latency-bound, and before the loads were left untouched until use (when the realigning shift
+	// made every load wait at issue) it ran at 2890 / 2430 / 2375 / 1905.
 	for (int y0 = 0; y0 < H; y0 += TAPS)
 	{
 #pragma unroll
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 				{
 					uint32_t newest[NDW];
 #pragma unroll
-					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[m];
-					if (y + TAPS < rows) rs[r].next_row(rs[r].pending);     // window row (y + 1) + T - 1
+					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
+					if (y + TAPS - 1 + AHEAD < rows) rs[r].next_row(rs[r].pending[i % AHEAD]);     // window row (y + AHEAD) + T - 1
 					rs[r].realign(newest);
 					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
 					uint32_t ve[Stream::NX], vo[Stream::NX];
@@ -342,7 +348,8 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
 	const int ppw = kWave / lw;
 	const uint32_t grid = ceil_div(n, (size_t)ppw * (kThreads / kWave));
-	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI>), dim3(grid), dim3(kThreads), 0, st,
+	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
+	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS>), dim3(grid), dim3(kThreads), 0, st,
 			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n);
 	return launch_status("pred_stream_kernel");
 }
