@@ -169,10 +169,12 @@ extern "C" int hevcasm_hip_quantize_inverse(int16_t *dst, const int16_t *src, in
 	if (scale < -32768 || scale > 32767) return set_error(HEVCASM_HIP_EINVAL, "scale must fit int16 (the reference's SIMD path multiplies with pmaddwd, quantize_a.asm:53-109)");
 	if (n == 0) return 0;
 	if (!dst || !src) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	// memory-bound: cap the grid at 8 workgroups per CU and grid-stride the rest
+	// memory-bound: one 16-byte vector per lane and no loop -- one-shot workgroups stream faster than a capped,
+	// grid-striding grid on this part (profiles/r01_hbm_stream.txt: 6.3 against 5.0 TB/s for a plain copy); the
+	// kernel's loop only runs when the batch exceeds 2^31 lanes
 	size_t wgs = (n / 8 + kThreads - 1) / kThreads;
 	if (wgs < 1) wgs = 1;
-	if (wgs > 256 * 8) wgs = 256 * 8;
+	if (wgs > 0x7fffffffull / kThreads) wgs = 0x7fffffffull / kThreads;
 	hipLaunchKernelGGL(quantize_inverse_kernel, dim3((uint32_t)wgs), dim3(kThreads), 0, as_stream(stream), dst, src, scale, shift, n);
 	return launch_status("quantize_inverse_kernel");
 }
