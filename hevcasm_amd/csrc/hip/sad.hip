@@ -155,6 +155,37 @@ template <int C, int LPR> struct AlignedRefChunk
 	}
 };
 
+// Reference rows of 8- or 12-byte chunks, two or more lanes to a row, loaded dword-aligned with NO tail load: each
+// lane loads the C + 4 aligned bytes that contain its C (global_load_dwordx3 / x4), so the loads of neighbouring lanes
+// overlap by a dword.  The vector L1 counts one access per quad of lanes and row for dword-aligned loads whether or
+// not they overlap (profiles/r01_tcp_access_model.txt: 12 bytes at 8-byte pitch, 2 lanes per row -> 32 accesses for
+// 32 rows), where the same row costs two accesses when it is loaded at its byte address and is misaligned.
+// A row's last lane whose chunk is aligned would read the dword past the row, which may lie outside the plane: it
+// loads the dword BEFORE its chunk instead (inside the row, LPR >= 2) and uses the upper part.
+template <int C, int LPR> struct OverlapRefChunk
+{
+	static_assert(LPR >= 2 && (C == 8 || C == 12), "the last lane's window needs the chunk before it");
+	uint32_t d[C / 4 + 1];
+	__device__ __forceinline__ void load(const uint8_t *base, uint32_t off, bool last_lane_of_row)
+	{
+		const uint32_t back = (last_lane_of_row && !(off & 3u)) ? 4u : 0u;
+		Chunk<C + 4> c;
+		c.load(base + (size_t)((off & ~3u) - back));
+#pragma unroll
+		for (int i = 0; i <= C / 4; ++i) d[i] = c.d[i];
+	}
+	__device__ __forceinline__ void finish(uint32_t sh, bool last_lane_of_row, Chunk<C> &out) const
+	{
+		const bool back = last_lane_of_row && !sh;
+		uint32_t w[C / 4 + 1];
+#pragma unroll
+		for (int i = 0; i < C / 4; ++i) w[i] = back ? d[i + 1] : d[i];
+		w[C / 4] = d[C / 4];
+#pragma unroll
+		for (int i = 0; i < C / 4; ++i) out.d[i] = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+	}
+};
+
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 // LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP>
@@ -213,12 +244,21 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// aligned form quarters the accesses of a 64-byte row; it pays for the 4-way kernel, which is bound by that rate.
 	// For one reference it was measured slower: 64x64 1.48 against 1.38 ms, 32x32 0.42 against 0.37 -- HBM-bound, and the
 	// extra tail loads and funnel shifts are pure cost.  8-byte chunks: slower too, half the lanes issue the tail load.)
+	// 8-byte chunks (16-, 24-, 40-, 56-wide): overlapping aligned loads, see OverlapRefChunk.  Same-box A/B, ms per 1 Mi
+	// blocks (profiles/r01_sad_overlap_ab.txt): 4-way 16x64 0.75 -> 0.59, 16x32 0.38 -> 0.29, 16x16 0.192 -> 0.170,
+	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41, shorter blocks unchanged; the short single-trip blocks
+	// (16x12, 16x8) lose 4-10 %, they are bound by latency and the realignment is extra work, so they keep byte-address loads.
+	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
+	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
+	// (fewer L1 accesses but twice the lane loads: 32x32 0.58 -> 0.62, 32x24 0.43 -> 0.55).
+	constexpr bool OVERLAP = C == 8 && LPR >= 2 && (WAYS == 4 ? (LOOP || U == 4) : LOOP);
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
 	Chunk<C> s[U];
 	AlignedRefChunk<C, LPR> ra[ALIGNED ? U : 1][ALIGNED ? WAYS : 1];   // wide 4-way blocks: dword-aligned loads + funnel shift
-	Chunk<C> r[ALIGNED ? 1 : U][ALIGNED ? 1 : WAYS];                   // everything else: loads at the byte address
+	OverlapRefChunk<OVERLAP ? C : 8, OVERLAP ? LPR : 2> rv[OVERLAP ? U : 1][OVERLAP ? WAYS : 1];   // 8-/12-byte chunks: overlapping aligned loads
+	Chunk<C> r[ALIGNED || OVERLAP ? 1 : U][ALIGNED || OVERLAP ? 1 : WAYS];   // everything else: loads at the byte address
 
 	// slot u <- row u of the trip `ahead` trips below the current one
 	auto fill = [&](int u, int ahead)
@@ -229,6 +269,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 		{
 			const uint32_t o = orf[k] + (ahead * U + u) * step_ref;
 			if constexpr (ALIGNED) ra[u][k].load_main(ref_al, o);
+			else if constexpr (OVERLAP) rv[u][k].load(ref_al, o, last);
 			else r[u][k].load(ref_al + (size_t)o);
 		}
 		if constexpr (ALIGNED)
@@ -249,6 +290,12 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 			{
 				Chunk<C> x;
 				ra[u][k].finish((orf[k] + u * step_ref) & 3u, last, x);
+				acc[k].add(s[u], x);
+			}
+			else if constexpr (OVERLAP)
+			{
+				Chunk<C> x;
+				rv[u][k].finish((orf[k] + u * step_ref) & 3u, last, x);
 				acc[k].add(s[u], x);
 			}
 			else
