@@ -226,4 +226,7 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
+        if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
+            bench_pred(frames=int(w[4:]))
+            continue
         dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, ssdlin=bench_ssd_linear)[w]()
