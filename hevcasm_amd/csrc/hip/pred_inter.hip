@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
-	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks)
+	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments)
 {
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
@@ -229,7 +229,12 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	int j = lane - sub * LW;
 	const bool spare = sub >= PPW;          // lanes left over when 64 % LW != 0: park them on lane 0's data
 	if (spare) { sub = PPW - 1; j = 0; }
-	uint32_t pu = wave * PPW + sub;
+	// Small launches of tall PUs are cut into 2 or 4 row segments, one wave each (neighbouring waves = the segments of
+	// one group of PUs, so the T-1 window rows two segments share come from L2): see launch_pred_ndw().
+	const int segment = (int)(wave & ((1u << log2_segments) - 1u));
+	const int y_first = segment * (H >> log2_segments);
+	H >>= log2_segments;                       // the launcher only splits heights that divide
+	uint32_t pu = (wave >> log2_segments) * PPW + sub;
 	const bool in_batch = pu < n_blocks;
 	if (!in_batch) pu = n_blocks - 1;
 
@@ -245,11 +250,11 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	{
 		const uint8_t *base = (r ? ref1 : ref0) + (r ? ref1_off : ref0_off)[pu];
 		rs[r].stride = stride_ref;
-		rs[r].p = base - (ptrdiff_t)BEFORE * stride_ref - BEFORE + CPL * j - over;
+		rs[r].p = base + (ptrdiff_t)(y_first - BEFORE) * stride_ref - BEFORE + CPL * j - over;
 		rs[r].shift = 8 * over;
 		rs[r].c.load((r ? frac1 : frac0)[pu]);
 	}
-	uint8_t *out = dst + dst_off[pu] + CPL * j;
+	uint8_t *out = dst + dst_off[pu] + (ptrdiff_t)y_first * stride_dst + CPL * j;
 	const int rows = H + TAPS - 1;                    // window rows
 
 	// prologue: window rows 0 .. T-2 into slots 0 .. T-2, and the load of row T-1 in flight
@@ -347,10 +352,22 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 {
 	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
 	const int ppw = kWave / lw;
-	const uint32_t grid = ceil_div(n, (size_t)ppw * (kThreads / kWave));
+	// A wave lives for H rows and starts with two dependent round trips (descriptors, then window rows); a launch of
+	// fewer than ~16 waves per SIMD is one or two generations deep and ends with most of the chip idle.  Such launches
+	// of tall PUs are split into row segments of >= 2 T rows (the T-1 extra window rows per segment are loads only).
+	// 64 frames of 1080p per launch, same box, ms: uni 8-tap 64x64 0.0955 -> 0.0847, bi 64x64 0.162 -> 0.1445, bi 32x32
+	// 0.188 -> 0.170, bi 16x64 0.209 -> 0.192; nothing slower (profiles/r01_pred_segments_ab.txt).
+	size_t waves = ceil_div(n, (size_t)ppw);
+	int log2_segments = 0;
+	while (log2_segments < 2 && waves < 16384 && H % (2 << log2_segments) == 0 && (H >> (log2_segments + 1)) >= 2 * TAPS)
+	{
+		++log2_segments;
+		waves *= 2;
+	}
+	const uint32_t grid = ceil_div(waves, (size_t)(kThreads / kWave));
 	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
 	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS>), dim3(grid), dim3(kThreads), 0, st,
-			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n);
+			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
 	return launch_status("pred_stream_kernel");
 }
 

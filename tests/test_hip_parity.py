@@ -98,8 +98,10 @@ def test_pred_full_size_properties():
     import torch
     from hevcasm_amd import batch as B, workload as wl
     from oracle import pyoracle
-    for taps, (w, h), (fw, fh) in ((8, (16, 16), (1920, 1080)), (4, (8, 8), (960, 540)), (8, (64, 32), (1920, 1080))):
-        n = (fw // w) * (fh // h) * 16
+    # 64x32 at 16 frames is a small launch of tall PUs (the launcher cuts those into row segments, pred_inter.hip);
+    # 8x32 at 67 frames is 16 582 waves, above the threshold, so tall PUs in one piece are covered as well
+    for taps, (w, h), (fw, fh), frames in ((8, (16, 16), (1920, 1080), 16), (4, (8, 8), (960, 540), 16), (8, (64, 32), (1920, 1080), 16), (8, (8, 32), (1920, 1080), 67)):
+        n = (fw // w) * (fh // h) * frames
         c = wl.pred_case(taps, w, h, n, 99, frame=(fw, fh), fracs=(0, 0))
         ref, dst_off, ref_off, frac = B.u8(c["ref0"]), B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"])
         dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
