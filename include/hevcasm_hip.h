@@ -21,7 +21,8 @@
  *    plane's base pointer (the kernels address with base + 32-bit offset).  A plane larger than
  *    that is handled by splitting the batch and advancing the base pointer.
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls are
- *    asynchronous: they return once the launch is queued.
+ *    asynchronous: they return once the launch is queued.  A batch call does nothing but enqueue
+ *    kernels on that stream, so it may be recorded into a HIP graph (stream capture) and replayed.
  *  - Return value: 0 on success; HEVCASM_HIP_EINVAL for arguments outside the domain the
  *    reference function accepts (same conditions as the reference's asserts / NULL table
  *    entries); otherwise the hipError_t of the failing runtime call.  There is no CPU

@@ -301,6 +301,50 @@ def test_concurrent_host_threads_and_streams():
     assert not errors, errors
 
 
+def test_entry_points_capture_into_a_hip_graph():
+    """The batch entry points only enqueue work on the caller's stream, so a launch-bound inner loop can be
+    captured once into a HIP graph and replayed: SAD + 4-way SAD + inverse transform captured together, inputs
+    overwritten in place between replays, every replay checked against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    n = 3000
+    ca = wl.sad_case(16, 16, n, 901, ways=4)
+    cb = wl.sad_case(16, 16, n, 902, ways=4)          # same geometry, other pixels and displacements
+    src, ref = B.u8(ca["src"]).clone(), B.u8(ca["ref"]).clone()
+    so, ro = B.off32(ca["src_off"]).clone(), B.off32(ca["ref_off"]).clone()
+    ro1 = ro[::4].contiguous()
+    out1 = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out4 = torch.zeros(4 * n, dtype=torch.int32, device="cuda")
+    ci = wl.inverse_case(0, 3, 2000, 903, "natural")
+    coeffs = B.i16(ci["coeffs"]).clone()
+    pred, dst = B.u8(ci["pred"]), torch.zeros(ci["dst_bytes"], dtype=torch.uint8, device="cuda")
+    doff, poff = B.off32(ci["dst_off"]), B.off32(ci["pred_off"])
+    want_inv = np.asarray(cases.run_oracle("inverse", ci)[0])
+    stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(stream):      # warm-up outside capture (the first launch loads the code object)
+        B.sad(src, ca["stride_src"], ref, ca["stride_ref"], so, ro1, 16, 16, out=out1)
+        B.sad_multiref(src, ca["stride_src"], ref, ca["stride_ref"], so, ro, 16, 16, out=out4)
+        B.inverse_transform_add(dst, ci["stride_dst"], pred, ci["stride_pred"], doff, poff, coeffs, 0, 3)
+    torch.cuda.current_stream().wait_stream(stream)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        B.sad(src, ca["stride_src"], ref, ca["stride_ref"], so, ro1, 16, 16, out=out1)
+        B.sad_multiref(src, ca["stride_src"], ref, ca["stride_ref"], so, ro, 16, 16, out=out4)
+        B.inverse_transform_add(dst, ci["stride_dst"], pred, ci["stride_pred"], doff, poff, coeffs, 0, 3)
+    for c in (ca, cb, ca):
+        src.copy_(B.u8(c["src"])); ref.copy_(B.u8(c["ref"])); ro.copy_(B.off32(c["ref_off"])); ro1.copy_(ro[::4])
+        out1.zero_(); out4.zero_(); dst.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        want4 = np.asarray(pyoracle.sad_multiref_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], 16, 16)).reshape(-1)
+        assert np.array_equal(out4.cpu().numpy().reshape(-1), want4)
+        assert np.array_equal(out1.cpu().numpy(), want4.reshape(-1, 4)[:, 0])
+        assert np.array_equal(cases._dst_rows(dst.cpu().numpy(), ci["stride_dst"], ci["dst_off"], 8, 8), want_inv)
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch
