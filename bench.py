@@ -134,7 +134,7 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     # throughput of the same mix (equal block counts per (size, ways)): harmonic combination per process, summed
     total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
     sad16 = sum(r[(16, 16, 1)] for r in per_proc)
-    return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference",
+    return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference", value_per_core=round(total / procs_n / 1e6, 3),
                 sample="reference C path (gcc -O3, HEVCASM_C_REF tables) via oracle/_ref/refdrv: %d processes x %d (size, ways) combos x %d blocks "
                        "repeated for %d ms each, same size mix as the GPU step" % (procs_n, len(combos), sample_blocks, ms_each),
                 sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3))
@@ -254,6 +254,8 @@ def main():
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(sizes, 2048, args.cpu_seconds)
+            if cpu:
+                cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
