@@ -1,0 +1,99 @@
+// How fast can 16x16 tiles of an 8-bit frame be streamed, by lane mapping?  Pure loads (xor-reduced), no SAD arithmetic:
+// the ceiling of the narrow-block kernels' access pattern, separated from everything else they do.
+//   X  block-major (what block_cost_kernel<16,...> does): lane = tile * 8 + row * 2 + chunk, 8-byte lanes, 4 rows in flight
+//   Y  row-major across the wave's 8 tiles: lane = row * 16 + tile * 2 + chunk  (16 lanes = 128 contiguous bytes of a frame row)
+//   Z  16-byte lanes, row-major: lane = row * 8 + tile  (8 lanes = 128 contiguous bytes), 8 rows in flight
+// each with the tile origin displaced per tile by (dx, dy) in [-7, 7]^2 ("ref") or not at all ("src").
+// hipcc --offload-arch=gfx950 -O3 tools/ubench/tile_stream.hip -o /tmp/tile_stream && /tmp/tile_stream
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <vector>
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(1))) U2 { u32x2 v; };
+struct __attribute__((packed, aligned(1))) U4 { u32x4 v; };
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <int MAP>
+__global__ __launch_bounds__(256) void stream(const uint8_t *__restrict__ frame, uint32_t stride, const uint32_t *__restrict__ off, uint32_t *out, uint32_t n)
+{
+	const uint32_t wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	uint32_t acc = 0;
+	if (MAP == 0)
+	{
+		const uint32_t t = lane >> 3, r = (lane >> 1) & 3, c = lane & 1;
+		const uint32_t o = off[wave * 8 + t] + r * stride + c * 8;
+		u32x2 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const U2 *>(frame + o + u * 4 * stride)->v;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y;
+	}
+	else if (MAP == 1)
+	{
+		const uint32_t r = lane >> 4, t = (lane >> 1) & 7, c = lane & 1;
+		const uint32_t o = off[wave * 8 + t] + r * stride + c * 8;
+		u32x2 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const U2 *>(frame + o + u * 4 * stride)->v;
+#pragma unroll
+		for (int u = 0; u < 4; ++u) acc ^= v[u].x ^ v[u].y;
+	}
+	else
+	{
+		const uint32_t r = lane >> 3, t = lane & 7;
+		const uint32_t o = off[wave * 8 + t] + r * stride;
+		u32x4 v[2];
+#pragma unroll
+		for (int u = 0; u < 2; ++u) v[u] = reinterpret_cast<const U4 *>(frame + o + u * 8 * stride)->v;
+#pragma unroll
+		for (int u = 0; u < 2; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+	}
+	if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main()
+{
+	const uint32_t W = 1920, H = 1152, n = 1u << 20, per_frame = (W / 16) * (H / 16), frames = (n + per_frame - 1) / per_frame;
+	const uint32_t stride = W + 32, rows = H + 16;
+	const size_t bytes = (size_t)stride * rows * frames + 4096;
+	uint8_t *frame; uint32_t *off, *out;
+	CK(hipMalloc(&frame, bytes)); CK(hipMalloc(&off, 4 * n)); CK(hipMalloc(&out, 4));
+	CK(hipMemset(frame, 3, bytes));
+	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+	for (int displaced = 0; displaced < 3; ++displaced)
+	{
+		std::vector<uint32_t> h(n);
+		srand(1);
+		for (uint32_t i = 0; i < n; ++i)
+		{
+			const uint32_t f = i / per_frame, k = i % per_frame, by = k / (W / 16), bx = k % (W / 16);
+			int dx = 0, dy = 0;
+			if (displaced == 1) { dx = rand() % 15 - 7; dy = rand() % 15 - 7; }
+			if (displaced == 2) { dx = (rand() % 4 - 2) * 4; dy = rand() % 15 - 7; }
+			h[i] = (uint32_t)(((size_t)f * rows + 8 + by * 16 + dy) * stride + 16 + bx * 16 + dx);
+		}
+		CK(hipMemcpy(off, h.data(), 4 * n, hipMemcpyHostToDevice));
+		for (int map = 0; map < 3; ++map)
+		{
+			float best = 1e30f;
+			for (int rep = 0; rep < 8; ++rep)
+			{
+				// another 256 MiB pass in between so that the Infinity Cache holds none of the frame
+				CK(hipMemsetAsync(frame + bytes - 4096, rep, 4096, 0));
+				CK(hipEventRecord(e0));
+				if (map == 0) hipLaunchKernelGGL(stream<0>, dim3(n / 32), dim3(256), 0, 0, frame, stride, off, out, n);
+				else if (map == 1) hipLaunchKernelGGL(stream<1>, dim3(n / 32), dim3(256), 0, 0, frame, stride, off, out, n);
+				else hipLaunchKernelGGL(stream<2>, dim3(n / 32), dim3(256), 0, 0, frame, stride, off, out, n);
+				CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+				float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+				if (rep && ms < best) best = ms;
+			}
+			printf("%-28s map %c  %7.4f ms  %7.1f GB/s (256 B per tile + 4 B descriptor)\n",
+				displaced == 0 ? "tiles in place (src)" : displaced == 1 ? "displaced +-7 (ref)" : "displaced, dx multiple of 4", "XYZ"[map], best, n * 260.0 / best * 1e-6);
+		}
+	}
+	return 0;
+}
