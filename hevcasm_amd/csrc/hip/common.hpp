@@ -25,11 +25,19 @@ struct __attribute__((packed, aligned(1))) U3 { uint32_t a, b, c; };
 struct __attribute__((packed, aligned(1))) U4 { u32x4 v; };
 struct __attribute__((packed, aligned(1))) H1 { uint16_t v; };
 
+// the same, as streaming (non-temporal) loads: for data a kernel touches exactly once, so that it does not push the
+// lines other waves are about to reuse out of the vector L1
+typedef uint32_t u32x1_u __attribute__((aligned(1)));
+typedef u32x2 u32x2_u __attribute__((aligned(1)));
+typedef u32x3 u32x3_u __attribute__((aligned(1)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));
+
 template <int BYTES> struct Chunk;
 template <> struct Chunk<4>
 {
 	uint32_t d[1];
 	__device__ __forceinline__ void load(const uint8_t *p) { d[0] = reinterpret_cast<const U1 *>(p)->v; }
+	__device__ __forceinline__ void load_stream(const uint8_t *p) { d[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x1_u *>(p)); }
 	__device__ __forceinline__ void store(uint8_t *p) const { reinterpret_cast<U1 *>(p)->v = d[0]; }
 };
 template <> struct Chunk<8>
@@ -38,6 +46,11 @@ template <> struct Chunk<8>
 	__device__ __forceinline__ void load(const uint8_t *p)
 	{
 		const u32x2 v = reinterpret_cast<const U2 *>(p)->v;
+		d[0] = v.x; d[1] = v.y;
+	}
+	__device__ __forceinline__ void load_stream(const uint8_t *p)
+	{
+		const u32x2 v = __builtin_nontemporal_load(reinterpret_cast<const u32x2_u *>(p));
 		d[0] = v.x; d[1] = v.y;
 	}
 	__device__ __forceinline__ void store(uint8_t *p) const
@@ -54,6 +67,11 @@ template <> struct Chunk<12>
 		const U3 v = *reinterpret_cast<const U3 *>(p);   // one global_load_dwordx3
 		d[0] = v.a; d[1] = v.b; d[2] = v.c;
 	}
+	__device__ __forceinline__ void load_stream(const uint8_t *p)
+	{
+		const u32x3 v = __builtin_nontemporal_load(reinterpret_cast<const u32x3_u *>(p));
+		d[0] = v.x; d[1] = v.y; d[2] = v.z;
+	}
 	__device__ __forceinline__ void store(uint8_t *p) const
 	{
 		U3 v; v.a = d[0]; v.b = d[1]; v.c = d[2];
@@ -66,6 +84,11 @@ template <> struct Chunk<16>
 	__device__ __forceinline__ void load(const uint8_t *p)
 	{
 		const u32x4 v = reinterpret_cast<const U4 *>(p)->v;
+		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+	}
+	__device__ __forceinline__ void load_stream(const uint8_t *p)
+	{
+		const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_u *>(p));
 		d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
 	}
 	__device__ __forceinline__ void store(uint8_t *p) const

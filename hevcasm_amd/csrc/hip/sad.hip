@@ -255,6 +255,13 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
+	// Source rows are read exactly once.  Where the blocks of a wave cover whole 128-byte lines of a frame row between
+	// them (8-, 16-, 32-, 64-wide: BPW * W = 128 when the blocks are raster neighbours) they are loaded as streaming
+	// (non-temporal) loads, which keeps them from evicting the reference lines the neighbouring blocks are about to hit
+	// in the vector L1: same-box A/B (profiles/r01_sad_stream_src_ab.txt) 64x64 -5 %, 64x32 -5 %, 32x32 -5 %, 16x16 -4 %,
+	// 8x8 -6 %, 4-way 64x64 -3 %.  For the other widths a wave uses part of a line and the neighbour wants the rest
+	// from the L1: 48x64 +11 %, 24x32 +6 %, 12x16 +8 % with streaming loads, so they keep ordinary ones.
+	constexpr bool STREAM_SRC = (W * BPW) % 128 == 0;
 	Chunk<C> s[U];
 	AlignedRefChunk<C, LPR> ra[ALIGNED ? U : 1][ALIGNED ? WAYS : 1];   // wide 4-way blocks: dword-aligned loads + funnel shift
 	OverlapRefChunk<OVERLAP ? C : 8, OVERLAP ? LPR : 2> rv[OVERLAP ? U : 1][OVERLAP ? WAYS : 1];   // 8-/12-byte chunks: overlapping aligned loads
@@ -263,7 +270,8 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// slot u <- row u of the trip `ahead` trips below the current one
 	auto fill = [&](int u, int ahead)
 	{
-		s[u].load(src + (size_t)(os + (ahead * U + u) * step_src));
+		if constexpr (STREAM_SRC) s[u].load_stream(src + (size_t)(os + (ahead * U + u) * step_src));
+		else s[u].load(src + (size_t)(os + (ahead * U + u) * step_src));
 #pragma unroll
 		for (int k = 0; k < WAYS; ++k)
 		{
