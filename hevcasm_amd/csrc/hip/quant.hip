@@ -113,7 +113,11 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	Chunk<PX> p;
 	Chunk<2 * PX> r;
 	p.load(pred + pred_off[blk] + y * stride_pred + x);
-	r.load(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
+	// The residual of a 16x16 / 32x32 block is read once and a row is a whole number of 32-byte sectors per lane group:
+	// streaming loads leave the L1 to the prediction rows (16x16 0.066 -> 0.058 ms, 32x32 0.066 -> 0.057 per 2^26
+	// pixels; 8x8, whose 16-byte rows share lines across instructions, loses 7 % with them and keeps ordinary loads).
+	if (N >= 16) r.load_stream(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
+	else r.load(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
 	Chunk<PX> o;
 #pragma unroll
 	for (int k = 0; k < PX / 4; ++k)
