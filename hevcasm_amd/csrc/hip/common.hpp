@@ -39,6 +39,7 @@ template <> struct Chunk<4>
 	__device__ __forceinline__ void load(const uint8_t *p) { d[0] = reinterpret_cast<const U1 *>(p)->v; }
 	__device__ __forceinline__ void load_stream(const uint8_t *p) { d[0] = __builtin_nontemporal_load(reinterpret_cast<const u32x1_u *>(p)); }
 	__device__ __forceinline__ void store(uint8_t *p) const { reinterpret_cast<U1 *>(p)->v = d[0]; }
+	__device__ __forceinline__ void store_stream(uint8_t *p) const { __builtin_nontemporal_store(d[0], reinterpret_cast<u32x1_u *>(p)); }
 };
 template <> struct Chunk<8>
 {
@@ -57,6 +58,11 @@ template <> struct Chunk<8>
 	{
 		u32x2 v; v.x = d[0]; v.y = d[1];
 		reinterpret_cast<U2 *>(p)->v = v;
+	}
+	__device__ __forceinline__ void store_stream(uint8_t *p) const
+	{
+		u32x2 v; v.x = d[0]; v.y = d[1];
+		__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(p));
 	}
 };
 template <> struct Chunk<12>
@@ -95,6 +101,11 @@ template <> struct Chunk<16>
 	{
 		u32x4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
 		reinterpret_cast<U4 *>(p)->v = v;
+	}
+	__device__ __forceinline__ void store_stream(uint8_t *p) const
+	{
+		u32x4 v; v.x = d[0]; v.y = d[1]; v.z = d[2]; v.w = d[3];
+		__builtin_nontemporal_store(v, reinterpret_cast<u32x4_u *>(p));
 	}
 };
 

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(kThreads) void quantize_inverse_kernel(
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 			c.d[k] = pack16(dequant1(sext_lo(c.d[k]), scale, round, shift), dequant1(sext_hi(c.d[k]), scale, round, shift));
-		c.store(reinterpret_cast<uint8_t *>(dst + 8 * i));
+		c.store_stream(reinterpret_cast<uint8_t *>(dst + 8 * i));
 	}
 	// tail (n not a multiple of 8): the reference's C body accepts any n
 	const size_t t = 8 * n8 + (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kThreads) void quantize_kernel(
 			any |= lo | hi;
 			c.d[k] = pack16(lo, hi);
 		}
-		if (live) c.store(reinterpret_cast<uint8_t *>(dst + e));
+		if (live) c.store_stream(reinterpret_cast<uint8_t *>(dst + e));
 	}
 #pragma unroll
 	for (int d = LPB / 2; d >= 1; d >>= 1) any |= __shfl_xor(any, d, kWave);
