@@ -29,8 +29,8 @@ __global__ __launch_bounds__(kThreads) void ssd_linear_kernel(
 	for (uint32_t o = 16 * j; o < whole; o += 16 * LPS)
 	{
 		Chunk<16> x, y;
-		x.load(a + o);
-		y.load(b + o);
+		x.load_stream(a + o);   // both runs are read exactly once
+		y.load_stream(b + o);
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 		{
