@@ -261,6 +261,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// in the vector L1: same-box A/B (profiles/r01_sad_stream_src_ab.txt) 64x64 -5 %, 64x32 -5 %, 32x32 -5 %, 16x16 -4 %,
 	// 8x8 -6 %, 4-way 64x64 -3 %.  For the other widths a wave uses part of a line and the neighbour wants the rest
 	// from the L1: 48x64 +11 %, 24x32 +6 %, 12x16 +8 % with streaming loads, so they keep ordinary ones.
+	// (Reference rows as streaming loads, one reference: 16-25 % slower at every size -- their lines ARE reused.)
 	constexpr bool STREAM_SRC = (W * BPW) % 128 == 0;
 	Chunk<C> s[U];
 	AlignedRefChunk<C, LPR> ra[ALIGNED ? U : 1][ALIGNED ? WAYS : 1];   // wide 4-way blocks: dword-aligned loads + funnel shift
