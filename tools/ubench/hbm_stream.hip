@@ -16,6 +16,17 @@ __global__ __launch_bounds__(256) void read_sum(const u32x4 *__restrict__ in, si
 	const uint32_t s = acc.x ^ acc.y ^ acc.z ^ acc.w;
 	if (s == 0x12345678u) out[0] = s;   // practically never: keeps the loads alive
 }
+__global__ __launch_bounds__(256) void read_sum_nt(const u32x4 *__restrict__ in, size_t n, uint32_t *out)
+{
+	u32x4 acc = {0, 0, 0, 0};
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) acc += __builtin_nontemporal_load(in + i);
+	const uint32_t s = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	if (s == 0x12345678u) out[0] = s;
+}
+__global__ __launch_bounds__(256) void copy_nt(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, size_t n)
+{
+	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
+}
 __global__ __launch_bounds__(256) void copy(const u32x4 *__restrict__ in, u32x4 *__restrict__ out, size_t n)
 {
 	for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = in[i];
@@ -51,6 +62,21 @@ int main()
 			const double moved = which == 1 ? 2.0 * bytes : (double)bytes;
 			printf("%-8s grid %8d  %7.3f ms  %7.1f GB/s\n", which == 0 ? "read" : which == 1 ? "copy" : "fill", g, best, moved / best * 1e-6);
 		}
+	// streaming (non-temporal) forms, one-shot workgroups
+	for (int which = 0; which < 2; ++which)
+	{
+		float best = 1e30f;
+		for (int rep = 0; rep < 6; ++rep)
+		{
+			CK(hipEventRecord(e0));
+			if (which == 0) hipLaunchKernelGGL(read_sum_nt, dim3(1 << 20), dim3(256), 0, 0, a, n, o);
+			else hipLaunchKernelGGL(copy_nt, dim3(1 << 20), dim3(256), 0, 0, a, b, n);
+			CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+			float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+			if (rep && ms < best) best = ms;
+		}
+		printf("%-8s grid %8d  %7.3f ms  %7.1f GB/s\n", which == 0 ? "read nt" : "copy nt", 1 << 20, best, (which ? 2.0 : 1.0) * bytes / best * 1e-6);
+	}
 	// Short launches: one pass over S bytes with one-shot workgroups, every repetition on a different slice of the
 	// 4 GiB buffer (so the 256 MB Infinity Cache never holds it).  This is the line the bench's 0.1-0.4 ms kernels
 	// (1 Mi small blocks per launch) are to be read against: launch ramp-up and the tail are a fixed cost.
