@@ -269,10 +269,13 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	Chunk<C> r[ALIGNED || OVERLAP ? 1 : U][ALIGNED || OVERLAP ? 1 : WAYS];   // everything else: loads at the byte address
 
 	// slot u <- row u of the trip `ahead` trips below the current one
-	auto fill = [&](int u, int ahead)
+	auto fill_src = [&](int u, int ahead)
 	{
 		if constexpr (STREAM_SRC) s[u].load_stream(src + (size_t)(os + (ahead * U + u) * step_src));
 		else s[u].load(src + (size_t)(os + (ahead * U + u) * step_src));
+	};
+	auto fill_ref = [&](int u, int ahead)
+	{
 #pragma unroll
 		for (int k = 0; k < WAYS; ++k)
 		{
@@ -283,12 +286,17 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 		}
 		if constexpr (ALIGNED)
 		{
-			if (last)      // one divergent region per slot, not one per load
+			if (last)
 			{
 #pragma unroll
 				for (int k = 0; k < WAYS; ++k) ra[u][k].load_tail(ref_al, orf[k] + (ahead * U + u) * step_ref);
 			}
 		}
+	};
+	auto fill = [&](int u, int ahead)
+	{
+		fill_src(u, ahead);
+		fill_ref(u, ahead);
 	};
 	auto drain = [&](int u)
 	{
@@ -314,8 +322,26 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 		}
 	};
 
+	// Single-trip blocks issue all their source rows first and then all their reference rows (the compiler is kept from
+	// interleaving them): same-box A/B, ms per 1 Mi blocks (profiles/r01_sad_prologue_order_ab.txt): 16x16 0.116 -> 0.107,
+	// 4-way 16x16 0.169 -> 0.148, 32x32 0.358 -> 0.346, 8x16 0.073 -> 0.069; reference rows first does about as well.
+	// Blocks of several trips lose with either order (4-way 64x64 +4 %, 16x64 +6 %, 48x64 +9 %) and 4-way 8-wide blocks
+	// lose 1.5-3 %: they keep the slot-by-slot order.
+	constexpr bool SPLIT_PROLOGUE = !LOOP && !(WAYS == 4 && C == 8 && LPR == 1);
+	if constexpr (SPLIT_PROLOGUE)
+	{
 #pragma unroll
-	for (int u = 0; u < U; ++u) fill(u, 0);
+		for (int u = 0; u < U; ++u) fill_src(u, 0);
+		__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+		for (int u = 0; u < U; ++u) fill_ref(u, 0);
+		__builtin_amdgcn_sched_barrier(0);
+	}
+	else
+	{
+#pragma unroll
+		for (int u = 0; u < U; ++u) fill(u, 0);
+	}
 	if constexpr (LOOP)
 	{
 		for (int t = 1; t < trips; ++t)
