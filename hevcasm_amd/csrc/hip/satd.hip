@@ -40,24 +40,41 @@ __global__ __launch_bounds__(kThreads) void hadamard_satd_kernel(
 	if (blk >= n_blocks) return;
 	const uint8_t *pa = srcA + offA[blk], *pb = srcB + offB[blk];
 
+	// all rows of the first block, then all rows of the second (not alternating: see the load-order note in sad.hip)
+	uint32_t ra[N][(N + 3) / 4], rb[N][(N + 3) / 4];
+#pragma unroll
+	for (int y = 0; y < N; ++y)
+	{
+		if (N == 2) ra[y][0] = reinterpret_cast<const H1 *>(pa + y * stride_a)->v;
+		else
+		{
+			Chunk<(N >= 4 ? N : 4)> c;
+			c.load(pa + y * stride_a);
+#pragma unroll
+			for (int i = 0; i < N / 4; ++i) ra[y][i] = c.d[i];
+		}
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int y = 0; y < N; ++y)
+	{
+		if (N == 2) rb[y][0] = reinterpret_cast<const H1 *>(pb + y * stride_b)->v;
+		else
+		{
+			Chunk<(N >= 4 ? N : 4)> c;
+			c.load(pb + y * stride_b);
+#pragma unroll
+			for (int i = 0; i < N / 4; ++i) rb[y][i] = c.d[i];
+		}
+	}
+	__builtin_amdgcn_sched_barrier(0);
 	int d[N][N];
 #pragma unroll
 	for (int y = 0; y < N; ++y)
 	{
 		uint32_t a[(N + 3) / 4], b[(N + 3) / 4];
-		if (N == 2)
-		{
-			a[0] = reinterpret_cast<const H1 *>(pa + y * stride_a)->v;
-			b[0] = reinterpret_cast<const H1 *>(pb + y * stride_b)->v;
-		}
-		else
-		{
-			Chunk<(N >= 4 ? N : 4)> ca, cb;
-			ca.load(pa + y * stride_a);
-			cb.load(pb + y * stride_b);
 #pragma unroll
-			for (int i = 0; i < N / 4; ++i) { a[i] = ca.d[i]; b[i] = cb.d[i]; }
-		}
+		for (int i = 0; i < (N + 3) / 4; ++i) { a[i] = ra[y][i]; b[i] = rb[y][i]; }
 #pragma unroll
 		for (int x = 0; x < N; ++x)
 			d[y][x] = (int)((a[x / 4] >> (8 * (x & 3))) & 0xff) - (int)((b[x / 4] >> (8 * (x & 3))) & 0xff);
