@@ -408,6 +408,8 @@ template <int W, int C, int R, int WAYS, int OP> static int launch_rows(const Ar
 	// one reference, 8 rows per lane: one trip of 8 (source rows first, then reference rows) instead of two trips of 4 --
 	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %; with four references the registers run out (16x32 +28 %)
 	if constexpr (WAYS == 1) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP>(a); }
+	if constexpr (WAYS == 1) { if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP>(a); }                 // 64x48: -2 %
+	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP>(a); }    // 16x64: -10 %
 	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP>(a);
 	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP>(a);   // heights 12, 24, 48
 	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP>(a);
