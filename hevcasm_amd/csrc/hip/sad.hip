@@ -251,7 +251,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
 	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
 	// (fewer L1 accesses but twice the lane loads: 32x32 0.58 -> 0.62, 32x24 0.43 -> 0.55).
-	constexpr bool OVERLAP = C == 8 && LPR >= 2 && (WAYS == 4 ? (LOOP || U == 4) : LOOP);
+	constexpr bool OVERLAP = C == 8 && LPR >= 2 && (WAYS == 4 ? (LOOP || U >= 4) : LOOP);
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
@@ -406,8 +406,9 @@ template <int W, int C, int R, int WAYS, int OP> static int launch_rows(const Ar
 {
 	const int rows_per_lane = a.H / R;
 	// one reference, 8 rows per lane: one trip of 8 (source rows first, then reference rows) instead of two trips of 4 --
-	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %; with four references the registers run out (16x32 +28 %)
-	if constexpr (WAYS == 1) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP>(a); }
+	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %
+	// (four references: 8-byte chunks only -- 16x32 -6 %, 24x32 -6 %; 64x64 and 32x64 the same either way, 48x64 +6 %)
+	if constexpr (WAYS == 1 || C <= 8) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP>(a); }
 	if constexpr (WAYS == 1) { if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP>(a); }                 // 64x48: -2 %
 	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP>(a); }    // 16x64: -10 %
 	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP>(a);
