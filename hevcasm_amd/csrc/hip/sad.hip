@@ -395,9 +395,11 @@ template <int W, int C, int R, int U, int WAYS, int OP> static int launch_cfg(co
 	if (a.H == R * U)
 		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, false>), dim3(grid), dim3(kThreads), 0, a.st,
 				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
-	else
+	else if constexpr (U <= 4)      // the deep unrolls are only ever picked for a single trip: no looping variant of them is built
 		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, true>), dim3(grid), dim3(kThreads), 0, a.st,
 				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
+	else
+		return set_error(HEVCASM_HIP_EINVAL, "internal: single-trip configuration chosen for a multi-trip height");
 	return launch_status("block_cost_kernel");
 }
 
