@@ -164,7 +164,7 @@ template <int C, int LPR> struct AlignedRefChunk
 // loads the dword BEFORE its chunk instead (inside the row, LPR >= 2) and uses the upper part.
 template <int C, int LPR> struct OverlapRefChunk
 {
-	static_assert(LPR >= 2 && (C == 8 || C == 12), "the last lane's window needs the chunk before it");
+	static_assert(LPR >= 2 && (C == 4 || C == 8 || C == 12), "the last lane's window needs the chunk before it");
 	uint32_t d[C / 4 + 1];
 	__device__ __forceinline__ void load(const uint8_t *base, uint32_t off, bool last_lane_of_row)
 	{
@@ -251,7 +251,9 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
 	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
 	// (fewer L1 accesses but twice the lane loads: 32x32 0.58 -> 0.62, 32x24 0.43 -> 0.55).
-	constexpr bool OVERLAP = C == 8 && LPR >= 2 && (WAYS == 4 ? (LOOP || U >= 4) : LOOP);
+	// 4-byte chunks (12-, 20-, 28-wide ...): the same with 8-byte aligned loads -- a misaligned dword load costs the L1 four
+	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
+	constexpr bool OVERLAP = (C == 8 || C == 4) && LPR >= 2 && (WAYS == 4 ? (LOOP || U >= 4) : (LOOP || C == 4));
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
