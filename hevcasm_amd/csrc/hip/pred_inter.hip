@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 						else
 						{
 							u32x2 v; v.x = px[0]; v.y = px[NDW - 1];
-							reinterpret_cast<U2 *>(out)->v = v;
+							// written once and never read back: streaming store (uni 8-tap -2 % over the 24 PU sizes, 16x16 -7 %;
+							// chroma bi -7 %; nothing slower: profiles/r01_pred_ablation.txt)
+							__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
 						}
 					}
 					else
