@@ -162,9 +162,14 @@ template <int C, int LPR> struct AlignedRefChunk
 // 32 rows), where the same row costs two accesses when it is loaded at its byte address and is misaligned.
 // A row's last lane whose chunk is aligned would read the dword past the row, which may lie outside the plane: it
 // loads the dword BEFORE its chunk instead (inside the row, LPR >= 2) and uses the upper part.
+// One lane to a row (LPR == 1, 8-wide blocks): there is no chunk before the lane's own, so the flag the caller passes is
+// not "last lane of the row" but "this row has the highest address of the block": every other row may read the 4 bytes
+// past its end (the next row up lies beyond them), and the highest one reads the 4 bytes before its start (the row below
+// lies before them) -- both inside the plane as long as rows are at least 8 bytes apart, which the launcher checks
+// (closer rows get the TIGHT kernels, which load at the byte address).
 template <int C, int LPR> struct OverlapRefChunk
 {
-	static_assert(LPR >= 2 && (C == 4 || C == 8 || C == 12), "the last lane's window needs the chunk before it");
+	static_assert(C == 4 || C == 8 || C == 12, "chunk + one dword must be a load width");
 	uint32_t d[C / 4 + 1];
 	__device__ __forceinline__ void load(const uint8_t *base, uint32_t off, bool last_lane_of_row)
 	{
@@ -188,7 +193,8 @@ template <int C, int LPR> struct OverlapRefChunk
 
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 // LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
-template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP>
+// TIGHT: the reference rows of an 8-wide block are less than 8 bytes apart (see OverlapRefChunk, one lane to a row)
+template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
 __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
@@ -254,6 +260,10 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// 4-byte chunks (12-, 20-, 28-wide ...): the same with 8-byte aligned loads -- a misaligned dword load costs the L1 four
 	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
 	constexpr bool OVERLAP = (C == 8 || C == 4) && LPR >= 2 && (WAYS == 4 ? (LOOP || U >= 4) : (LOOP || C == 4));
+	// 8-wide blocks (one lane to a row), single trip: the same aligned 12-byte loads, see OverlapRefChunk -- 4-way 8x8
+	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
+	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
+	constexpr bool OVERLAP1 = C == 8 && LPR == 1 && !LOOP && !TIGHT;
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
 	const bool last = chunk == LPR - 1;
 
@@ -267,8 +277,10 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	constexpr bool STREAM_SRC = (W * BPW) % 128 == 0;
 	Chunk<C> s[U];
 	AlignedRefChunk<C, LPR> ra[ALIGNED ? U : 1][ALIGNED ? WAYS : 1];   // wide 4-way blocks: dword-aligned loads + funnel shift
-	OverlapRefChunk<OVERLAP ? C : 8, OVERLAP ? LPR : 2> rv[OVERLAP ? U : 1][OVERLAP ? WAYS : 1];   // 8-/12-byte chunks: overlapping aligned loads
-	Chunk<C> r[ALIGNED || OVERLAP ? 1 : U][ALIGNED || OVERLAP ? 1 : WAYS];   // everything else: loads at the byte address
+	OverlapRefChunk<OVERLAP || OVERLAP1 ? C : 8, OVERLAP || OVERLAP1 ? LPR : 2> rv[OVERLAP || OVERLAP1 ? U : 1][OVERLAP || OVERLAP1 ? WAYS : 1];   // 4-/8-byte chunks: overlapping aligned loads
+	Chunk<C> r[ALIGNED || OVERLAP || OVERLAP1 ? 1 : U][ALIGNED || OVERLAP || OVERLAP1 ? 1 : WAYS];   // everything else: loads at the byte address
+	// OVERLAP1: does slot u hold the block's highest-address row?  (single trip: this lane's row in slot u is row0 + R * u)
+	auto top_row = [&](int u) { return stride_ref > 0 ? row0 + R * u == (uint32_t)H - 1 : row0 + R * u == 0; };
 
 	// slot u <- row u of the trip `ahead` trips below the current one
 	auto fill_src = [&](int u, int ahead)
@@ -284,6 +296,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 			const uint32_t o = orf[k] + (ahead * U + u) * step_ref;
 			if constexpr (ALIGNED) ra[u][k].load_main(ref_al, o);
 			else if constexpr (OVERLAP) rv[u][k].load(ref_al, o, last);
+			else if constexpr (OVERLAP1) rv[u][k].load(ref_al, o, top_row(u));
 			else r[u][k].load(ref_al + (size_t)o);
 		}
 		if constexpr (ALIGNED)
@@ -315,6 +328,12 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 			{
 				Chunk<C> x;
 				rv[u][k].finish((orf[k] + u * step_ref) & 3u, last, x);
+				acc[k].add(s[u], x);
+			}
+			else if constexpr (OVERLAP1)
+			{
+				Chunk<C> x;
+				rv[u][k].finish((orf[k] + u * step_ref) & 3u, top_row(u), x);
 				acc[k].add(s[u], x);
 			}
 			else
@@ -390,15 +409,15 @@ struct Args
 	const uint32_t *so; const uint32_t *ro; int *out; int H; size_t n; hipStream_t st;
 };
 
-template <int W, int C, int R, int U, int WAYS, int OP> static int launch_cfg(const Args &a)
+template <int W, int C, int R, int U, int WAYS, int OP, bool TIGHT> static int launch_cfg(const Args &a)
 {
 	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
 	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
 	if (a.H == R * U)
-		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, false>), dim3(grid), dim3(kThreads), 0, a.st,
+		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, false, TIGHT>), dim3(grid), dim3(kThreads), 0, a.st,
 				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
 	else if constexpr (U <= 4)      // the deep unrolls are only ever picked for a single trip: no looping variant of them is built
-		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, true>), dim3(grid), dim3(kThreads), 0, a.st,
+		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, true, TIGHT>), dim3(grid), dim3(kThreads), 0, a.st,
 				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
 	else
 		return set_error(HEVCASM_HIP_EINVAL, "internal: single-trip configuration chosen for a multi-trip height");
@@ -406,26 +425,30 @@ template <int W, int C, int R, int U, int WAYS, int OP> static int launch_cfg(co
 }
 
 // rows per lane = H / R; take the deepest unroll that divides it
-template <int W, int C, int R, int WAYS, int OP> static int launch_rows(const Args &a)
+template <int W, int C, int R, int WAYS, int OP, bool TIGHT> static int launch_rows(const Args &a)
 {
 	const int rows_per_lane = a.H / R;
 	// one reference, 8 rows per lane: one trip of 8 (source rows first, then reference rows) instead of two trips of 4 --
 	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %
 	// (four references: 8-byte chunks only -- 16x32 -6 %, 24x32 -6 %; 64x64 and 32x64 the same either way, 48x64 +6 %)
-	if constexpr (WAYS == 1 || C <= 8) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP>(a); }
-	if constexpr (WAYS == 1) { if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP>(a); }                 // 64x48: -2 %
-	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP>(a); }    // 16x64: -10 %
-	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP>(a);
-	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP>(a);   // heights 12, 24, 48
-	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP>(a);
-	return launch_cfg<W, C, R, 1, WAYS, OP>(a);
+	if constexpr (WAYS == 1 || C <= 8) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP, TIGHT>(a); }
+	if constexpr (WAYS == 1) { if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP, TIGHT>(a); }                 // 64x48: -2 %
+	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP, TIGHT>(a); }    // 16x64: -10 %
+	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP, TIGHT>(a);
+	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP, TIGHT>(a);   // heights 12, 24, 48
+	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP, TIGHT>(a);
+	return launch_cfg<W, C, R, 1, WAYS, OP, TIGHT>(a);
 }
 
 template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 {
 	typedef Plan<W> P;
-	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP>(a);
-	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP>(a);
+	if constexpr (W == 8)
+	{
+		if (a.sr < 8 && a.sr > -8) return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, true>(a);
+	}
+	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP, false>(a);
+	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, false>(a);
 }
 
 template <int WAYS, int OP>

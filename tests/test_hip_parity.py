@@ -216,6 +216,35 @@ def test_sad_misaligned_plane_base():
             assert np.array_equal(got1, want1), (w, h, k)
 
 
+def test_sad_narrow_blocks_bottom_up_and_tight_planes():
+    """The narrow-block kernels load reference rows as aligned words wider than the row piece (sad.hip, OverlapRefChunk):
+    positive and negative strides, displacement ranges 0 / 4 / 7, and planes that hold exactly the blocks with rows
+    8 bytes apart (nothing around them to over-read) or 4 bytes apart (overlapping rows: the byte-address kernels)."""
+    from hevcasm_amd import workload as wl
+    for (w, h) in ((8, 8), (8, 16), (8, 32), (8, 4), (8, 64), (12, 16), (20, 8), (4, 8)):
+        for ways in (1, 4):
+            fam = "sad4" if ways == 4 else "sad"
+            for md in (0, 4, 7):
+                c = wl.sad_case(w, h, 37, 1000 + w + h + md, ways=ways, max_disp=md)
+                cases.assert_same("%dx%d x%d disp %d" % (w, h, ways, md), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+                c2 = dict(c)
+                c2["src_off"] = (c["src_off"].astype(np.int64) + (h - 1) * c["stride_src"]).astype(np.uint32)
+                c2["ref_off"] = (c["ref_off"].astype(np.int64) + (h - 1) * c["stride_ref"]).astype(np.uint32)
+                c2["stride_src"], c2["stride_ref"] = -c["stride_src"], -c["stride_ref"]
+                cases.assert_same("bottom-up %dx%d x%d disp %d" % (w, h, ways, md), cases.run_hip(fam, c2), cases.run_oracle(fam, c2))
+    for h in (4, 8, 16, 32):
+        for ways in (1, 4):
+            fam = "sad4" if ways == 4 else "sad"
+            n = 9
+            src, ref = wl.fill_u8(8 * h * n, 77), wl.fill_u8(8 * h * n, 78)
+            so = (np.arange(n) * 8 * h).astype(np.uint32)
+            c = dict(src=src, stride_src=8, ref=ref, stride_ref=8, src_off=so, ref_off=np.repeat(so, ways).astype(np.uint32), w=8, h=h, n=n, ways=ways)
+            cases.assert_same("tight 8x%d x%d" % (h, ways), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+            ref2 = wl.fill_u8(4 * h * n + 8, 79)
+            c = dict(src=src, stride_src=8, ref=ref2, stride_ref=4, src_off=so, ref_off=np.repeat((np.arange(n) * 4 * h).astype(np.uint32), ways), w=8, h=h, n=n, ways=ways)
+            cases.assert_same("rows 4 bytes apart 8x%d x%d" % (h, ways), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+
+
 def test_sad_offsets_at_the_top_of_the_4gib_window():
     """The SAD kernels address with base + 32-bit offset: blocks whose bytes end just below 4 GiB - 64 must come out
     right (no wrap), both planes, 1-way and 4-way, negative stride included."""
