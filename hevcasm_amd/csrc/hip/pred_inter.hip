@@ -263,20 +263,27 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	{
 		uint32_t first[TAPS - 1][NDW];
 #pragma unroll
-		for (int q = 0; q < TAPS - 1; ++q)
-		{
-			if (q < rows) rs[r].next_row(first[q]); else rs[r].zero_row(first[q]);
-		}
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].next_row(first[q]);   // rows = H + T - 1 >= T: the first T - 1 window rows always exist
 #pragma unroll
 		for (int q = 0; q < TAPS - 1; ++q)
 		{
 			rs[r].realign(first[q]);
 			rs[r].unpack(q, first[q]);
 		}
-#pragma unroll
-		for (int a = 0; a < AHEAD; ++a)      // window rows T-1 .. T-2+AHEAD; row T-1+a has ring slot a (output row a consumes it)
+		// window rows T-1 .. T-2+AHEAD; row T-1+a has ring slot a (output row a consumes it).  One branch around the whole
+		// group when the PU has that many rows (a branch around every single load keeps them from being issued back to back)
+		if (H >= AHEAD)
 		{
-			if (TAPS - 1 + a < rows) rs[r].next_row(rs[r].pending[a]); else rs[r].zero_row(rs[r].pending[a]);
+#pragma unroll
+			for (int a = 0; a < AHEAD; ++a) rs[r].next_row(rs[r].pending[a]);
+		}
+		else
+		{
+#pragma unroll
+			for (int a = 0; a < AHEAD; ++a)
+			{
+				if (a < H) rs[r].next_row(rs[r].pending[a]); else rs[r].zero_row(rs[r].pending[a]);
+			}
 		}
 	}
 
