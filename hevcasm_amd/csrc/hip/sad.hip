@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// extra tail loads and funnel shifts are pure cost.  8-byte chunks: slower too, half the lanes issue the tail load.)
 	// 8-byte chunks (16-, 24-, 40-, 56-wide): overlapping aligned loads, see OverlapRefChunk.  Same-box A/B, ms per 1 Mi
 	// blocks (profiles/r01_sad_overlap_ab.txt): 4-way 16x64 0.75 -> 0.59, 16x32 0.38 -> 0.29, 16x16 0.192 -> 0.170,
-	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41, shorter blocks unchanged; the short single-trip blocks
+	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41 (before that size became a single trip of 16), shorter blocks unchanged; the short single-trip blocks
 	// (16x12, 16x8) lose 4-10 %, they are bound by latency and the realignment is extra work, so they keep byte-address loads.
 	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
 	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
