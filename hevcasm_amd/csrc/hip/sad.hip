@@ -252,14 +252,15 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	// extra tail loads and funnel shifts are pure cost.  8-byte chunks: slower too, half the lanes issue the tail load.)
 	// 8-byte chunks (16-, 24-, 40-, 56-wide): overlapping aligned loads, see OverlapRefChunk.  Same-box A/B, ms per 1 Mi
 	// blocks (profiles/r01_sad_overlap_ab.txt): 4-way 16x64 0.75 -> 0.59, 16x32 0.38 -> 0.29, 16x16 0.192 -> 0.170,
-	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41 (before that size became a single trip of 16), shorter blocks unchanged; the short single-trip blocks
-	// (16x12, 16x8) lose 4-10 %, they are bound by latency and the realignment is extra work, so they keep byte-address loads.
+	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41, shorter blocks unchanged.
 	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
 	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
 	// (fewer L1 accesses but twice the lane loads: 32x32 0.58 -> 0.62, 32x24 0.43 -> 0.55).
 	// 4-byte chunks (12-, 20-, 28-wide ...): the same with 8-byte aligned loads -- a misaligned dword load costs the L1 four
 	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
-	constexpr bool OVERLAP = (C == 8 || C == 4) && LPR >= 2 && (WAYS == 4 ? (LOOP || U >= 4) : (LOOP || C == 4));
+	// (With the loads still alternating between source and reference rows, the short single-trip blocks lost 4-10 % to the
+	// realignment; since they issue source rows first they gain too: 4-way 16x12 0.140 -> 0.105, 16x8 0.100 -> 0.079.)
+	constexpr bool OVERLAP = (C == 8 || C == 4) && LPR >= 2;
 	// 8-wide blocks (one lane to a row), single trip: the same aligned 12-byte loads, see OverlapRefChunk -- 4-way 8x8
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
