@@ -448,8 +448,8 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	{
 		if (a.sr < 8 && a.sr > -8) return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, true>(a);
 	}
-	// four references, 16- / 24-wide, 64 rows: 8 rows in flight make it a single trip of 8 (16x64 -3 %)
-	if constexpr (WAYS == 4 && P::C == 8 && P::LPR >= 2 && P::LPR <= 4) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
+	// four references, 16x64: 8 rows in flight make it a single trip of 8 (-3 %)
+	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP, false>(a);
 	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, false>(a);
 }
