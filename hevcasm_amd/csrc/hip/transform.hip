@@ -435,6 +435,14 @@ __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 			for (int j = 0; j < 4; ++j) r[4 * i + j] = c.d[j];
 		}
 	}
+	// The prediction rows (and the offsets they hang off) are fetched now, behind the coefficients, not where the row pass
+	// needs them: left to the compiler they were issued after the column pass -- three memory round trips in a row per wave.
+	const uint8_t *pp = pred + pred_off[blk];
+	uint8_t *d = dst + dst_off[blk];
+	Chunk<N> pr[N];
+#pragma unroll
+	for (int y = 0; y < N; ++y) pr[y].load(pp + y * stride_pred);
+	__builtin_amdgcn_sched_barrier(0);
 	if (DEQUANT)
 	{
 		const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;   // 24-bit operands: v_mad_i32_i24, not v_mul_lo_u32
@@ -471,8 +479,6 @@ __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 	}
 
 	// row pass + prediction + saturate
-	const uint8_t *pp = pred + pred_off[blk];
-	uint8_t *d = dst + dst_off[blk];
 #pragma unroll
 	for (int y = 0; y < N; ++y)
 	{
@@ -481,8 +487,7 @@ __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 		for (int k = 0; k < RD; ++k) p[k] = q[k * N + y];
 		int w2[N];
 		inverse_packed<N, DST>(p, 2048, w2);
-		Chunk<N> c;
-		c.load(pp + y * stride_pred);
+		Chunk<N> c = pr[y];
 #pragma unroll
 		for (int k = 0; k < N / 4; ++k)
 		{
