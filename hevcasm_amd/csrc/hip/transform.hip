@@ -298,9 +298,24 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	int v[N], w[N];
 	uint32_t p[N / 2];
 
+	// The add stage's lane deal (below: consecutive lanes hold the SAME row of consecutive blocks) is known now, so its
+	// offsets and prediction bytes are fetched now, behind the coefficients: where the add stage uses them they would be
+	// two more memory round trips at the very end of every workgroup.
+	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
+	uint32_t blk2 = wg * BPWG + local2;
+	const bool live2 = blk2 < n_blocks;
+	if (!live2) blk2 = n_blocks - 1;
+	const uint8_t *pp = pred + pred_off[blk2] + t2 * stride_pred;
+	uint8_t *d = dst + dst_off[blk2] + t2 * stride_dst;
+	constexpr int CB = N >= 16 ? 16 : N;
+	Chunk<CB> pr[N / CB];
+
 	// row t of the coefficient block -> column-major pairs in P1 (dequantised on the way when fused)
 	// coefficients are read once: as streaming loads at 16x16 (-4 %); at 32x32 two lanes share each line and it costs 8 %
 	global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
+#pragma unroll
+	for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
+	__builtin_amdgcn_sched_barrier(0);
 	if (DEQUANT)
 	{
 		// quantize.c:53-62.  scale < 2^15 (checked by the entry point) and the levels are int16: telling the
@@ -346,10 +361,6 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// Second stage + add.  The lanes are re-dealt so that consecutive lanes hold the SAME row of
 	// consecutive blocks: with blocks in raster order their prediction / destination rows are then
 	// contiguous in memory (one 64..256-byte run per row instead of N-byte pieces a stride apart).
-	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
-	uint32_t blk2 = wg * BPWG + local2;
-	const bool live2 = blk2 < n_blocks;
-	if (!live2) blk2 = n_blocks - 1;
 	{
 		const uint32_t *row = tiles + local2 * T::DWORDS + t2 * T::S2;
 		if constexpr (N >= 8)
@@ -376,16 +387,12 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// pred + residual stays inside int16.  Hence clip8(pred + ((w) >> 12)) == sat_u8((w + (pred << 12)) >> 12)
 	// (w already carries the rounding constant; adding a multiple of 4096 commutes with the shift),
 	// which is one v_lshl_add per pixel and one v_ashr_pk_u8_i32 per two pixels.
-	const uint8_t *pp = pred + pred_off[blk2] + t2 * stride_pred;
-	uint8_t *d = dst + dst_off[blk2] + t2 * stride_dst;
-	constexpr int CB = N >= 16 ? 16 : N;
 	if (live2)
 	{
 #pragma unroll
 		for (int q = 0; q < N / CB; ++q)
 		{
-			Chunk<CB> c;
-			c.load(pp + q * CB);
+			Chunk<CB> c = pr[q];
 #pragma unroll
 			for (int k = 0; k < CB / 4; ++k)
 			{
