@@ -433,7 +433,7 @@ template <int W, int C, int R, int WAYS, int OP, bool TIGHT> static int launch_r
 	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %
 	// (four references: 8-byte chunks only -- 16x32 -6 %, 24x32 -6 %; 64x64 and 32x64 the same either way, 48x64 +6 %)
 	if constexpr (WAYS == 1 || C <= 8) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP, TIGHT>(a); }
-	if constexpr (WAYS == 1) { if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP, TIGHT>(a); }                 // 64x48: -2 %
+	if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP, TIGHT>(a);                                       // 64x48: -2 % (one and four references)
 	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP, TIGHT>(a); }    // 16x64: -10 %
 	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP, TIGHT>(a);
 	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP, TIGHT>(a);   // heights 12, 24, 48
