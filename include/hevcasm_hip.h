@@ -69,8 +69,9 @@ int hevcasm_hip_stream_synchronize(void *stream);
 /* Batched hevcasm_sad (sad.h; reference sad.h:50, C body sad.c:47-60).
  * sad[i] = SAD(src + src_off[i], ref + ref_off[i]); width, height multiples of 4 in 4..64.
  * Memory touched: the block rows themselves, and for the reference plane at most the 4-byte-aligned words that hold
- * a byte of a block row (the kernels load reference rows word-aligned and realign in registers); nothing is written
- * but sad[]. */
+ * a byte of a block row (the kernels load reference rows word-aligned and realign in registers) -- for 8-wide blocks also
+ * up to 4 bytes that lie between two rows of the same block; never anything below the lowest or above the highest
+ * word that holds a byte of the block.  Nothing is written but sad[]. */
 int hevcasm_hip_sad_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *sad,
