@@ -95,6 +95,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise HevcasmError(
                 "%s is missing: build it with `make -C hevcasm_amd/csrc` or __graft_entry__.build()" % LIB_PATH)
+        # A process must hold ONE HIP runtime.  torch ships its own libamdhip64; if this library were loaded first it
+        # would bring in /opt/rocm's, torch would then add its own, and the second one to initialise sees no device
+        # (hevcasm_hip_available() == 0 with an empty error string).  So when torch is installed it goes first and this
+        # library binds to the runtime already in the process.  A C consumer without Python is not affected.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         handle = C.CDLL(LIB_PATH)
         for table in (HIP_API, HOST_API):
             for name, (res, args) in table.items():

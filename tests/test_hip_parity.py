@@ -374,6 +374,15 @@ def test_entry_points_capture_into_a_hip_graph():
         assert np.array_equal(cases._dst_rows(dst.cpu().numpy(), ci["stride_dst"], ci["dst_off"], 8, 8), want_inv)
 
 
+def test_build_then_smoke_in_one_process():
+    """The driver may call build() and smoke() from one interpreter: the library must not be loaded before torch (two HIP
+    runtimes in one process leave the second without devices; capi.lib() orders the loads)."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "smoke OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_error_codes_not_fallbacks():
     """Arguments outside the reference's domain are refused, never silently computed."""
     import torch
