@@ -78,6 +78,12 @@ def test_search_operators_and_small_families_random_parameters():
         size = int(rng.choice([2, 4, 8]))
         c = wl.sad_case(max(size, 4), max(size, 4), int(rng.integers(1, 300)), 8200 + i) | dict(size=size)
         cases.assert_same("fuzz satd %d" % size, cases.run_hip("satd", c), cases.run_oracle("satd", c))
+        # full-amplitude random checkerboards: every Hadamard coefficient can reach 64 * 255 (the 8x8 kernel works in int16)
+        src, ref = np.asarray(c["src"]).copy(), np.asarray(c["ref"]).copy()
+        src[:] = np.where(rng.integers(0, 2, src.shape) > 0, 255, 0)
+        ref[:] = np.where(rng.integers(0, 2, ref.shape) > 0, 255, 0)
+        c2 = dict(c, src=src, ref=ref)
+        cases.assert_same("fuzz satd %d full amplitude" % size, cases.run_hip("satd", c2), cases.run_oracle("satd", c2))
     for i in range(20):
         size, n = int(rng.integers(0, 5000)), int(rng.integers(1, 12))
         span = max(size, 1) + 5
