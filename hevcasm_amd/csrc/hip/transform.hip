@@ -736,16 +736,20 @@ __global__ __launch_bounds__(kThreads) void forward32_mfma_kernel(
 		o_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_lo, o_lo, 0, 0, 0);
 		o_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_hi, o_hi, 0, 0, 0);
 
-		// two neighbouring columns per dword store: even lanes take the odd lane's value by DPP
-		int16_t *out = coeffs + (size_t)blk * 1024 + r;
+		// Two neighbouring columns per dword store, and every lane stores: for a pair of output rows (i, i + 1) the even lanes
+		// write columns (r, r + 1) of row i (the odd lane's value comes by DPP) and the odd lanes columns (r - 1, r) of row
+		// i + 1 -- 8 store instructions of 64 dwords instead of 16 of 32 (-2.7 %).
+		int16_t *out = coeffs + (size_t)blk * 1024 + (r & ~1);
 #pragma unroll
-		for (int i = 0; i < 16; ++i)
+		for (int i = 0; i < 16; i += 2)
 		{
-			const int v = ((o_hi[i] << 8) + o_lo[i]) >> S2;
-			const int next = __builtin_amdgcn_mov_dpp(v, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
-			const uint32_t both = __builtin_amdgcn_perm((uint32_t)next, (uint32_t)v, 0x05040100);
-			const int m = (i & 3) + 8 * (i >> 2) + 4 * h;
-			if (!(l & 1)) *reinterpret_cast<uint32_t *>(out + 32 * m) = both;
+			const int v0 = ((o_hi[i] << 8) + o_lo[i]) >> S2, v1 = ((o_hi[i + 1] << 8) + o_lo[i + 1]) >> S2;
+			const int from_next = __builtin_amdgcn_mov_dpp(v0, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);   // even lanes: row i, column r + 1
+			const int from_prev = __builtin_amdgcn_mov_dpp(v1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);   // odd lanes: row i + 1, column r - 1
+			const uint32_t even_pair = __builtin_amdgcn_perm((uint32_t)from_next, (uint32_t)v0, 0x05040100);
+			const uint32_t odd_pair = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)from_prev, 0x05040100);
+			const int m0 = (i & 3) + 8 * (i >> 2) + 4 * h, m1 = ((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * h;
+			*reinterpret_cast<uint32_t *>(out + 32 * ((l & 1) ? m1 : m0)) = (l & 1) ? odd_pair : even_pair;
 		}
 #pragma unroll
 		for (int i = 0; i < 8; ++i) x[i] = xn[i];
