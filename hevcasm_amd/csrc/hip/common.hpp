@@ -126,12 +126,13 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, 
 // host side -------------------------------------------------------------------------------
 
 int set_error(int code, const char *what);     // records thread-local text, returns code
-int check_device();                            // 0 or HEVCASM_HIP_ENODEV
+int check_device();                            // 0 or HEVCASM_HIP_ENODEV; the current device must be a gfx950; clears the thread's stale HIP error
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define HEVC_HIP_TRY(expr) \
 	do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hevc::set_error((int)e_, hipGetErrorString(e_)); } while (0)
 
+// check_device() at the top of the entry point has cleared any earlier error of this thread: what is found here is this launch's
 inline int launch_status(const char *kernel)
 {
 	hipError_t e = hipGetLastError();

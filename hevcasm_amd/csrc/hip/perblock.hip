@@ -65,18 +65,38 @@ struct Arena
 
 thread_local Arena g_arena;
 
-// copy a w x h byte rectangle whose top-left is `p` (row stride `stride`), with `margin_before`
-// rows/columns before it and `margin_after` after it, into the arena; returns the offset of the
-// staged top-left sample and the staged row stride.
-size_t stage_plane(Arena &a, const uint8_t *p, ptrdiff_t stride, int w, int h, int before, int after, ptrdiff_t *staged_stride)
+// copy a w x h byte rectangle whose top-left is `p` (row stride `stride`), with `before_x` columns / `before_y` rows
+// before it and `after_x` / `after_y` after it, into the arena; returns the offset of the staged top-left sample and the
+// staged row stride.  Nothing outside that rectangle is read from the caller's memory.
+size_t stage_window(Arena &a, const uint8_t *p, ptrdiff_t stride, int w, int h, int before_x, int after_x, int before_y, int after_y, ptrdiff_t *staged_stride)
 {
-	const int sw = w + before + after, sh = h + before + after;
+	const int sw = w + before_x + after_x, sh = h + before_y + after_y;
 	const ptrdiff_t ss = (sw + 15) & ~15;
 	const size_t off = a.take((size_t)ss * sh);
 	for (int y = 0; y < sh; ++y)
-		std::memcpy(a.h<uint8_t>(off) + y * ss, p + (ptrdiff_t)(y - before) * stride - before, (size_t)sw);
+		std::memcpy(a.h<uint8_t>(off) + y * ss, p + (ptrdiff_t)(y - before_y) * stride - before_x, (size_t)sw);
 	*staged_stride = ss;
-	return off + (size_t)before * ss + before;
+	return off + (size_t)before_y * ss + before_x;
+}
+
+size_t stage_plane(Arena &a, const uint8_t *p, ptrdiff_t stride, int w, int h, ptrdiff_t *staged_stride)
+{
+	return stage_window(a, p, stride, w, h, 0, 0, 0, 0, staged_stride);
+}
+
+// A prediction reference: the filter margins are staged only in a direction whose fraction is non-zero, which is what the
+// reference reads (pred_inter.c:141-228) and what the kernel reads (pred_inter.hip, Footprint).  Both references of a
+// bi-prediction get the same staged stride (the batch entry point takes one stride_ref): rows are 64 + 7 bytes at most.
+size_t stage_reference(Arena &a, const uint8_t *ref, ptrdiff_t stride_ref, int taps, int w, int h, int xFrac, int yFrac, ptrdiff_t *staged_stride)
+{
+	const int before = taps / 2 - 1, after = taps / 2;
+	const ptrdiff_t ss = 80;
+	const int bx = xFrac ? before : 0, ax = xFrac ? after : 0, by = yFrac ? before : 0, ay = yFrac ? after : 0;
+	const size_t off = a.take((size_t)ss * (h + by + ay));
+	for (int y = 0; y < h + by + ay; ++y)
+		std::memcpy(a.h<uint8_t>(off) + y * ss, ref + (ptrdiff_t)(y - by) * stride_ref - bx, (size_t)(w + bx + ax));
+	*staged_stride = ss;
+	return off + (size_t)by * ss + bx;
 }
 
 size_t stage_u32(Arena &a, uint32_t v0, uint32_t v1 = 0, uint32_t v2 = 0, uint32_t v3 = 0)
@@ -93,7 +113,7 @@ void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, 
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sr;
-	const size_t r = stage_plane(a, ref, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr);
+	const size_t r = stage_reference(a, ref, stride_ref, taps, w, h, xFrac, yFrac, &sr);
 	const ptrdiff_t sd = (w + 15) & ~15;
 	const size_t d = a.take((size_t)sd * h);
 	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)r);
@@ -111,8 +131,8 @@ void pred_bi(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, 
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sr, sr1;
-	const size_t r0 = stage_plane(a, ref0, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr);
-	const size_t r1 = stage_plane(a, ref1, stride_ref, w, h, taps / 2 - 1, taps / 2, &sr1);
+	const size_t r0 = stage_reference(a, ref0, stride_ref, taps, w, h, xFrac0, yFrac0, &sr);
+	const size_t r1 = stage_reference(a, ref1, stride_ref, taps, w, h, xFrac1, yFrac1, &sr1);
 	const ptrdiff_t sd = (w + 15) & ~15;
 	const size_t d = a.take((size_t)sd * h);
 	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)r0, (uint32_t)r1);
@@ -131,7 +151,7 @@ void inverse(int trType, int log2n, uint8_t *dst, ptrdiff_t stride_dst, const ui
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sp;
-	const size_t p = stage_plane(a, pred, stride_pred, n, n, 0, 0, &sp);
+	const size_t p = stage_plane(a, pred, stride_pred, n, n, &sp);
 	const ptrdiff_t sd = (n + 15) & ~15;
 	const size_t d = a.take((size_t)sd * n);
 	const size_t c = a.take(sizeof(int16_t) * n * n);
@@ -167,8 +187,8 @@ int hevcasm_hip1_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *re
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t ss, sr;
-	const size_t s = stage_plane(a, src, stride_src, w, h, 0, 0, &ss);
-	const size_t r = stage_plane(a, ref, stride_ref, w, h, 0, 0, &sr);
+	const size_t s = stage_plane(a, src, stride_src, w, h, &ss);
+	const size_t r = stage_plane(a, ref, stride_ref, w, h, &sr);
 	const size_t offs = stage_u32(a, (uint32_t)s, (uint32_t)r);
 	const size_t out = a.take(16);
 	Arena::check_call(hevcasm_hip_sad_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), rect, 1, a.stream), "sad");
@@ -182,9 +202,9 @@ void hevcasm_hip1_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t ss, sr = 0;
-	const size_t s = stage_plane(a, src, stride_src, w, h, 0, 0, &ss);
+	const size_t s = stage_plane(a, src, stride_src, w, h, &ss);
 	size_t r[4];
-	for (int k = 0; k < 4; ++k) r[k] = stage_plane(a, ref[k], stride_ref, w, h, 0, 0, &sr);
+	for (int k = 0; k < 4; ++k) r[k] = stage_plane(a, ref[k], stride_ref, w, h, &sr);
 	const size_t so = stage_u32(a, (uint32_t)s);
 	const size_t ro = stage_u32(a, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
 	const size_t out = a.take(16);
@@ -198,8 +218,8 @@ int hevcasm_hip1_ssd(const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sa, sb;
-	const size_t pa = stage_plane(a, srcA, stride_srcA, w, h, 0, 0, &sa);
-	const size_t pb = stage_plane(a, srcB, stride_srcB, w, h, 0, 0, &sb);
+	const size_t pa = stage_plane(a, srcA, stride_srcA, w, h, &sa);
+	const size_t pb = stage_plane(a, srcB, stride_srcB, w, h, &sb);
 	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
 	const size_t out = a.take(16);
 	Arena::check_call(hevcasm_hip_ssd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), w, h, 1, a.stream), "ssd");
@@ -213,8 +233,8 @@ static int satd1(int log2n, const uint8_t *srcA, ptrdiff_t stride_srcA, const ui
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sa, sb;
-	const size_t pa = stage_plane(a, srcA, stride_srcA, n, n, 0, 0, &sa);
-	const size_t pb = stage_plane(a, srcB, stride_srcB, n, n, 0, 0, &sb);
+	const size_t pa = stage_plane(a, srcA, stride_srcA, n, n, &sa);
+	const size_t pb = stage_plane(a, srcB, stride_srcB, n, n, &sb);
 	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
 	const size_t out = a.take(16);
 	Arena::check_call(hevcasm_hip_hadamard_satd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), log2n, 1, a.stream), "hadamard_satd");
@@ -285,7 +305,7 @@ void hevcasm_hip1_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const
 	Arena &a = g_arena;
 	a.reset();
 	ptrdiff_t sp;
-	const size_t p = stage_plane(a, pred, stride_pred, n, n, 0, 0, &sp);
+	const size_t p = stage_plane(a, pred, stride_pred, n, n, &sp);
 	const ptrdiff_t sd = (n + 15) & ~15;
 	const size_t d = a.take((size_t)sd * n);
 	const size_t r = a.take(sizeof(int16_t) * n * n);

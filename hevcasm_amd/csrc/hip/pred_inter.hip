@@ -21,8 +21,17 @@
 // neighbours' vertical results with DPP wave shifts and runs the HORIZONTAL filter with
 // v_dot2_i32_i16 on (even, even) / (odd, odd) column pairs.  A sliding window of T unpacked rows
 // lives in registers (loop unrolled by T so the slot indices are static).  ceil((W + T - 1) / 4)
-// lanes per PU, as many PUs per wave as fit.  Reads exactly the reference's window (the last
-// lane's dword is shifted left to end at the window's last byte), writes exactly W x H.
+// lanes per PU, as many PUs per wave as fit.
+//
+// Footprint.  The reference reads the filter margins only in a direction whose fraction is non-zero:
+// W x H for an integer motion vector (memcpy, pred_inter.c:141-151), (W + T - 1) x H for a horizontal-only,
+// W x (H + T - 1) for a vertical-only and (W + T - 1) x (H + T - 1) for a two-dimensional fraction
+// (pred_inter.c:154-228); its x86 bi-prediction kernels do the same per reference.  This kernel reads exactly that
+// rectangle per reference and nothing outside it: for a zero fraction the window of that direction starts at
+// the block (the tap {64} sits at filter position 0) and ends with it -- a lane whose load would pass the window's
+// last column is moved left to end there (and its bytes shifted back in registers), a row stream that
+// reaches the block's last row stays on it (the rows "below" only ever meet zero coefficients).  Blocks narrower
+// than a lane load (W < 4) with xFrac = 0 are loaded byte by byte.  Writes exactly W x H.
 // Algorithmic bytes per PU: refs * (W + T - 1)(H + T - 1) + W * H (+ 4 (1 + refs) + refs descriptor bytes).
 
 #include "common.hpp"
@@ -42,10 +51,10 @@ constexpr uint32_t pk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint
 constexpr PredTables make_pred_tables()
 {
 	constexpr int luma[4][8] = {
-		{ 0, 0, 0, 64, 0, 0, 0, 0 }, { -1, 4, -10, 58, 17, -5, 1, 0 },
+		{ 64, 0, 0, 0, 0, 0, 0, 0 } /* window starts at the block */, { -1, 4, -10, 58, 17, -5, 1, 0 },
 		{ -1, 4, -11, 40, 40, -11, 4, -1 }, { 0, 1, -5, 17, 58, -10, 4, -1 } };
 	constexpr int chroma[8][4] = {
-		{ 0, 64, 0, 0 }, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
+		{ 64, 0, 0, 0 } /* window starts at the block */, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
 		{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
 	PredTables t = {};
 	for (int f = 0; f < 4; ++f)
@@ -104,18 +113,31 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	uint32_t e[TAPS][NDW], o[TAPS][NDW];   // window slots: even / odd columns of each dword as int16 pairs
 	uint32_t pending[AHEAD][NDW];   // the AHEAD window rows whose loads are in flight (ring, slot = row % AHEAD)
 	const uint8_t *p;            // this lane's bytes of the next window row to load
-	ptrdiff_t stride;
-	uint32_t shift;              // 8 * bytes the last lane's load was moved left to stay inside the window
+	ptrdiff_t step;              // row stride while the stream moves down the window ...
+	ptrdiff_t step_last;         // ... and from the PU's last row on: the same, or 0 when yFrac == 0 (nothing below the block may be read)
+	uint32_t shift;              // 8 * bytes this lane's load was moved left to stay inside the window
+	bool bytewise;               // NARROW only: the window is narrower than a lane load (W < 4, xFrac == 0)
 	Coefs<TAPS> c;
 
-	// Issue the load of the next window row of the stream (rows are consumed strictly in order).  The
-	// registers are left exactly as loaded: touching them here -- even the realigning shift -- would make
-	// the wave wait for the load here and throw the look-ahead away (realign() is applied on use).
-	__device__ __forceinline__ void next_row(uint32_t (&d)[NDW])
+	// Issue the load of window row `i` of the stream (rows are consumed strictly in order; `i` and `last` are
+	// wave-uniform, `last` = the stream index of the PU's last row when yFrac == 0).  The registers are left
+	// exactly as loaded: touching them here -- even the realigning shift -- would make the wave wait for the
+	// load here and throw the look-ahead away (realign() is applied on use).
+	template <bool NARROW> __device__ __forceinline__ void next_row(uint32_t (&d)[NDW], int i, int last, int W)
 	{
 		if (NDW == 1)
 		{
-			d[0] = reinterpret_cast<const U1 *>(p)->v;
+			if (NARROW && bytewise)
+			{
+				uint32_t v = p[0];
+				if (W > 1) v |= (uint32_t)p[1] << 8;
+				if (W > 2) v |= (uint32_t)p[2] << 16;
+				d[0] = v;
+			}
+			else
+			{
+				d[0] = reinterpret_cast<const U1 *>(p)->v;
+			}
 		}
 		else
 		{
@@ -123,7 +145,7 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 			d[0] = v.x;
 			d[NDW - 1] = v.y;
 		}
-		p += stride;
+		p += i >= last ? step_last : step;
 	}
 	// the last lane's load was moved left to stay inside the window: move its bytes back
 	__device__ __forceinline__ void realign(uint32_t (&d)[NDW]) const
@@ -208,7 +230,7 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	}
 };
 
-template <int TAPS, int NDW, bool BI, int AHEAD>
+template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
@@ -232,15 +254,16 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	// Small launches of tall PUs are cut into 2 or 4 row segments, one wave each (neighbouring waves = the segments of
 	// one group of PUs, so the T-1 window rows two segments share come from L2): see launch_pred_ndw().
 	const int segment = (int)(wave & ((1u << log2_segments) - 1u));
+	const int H_pu = H;
 	const int y_first = segment * (H >> log2_segments);
 	H >>= log2_segments;                       // the launcher only splits heights that divide
+	// stream index of the PU's last row for a stream that starts AT row y_first (yFrac == 0).  Segments are at least 2 T rows,
+	// so only the PU's last segment ever gets there (the others' T - 1 look-ahead rows are rows of the next segment).
+	const int last_row = H_pu - 1 - y_first;
 	uint32_t pu = (wave >> log2_segments) * PPW + sub;
 	const bool in_batch = pu < n_blocks;
 	if (!in_batch) pu = n_blocks - 1;
 
-	const int window = W + TAPS - 1;                  // columns the filter reads (>= CPL is guaranteed by the launcher)
-	const int natural_end = CPL * j + CPL;
-	const int over = natural_end > window ? natural_end - window : 0;   // only the last lane: 0 .. CPL-1
 	const int cols = min(CPL, W - CPL * j);           // output columns this lane stores (<= 0: none)
 	const bool stores = in_batch && !spare && cols > 0;
 
@@ -249,10 +272,24 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	for (int r = 0; r < NREF; ++r)
 	{
 		const uint8_t *base = (r ? ref1 : ref0) + (r ? ref1_off : ref0_off)[pu];
-		rs[r].stride = stride_ref;
-		rs[r].p = base + (ptrdiff_t)(y_first - BEFORE) * stride_ref - BEFORE + CPL * j - over;
-		rs[r].shift = 8 * over;
-		rs[r].c.load((r ? frac1 : frac0)[pu]);
+		const int frac = (r ? frac1 : frac0)[pu];
+		const bool fx = (frac & 15) != 0, fy = (frac >> 4) != 0;
+		// the columns / rows the reference reads for this fraction: the filter margins only where it filters
+		const int window = fx ? W + TAPS - 1 : W;
+		const int before_x = fx ? BEFORE : 0, before_y = fy ? BEFORE : 0;
+		// A lane whose natural load [CPL j, CPL j + CPL) would pass the window's end is moved left to end there; lanes
+		// wholly beyond it (the window of a zero fraction is T - 1 columns shorter than the lane count allows for) hold
+		// nothing any stored pixel depends on with a non-zero coefficient: they load the same last CPL columns.
+		const int natural_end = CPL * j + CPL;
+		int over = natural_end > window ? natural_end - window : 0;
+		rs[r].bytewise = NARROW && window < CPL;
+		if (NARROW && window < CPL) over = CPL * j;                       // byte loads start at the block's first column
+		rs[r].p = base + (ptrdiff_t)(y_first - before_y) * stride_ref - before_x + CPL * j - over;
+		rs[r].shift = (uint32_t)min(8 * over, 32 * NDW - 8);
+		if (NARROW && window < CPL) rs[r].shift = 0;
+		rs[r].step = stride_ref;
+		rs[r].step_last = fy ? stride_ref : 0;
+		rs[r].c.load(frac);
 	}
 	uint8_t *out = dst + dst_off[pu] + (ptrdiff_t)y_first * stride_dst + CPL * j;
 	const int rows = H + TAPS - 1;                    // window rows
@@ -263,7 +300,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	{
 		uint32_t first[TAPS - 1][NDW];
 #pragma unroll
-		for (int q = 0; q < TAPS - 1; ++q) rs[r].next_row(first[q]);   // rows = H + T - 1 >= T: the first T - 1 window rows always exist
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].template next_row<NARROW>(first[q], q, last_row, W);   // rows = H + T - 1 >= T: the first T - 1 window rows always exist (a yFrac == 0 stream repeats the PU's last row)
 #pragma unroll
 		for (int q = 0; q < TAPS - 1; ++q)
 		{
@@ -275,14 +312,14 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 		if (H >= AHEAD)
 		{
 #pragma unroll
-			for (int a = 0; a < AHEAD; ++a) rs[r].next_row(rs[r].pending[a]);
+			for (int a = 0; a < AHEAD; ++a) rs[r].template next_row<NARROW>(rs[r].pending[a], TAPS - 1 + a, last_row, W);
 		}
 		else
 		{
 #pragma unroll
 			for (int a = 0; a < AHEAD; ++a)
 			{
-				if (a < H) rs[r].next_row(rs[r].pending[a]); else rs[r].zero_row(rs[r].pending[a]);
+				if (a < H) rs[r].template next_row<NARROW>(rs[r].pending[a], TAPS - 1 + a, last_row, W); else rs[r].zero_row(rs[r].pending[a]);
 			}
 		}
 	}
@@ -309,7 +346,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 					uint32_t newest[NDW];
 #pragma unroll
 					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
-					if (y + TAPS - 1 + AHEAD < rows) rs[r].next_row(rs[r].pending[i % AHEAD]);     // window row (y + AHEAD) + T - 1
+					if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], y + TAPS - 1 + AHEAD, last_row, W);     // window row (y + AHEAD) + T - 1
 					rs[r].realign(newest);
 					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
 					uint32_t ve[Stream::NX], vo[Stream::NX];
@@ -375,8 +412,12 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	}
 	const uint32_t grid = ceil_div(waves, (size_t)(kThreads / kWave));
 	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
-	hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS>), dim3(grid), dim3(kThreads), 0, st,
-			dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+	if (NDW == 1 && W < 4)   // a zero-xFrac window is narrower than the 4-byte lane load: those lanes load byte by byte
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1>), dim3(grid), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+	else
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false>), dim3(grid), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
 	return launch_status("pred_stream_kernel");
 }
 

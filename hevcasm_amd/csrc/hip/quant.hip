@@ -94,7 +94,7 @@ __global__ __launch_bounds__(kThreads) void quantize_kernel(
 // quantize.c:292-302.  A lane owns PX = min(8, N) horizontally adjacent pixels; 256 / (N * N / PX) blocks per workgroup.
 template <int N>
 __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
-	uint8_t *__restrict__ rec, ptrdiff_t stride_rec, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,   // rec may alias pred (in-place reconstruction): no __restrict__
 	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ res, uint32_t n_blocks)
 {
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 // 4x4 blocks: one lane per block (32 bytes of residual in two 16-byte loads, four row dwords in and
 // out); with one lane per ROW the address unit spent a full wave-instruction on 4 bytes per lane.
 __global__ __launch_bounds__(kThreads) void reconstruct4_lane_kernel(
-	uint8_t *__restrict__ rec, ptrdiff_t stride_rec, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,   // rec may alias pred (in-place reconstruction): no __restrict__
 	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ res, uint32_t n_blocks)
 {
@@ -187,8 +187,11 @@ extern "C" int hevcasm_hip_quantize_batch(int16_t *dst, const int16_t *src, int 
 		int n_per_block, size_t n_blocks, int *cbf, void *stream)
 {
 	if (int e = check_device()) return e;
-	// the reference asserts these (quantize.c:162-168)
-	if (scale >= 0x8000 || offset >= 0x8000 || shift < 16 || shift > 27) return set_error(HEVCASM_HIP_EINVAL, "scale/offset/shift outside the reference's domain");
+	// the reference asserts the upper bounds (quantize.c:162-168); a quantiser's scale and rounding offset are non-negative
+	// by construction (the kernel's 24-bit multiply assumes 0 <= scale < 2^15), so negative ones are refused rather than
+	// computed differently from the reference's C body
+	if (scale < 0 || scale >= 0x8000 || offset < 0 || offset >= 0x8000 || shift < 16 || shift > 27)
+		return set_error(HEVCASM_HIP_EINVAL, "scale/offset/shift outside the reference's domain (0 <= scale, offset < 0x8000; 16 <= shift <= 27)");
 	if (n_blocks == 0) return 0;
 	if (n_blocks > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks exceeds 2^32-1");
 	if (!dst || !src || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");

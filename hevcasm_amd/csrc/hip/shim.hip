@@ -41,9 +41,41 @@ static int count_devices()
 	return good;
 }
 
+// per device: -1 unknown, 0 not gfx950, 1 gfx950
+static constexpr int kMaxDevices = 64;
+static std::atomic<signed char> g_is_gfx950[kMaxDevices];
+static std::atomic<bool> g_is_init{false};
+
+static bool device_is_gfx950(int dev)
+{
+	if (dev < 0 || dev >= kMaxDevices) return is_gfx950(dev);
+	if (!g_is_init.load(std::memory_order_acquire))
+	{
+		for (int d = 0; d < kMaxDevices; ++d) g_is_gfx950[d].store(-1, std::memory_order_relaxed);
+		g_is_init.store(true, std::memory_order_release);   // racing initialisers all write the same values
+	}
+	int v = g_is_gfx950[dev].load(std::memory_order_acquire);
+	if (v < 0)
+	{
+		v = is_gfx950(dev) ? 1 : 0;
+		g_is_gfx950[dev].store((signed char)v, std::memory_order_release);
+	}
+	return v == 1;
+}
+
+// Called at the top of every entry point.  The CURRENT device of the calling thread must be a gfx950 (the code object holds
+// no other architecture).  Also drops whatever non-sticky error an earlier HIP call of this thread -- ours, the
+// application's or another library's -- left behind, so that launch_status() reports this call's launch and nothing else.
 int check_device()
 {
 	if (count_devices() <= 0) return set_error(HEVCASM_HIP_ENODEV, "no usable gfx950 (MI355X) device");
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || !device_is_gfx950(dev))
+	{
+		(void)hipGetLastError();
+		return set_error(HEVCASM_HIP_ENODEV, "the current device is not a gfx950 (MI355X): select one with hevcasm_hip_set_device()");
+	}
+	(void)hipGetLastError();
 	return 0;
 }
 
@@ -58,12 +90,13 @@ extern "C" int hevcasm_hip_available(void)
 	if (count_devices() <= 0) return 0;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess) return 0;
-	return is_gfx950(dev) ? 1 : 0;
+	return device_is_gfx950(dev) ? 1 : 0;
 }
 
 extern "C" int hevcasm_hip_set_device(int device)
 {
-	if (int e = check_device()) return e;
+	if (count_devices() <= 0) return set_error(HEVCASM_HIP_ENODEV, "no usable gfx950 (MI355X) device");
+	if (!device_is_gfx950(device)) return set_error(HEVCASM_HIP_ENODEV, "that device is not a gfx950 (MI355X)");
 	HEVC_HIP_TRY(hipSetDevice(device));
 	return 0;
 }

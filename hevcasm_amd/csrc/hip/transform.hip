@@ -277,7 +277,7 @@ template <int N> struct InverseTiles
 
 template <int N, bool DST, bool DEQUANT>
 __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
-	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,   // dst may alias pred (in-place reconstruction): no __restrict__
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 // Columns are processed two at a time in pair order so that only 2N first-pass sums are live.
 template <int N, bool DST, bool DEQUANT>
 __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
-	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ pred, ptrdiff_t stride_pred,
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,   // dst may alias pred (in-place reconstruction): no __restrict__
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {

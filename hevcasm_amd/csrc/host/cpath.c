@@ -91,23 +91,41 @@ int hevcasm_c_filter_tap(int n, int frac, int k)
 	return n == 8 ? luma[frac][k] : chroma[frac][k];
 }
 
-/* 14-bit intermediate prediction of one reference: horizontal pass at full precision into
- * int16, vertical pass >> 6 without rounding (reference pred_inter.c:506-527).  out has row
- * stride 64.  Both passes run whatever the fractions (a zero fraction is the tap {64}). */
-static void predict_14bit(int taps, int16_t *out, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
+/* First (horizontal) pass of one reference at full precision into int16 rows of stride 64: row y of `rows` is window row
+ * y - before of the plane (reference pred_inter.c:175, :506).  Memory read is the reference's and no more: the filter margins are
+ * touched only in a direction whose fraction is non-zero -- W x H for an integer vector (the reference's memcpy,
+ * pred_inter.c:141-151), (W + T - 1) x H horizontal-only, W x (H + T - 1) vertical-only (pred_inter.c:154-228).  Rows the
+ * vertical tap {64} never multiplies by anything but zero are left zero without being read. */
+static void horizontal_pass(int taps, int16_t *rows, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
 {
-	int16_t rows[(64 + 7) * 64];
 	const int before = taps / 2 - 1;
 	for (int y = 0; y < h + taps - 1; ++y)
 	{
+		if (!yFrac && (y < before || y >= before + h))
+		{
+			memset(rows + y * 64, 0, sizeof(int16_t) * (size_t)w);
+			continue;
+		}
 		const uint8_t *r = ref + (y - before) * stride_ref;
 		for (int x = 0; x < w; ++x)
 		{
-			int a = 0;
-			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, xFrac, k) * r[x + k - before];
+			int a = 64 * r[x];
+			if (xFrac)
+			{
+				a = 0;
+				for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, xFrac, k) * r[x + k - before];
+			}
 			rows[y * 64 + x] = (int16_t)a;
 		}
 	}
+}
+
+/* 14-bit intermediate prediction of one reference: horizontal pass at full precision, vertical pass >> 6 without
+ * rounding (reference pred_inter.c:506-527).  out has row stride 64.  A zero fraction is the tap {64}. */
+static void predict_14bit(int taps, int16_t *out, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
+{
+	int16_t rows[(64 + 7) * 64];
+	horizontal_pass(taps, rows, ref, stride_ref, w, h, xFrac, yFrac);
 	for (int y = 0; y < h; ++y)
 		for (int x = 0; x < w; ++x)
 		{
@@ -122,19 +140,9 @@ static void predict_14bit(int taps, int16_t *out, const uint8_t *ref, ptrdiff_t 
  * pred_inter.c:141-228) because the un-filtered direction contributes exactly a factor 64. */
 static void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
 {
-	const int before = taps / 2 - 1;
 	/* as predict_14bit, but all 12 fractional bits are kept until the single final rounding */
 	int16_t rows[(64 + 7) * 64];
-	for (int y = 0; y < h + taps - 1; ++y)
-	{
-		const uint8_t *r = ref + (y - before) * stride_ref;
-		for (int x = 0; x < w; ++x)
-		{
-			int a = 0;
-			for (int k = 0; k < taps; ++k) a += hevcasm_c_filter_tap(taps, xFrac, k) * r[x + k - before];
-			rows[y * 64 + x] = (int16_t)a;
-		}
-	}
+	horizontal_pass(taps, rows, ref, stride_ref, w, h, xFrac, yFrac);
 	for (int y = 0; y < h; ++y)
 		for (int x = 0; x < w; ++x)
 		{

@@ -3,9 +3,9 @@
  *
  * Counterpart of the reference's src/lib/hevcasm.c.  hevcasm_instruction_set_support()
  * (:99-138 there) additionally reports HEVCASM_HIP when the HIP side finds a gfx950 device.
- * hevcasm_main() (:152-186 there) runs the ten hot-path self-tests and the Hadamard SATD test
- * in the reference's order; the reference's intra-DC test belongs to a family this library
- * does not implement (out of scope) and is not run.
+ * hevcasm_main() (:152-186 there) runs the reference's twelve self-tests in the reference's order
+ * (the ten hot-path families, intra DC and Hadamard SATD), then the linear-SSD test, which the
+ * reference has (diff.c:113) but does not call from its main.
  */
 #include "hevcasm.h"
 #include "sad.h"

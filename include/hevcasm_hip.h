@@ -123,13 +123,17 @@ int hevcasm_hip_pred_intra_batch(
 /* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).
  * taps = 8 (luma, fractions 0..3, nPbW/nPbH <= 64) or 4 (chroma, fractions 0..7, <= 32).
  * frac[i] = xFrac | (yFrac << 4).  ref + ref_off[i] is the integer-pel top-left sample.
+ * Memory read per block is exactly the reference's: the filter margins (taps/2 - 1 samples before, taps/2 after) only in a
+ * direction whose fraction is non-zero -- nPbW x nPbH bytes for an integer motion vector, (nPbW + taps - 1) x nPbH for
+ * a horizontal-only, nPbW x (nPbH + taps - 1) for a vertical-only and the full window for a two-dimensional fraction.
  * Writes exactly nPbW x nPbH bytes per block. */
 int hevcasm_hip_pred_uni_8to8_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac,
 	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
 
-/* Batched hevcasm_pred_bi_8to8 (reference pred_inter.h:76; C body pred_inter.c:490-530). */
+/* Batched hevcasm_pred_bi_8to8 (reference pred_inter.h:76; C body pred_inter.c:490-530).  Memory read: as above, per
+ * reference and its own fraction pair (what the reference's x86 kernels read; its C body reads the full window always). */
 int hevcasm_hip_pred_bi_8to8_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t stride_ref,
 	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
@@ -140,7 +144,8 @@ int hevcasm_hip_pred_bi_8to8_batch(
 
 /* Batched hevcasm_inverse_transform_add (reference residual_decode.h:54; C path
  * residual_decode.c:69-413).  coeffs: n_blocks consecutive N x N int16 blocks (N = 1 <<
- * log2TrafoSize, 2..5); trType 1 = 4x4 DST.  dst may equal pred (in-place reconstruction). */
+ * log2TrafoSize, 2..5); trType 1 = 4x4 DST.  dst may equal pred with the same offsets and stride (in-place
+ * reconstruction); partially overlapping dst and pred blocks are not supported. */
 int hevcasm_hip_inverse_transform_add_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
 	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *coeffs,
@@ -170,13 +175,16 @@ int hevcasm_hip_quantize_inverse(
 	int16_t *dst, const int16_t *src, int scale, int shift, size_t n, void *stream);
 
 /* Batched hevcasm_quantize (reference quantize.h:78; quantize.c:160-186): n_blocks consecutive
- * blocks of n_per_block coefficients (16, 64, 256 or 1024); cbf[i] = OR of block i's levels. */
+ * blocks of n_per_block coefficients (16, 64, 256 or 1024); cbf[i] = OR of block i's levels.
+ * Domain: 0 <= scale < 0x8000, 0 <= offset < 0x8000, 16 <= shift <= 27 (the reference asserts the upper bounds,
+ * quantize.c:162-168; negative scale / offset are refused with HEVCASM_HIP_EINVAL). */
 int hevcasm_hip_quantize_batch(
 	int16_t *dst, const int16_t *src, int scale, int shift, int offset,
 	int n_per_block, size_t n_blocks, int *cbf, void *stream);
 
 /* Batched hevcasm_quantize_reconstruct (reference quantize.h:99; quantize.c:292-302):
- * res holds n_blocks consecutive nCbS x nCbS int16 blocks (nCbS = 4, 8, 16 or 32). */
+ * res holds n_blocks consecutive nCbS x nCbS int16 blocks (nCbS = 4, 8, 16 or 32).  rec may equal pred with the
+ * same offsets and stride (in-place reconstruction). */
 int hevcasm_hip_quantize_reconstruct_batch(
 	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
 	const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res,

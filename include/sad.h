@@ -18,20 +18,16 @@ extern "C" {
 /* SAD of a width x height block; rect = HEVCASM_RECT(width, height).  Returns the sum. */
 typedef int hevcasm_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, uint32_t rect);
 
-/* Eleven named sizes, then one slot shared by every other size. */
+/* The block sizes that own a table slot, in slot order (the order is ABI: reference sad.h:54-64). */
+#define HEVCASM_SAD_NAMED_SIZES(X) \
+	X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(32, 16) X(16, 32) X(16, 16) X(16, 8) X(8, 16) X(8, 8) X(8, 4)
+
+/* One pointer per named size -- fields sad64x64, sad64x32, ... sad8x4 -- then one slot shared by every other size. */
 typedef struct
 {
-	hevcasm_sad *sad64x64;
-	hevcasm_sad *sad64x32;
-	hevcasm_sad *sad32x64;
-	hevcasm_sad *sad32x32;
-	hevcasm_sad *sad32x16;
-	hevcasm_sad *sad16x32;
-	hevcasm_sad *sad16x16;
-	hevcasm_sad *sad16x8;
-	hevcasm_sad *sad8x16;
-	hevcasm_sad *sad8x8;
-	hevcasm_sad *sad8x4;
+#define X(w, h) hevcasm_sad *sad ## w ## x ## h;
+	HEVCASM_SAD_NAMED_SIZES(X)
+#undef X
 	hevcasm_sad *sadGeneric;
 }
 hevcasm_table_sad;
@@ -39,18 +35,9 @@ hevcasm_table_sad;
 /* Address of the table slot serving a width x height block. */
 static inline hevcasm_sad **hevcasm_get_sad(hevcasm_table_sad *table, int width, int height)
 {
-	const int r = HEVCASM_RECT(width, height);
-	if (r == HEVCASM_RECT(64, 64)) return &table->sad64x64;
-	if (r == HEVCASM_RECT(64, 32)) return &table->sad64x32;
-	if (r == HEVCASM_RECT(32, 64)) return &table->sad32x64;
-	if (r == HEVCASM_RECT(32, 32)) return &table->sad32x32;
-	if (r == HEVCASM_RECT(32, 16)) return &table->sad32x16;
-	if (r == HEVCASM_RECT(16, 32)) return &table->sad16x32;
-	if (r == HEVCASM_RECT(16, 16)) return &table->sad16x16;
-	if (r == HEVCASM_RECT(16, 8)) return &table->sad16x8;
-	if (r == HEVCASM_RECT(8, 16)) return &table->sad8x16;
-	if (r == HEVCASM_RECT(8, 8)) return &table->sad8x8;
-	if (r == HEVCASM_RECT(8, 4)) return &table->sad8x4;
+#define X(w, h) if (width == w && height == h) return &table->sad ## w ## x ## h;
+	HEVCASM_SAD_NAMED_SIZES(X)
+#undef X
 	return &table->sadGeneric;
 }
 

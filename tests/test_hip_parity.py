@@ -395,10 +395,43 @@ def test_error_codes_not_fallbacks():
     assert L.hevcasm_hip_sad_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), capi.rect(16, 68), 1, None) == capi.EINVAL
     assert L.hevcasm_hip_inverse_transform_add_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), p, 1, 3, 1, None) == capi.EINVAL
     assert L.hevcasm_hip_quantize_batch(p, p, 0x8000, 20, 14, 16, 1, o.data_ptr(), None) == capi.EINVAL
+    assert L.hevcasm_hip_quantize_batch(p, p, -1, 20, 14, 16, 1, o.data_ptr(), None) == capi.EINVAL      # negative scale / offset: refused,
+    assert L.hevcasm_hip_quantize_batch(p, p, 51, 20, -14, 16, 1, o.data_ptr(), None) == capi.EINVAL     # not computed differently from the C body
     assert L.hevcasm_hip_pred_uni_8to8_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), p, 6, 8, 8, 1, None) == capi.EINVAL
     assert b"hevcasm_hip error" in L.hevcasm_hip_last_error()
     # empty batches are legal no-ops
     assert L.hevcasm_hip_sad_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), capi.rect(16, 16), 0, None) == 0
+
+
+def test_in_place_reconstruction():
+    """dst == pred with the same offsets and stride (include/hevcasm_hip.h promises it): inverse transform + add of every
+    size, the fused dequantising form and hevcasm_quantize_reconstruct write over the prediction they read."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    for tr_type, log2n in ((1, 2), (0, 2), (0, 3), (0, 4), (0, 5)):
+        c = wl.inverse_case(tr_type, log2n, 300, 31 + log2n)
+        c["dst_off"], c["stride_dst"], c["dst_bytes"] = c["pred_off"], c["stride_pred"], c["pred"].size
+        want = cases.run_oracle("inverse", c)
+        s = 1 << log2n
+        plane = B.u8(c["pred"].copy())
+        B.inverse_transform_add(plane, c["stride_pred"], plane, c["stride_pred"], B.off32(c["pred_off"]), B.off32(c["pred_off"]), B.i16(c["coeffs"]), tr_type, log2n)
+        torch.cuda.synchronize()
+        cases.assert_same("inverse_in_place_%d_%d" % (tr_type, log2n), (cases._dst_rows(plane.cpu().numpy(), c["stride_pred"], c["pred_off"], s, s),), want)
+        c2 = dict(c, scale=51, shift=14)
+        want = cases.run_oracle("dequant_inverse", c2)
+        plane = B.u8(c["pred"].copy())
+        B.dequant_inverse_transform_add(plane, c["stride_pred"], plane, c["stride_pred"], B.off32(c["pred_off"]), B.off32(c["pred_off"]), B.i16(c["coeffs"]), 51, 14, tr_type, log2n)
+        torch.cuda.synchronize()
+        cases.assert_same("dequant_inverse_in_place_%d_%d" % (tr_type, log2n), (cases._dst_rows(plane.cpu().numpy(), c["stride_pred"], c["pred_off"], s, s),), want)
+    for name, family, c in cases.quant_cases():
+        if family != "recon":
+            continue
+        c = dict(c, rec_off=c["pred_off"], stride_rec=c["stride_pred"], rec_bytes=c["pred"].size)
+        want = cases.run_oracle("recon", c)
+        plane = B.u8(c["pred"].copy())
+        B.quantize_reconstruct(plane, c["stride_pred"], plane, c["stride_pred"], B.off32(c["pred_off"]), B.off32(c["pred_off"]), B.i16(c["res"]), c["ncbs"])
+        torch.cuda.synchronize()
+        cases.assert_same(name + "_in_place", (cases._dst_rows(plane.cpu().numpy(), c["stride_pred"], c["pred_off"], c["ncbs"], c["ncbs"]),), want)
 
 
 def test_selftest_hip_column():
