@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhevcasm_hip.so")
+# HEVCASM_HIP_LIB: another build of the same library (kernel A/B measurements, tools/ab.py); never set in tests or bench.py
+LIB_PATH = os.environ.get("HEVCASM_HIP_LIB") or os.path.join(_HERE, "lib", "libhevcasm_hip.so")
 EXE_PATH = os.path.join(_HERE, "lib", "hevcasm")
 
 EINVAL = -1

@@ -85,6 +85,12 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
 	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+__device__ __forceinline__ uint32_t med3_u32(uint32_t x, uint32_t lo, uint32_t hi)
+{
+	uint32_t r;
+	asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+	return r;
+}
 // value held by lane + 1 (lane 63 receives 0)
 __device__ __forceinline__ uint32_t from_next_lane(uint32_t v)
 {
@@ -112,19 +118,21 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	static constexpr int NX = NDW + (TAPS == 8 ? 2 : 1);   // column groups the horizontal pass reads
 	uint32_t e[TAPS][NDW], o[TAPS][NDW];   // window slots: even / odd columns of each dword as int16 pairs
 	uint32_t pending[AHEAD][NDW];   // the AHEAD window rows whose loads are in flight (ring, slot = row % AHEAD)
-	const uint8_t *p;            // this lane's bytes of the next window row to load
-	ptrdiff_t step;              // row stride while the stream moves down the window ...
-	ptrdiff_t step_last;         // ... and from the PU's last row on: the same, or 0 when yFrac == 0 (nothing below the block may be read)
+	const uint8_t *plane;        // the reference plane (wave-uniform: the loads are global_load v, v_offset, s[plane])
+	uint32_t off;                // this lane's bytes of the next window row to load, as an offset from `plane`
+	uint32_t lo, hi;             // the stream's row offsets stay inside [lo, hi]: the block's own rows when yFrac == 0
+	                             // (nothing above or below the block may be read), everything otherwise
 	uint32_t shift;              // 8 * bytes this lane's load was moved left to stay inside the window
 	bool bytewise;               // NARROW only: the window is narrower than a lane load (W < 4, xFrac == 0)
 	Coefs<TAPS> c;
 
-	// Issue the load of window row `i` of the stream (rows are consumed strictly in order; `i` and `last` are
-	// wave-uniform, `last` = the stream index of the PU's last row when yFrac == 0).  The registers are left
-	// exactly as loaded: touching them here -- even the realigning shift -- would make the wave wait for the
-	// load here and throw the look-ahead away (realign() is applied on use).
-	template <bool NARROW> __device__ __forceinline__ void next_row(uint32_t (&d)[NDW], int i, int last, int W)
+	// Issue the load of the next window row of the stream (rows are consumed strictly in order) and step to the one after:
+	// one add and one v_med3_u32 -- a stream with yFrac == 0 that has reached the block's last row stays on it.  The
+	// registers are left exactly as loaded: touching them here -- even the realigning shift -- would make the wave wait for
+	// the load here and throw the look-ahead away (realign() is applied on use).
+	template <bool NARROW> __device__ __forceinline__ void next_row(uint32_t (&d)[NDW], uint32_t step, int W)
 	{
+		const uint8_t *p = plane + (size_t)off;
 		if (NDW == 1)
 		{
 			if (NARROW && bytewise)
@@ -145,7 +153,7 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 			d[0] = v.x;
 			d[NDW - 1] = v.y;
 		}
-		p += i >= last ? step_last : step;
+		off = med3_u32(off + step, lo, hi);
 	}
 	// the last lane's load was moved left to stay inside the window: move its bytes back
 	__device__ __forceinline__ void realign(uint32_t (&d)[NDW]) const
@@ -267,11 +275,13 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	const int cols = min(CPL, W - CPL * j);           // output columns this lane stores (<= 0: none)
 	const bool stores = in_batch && !spare && cols > 0;
 
+	// Every byte a block touches lies within 4 GiB above its plane's base pointer (hevcasm_hip.h), so rows are addressed as
+	// uniform base + 32-bit lane offset: one VGPR and one add per row and plane instead of a 64-bit pointer.
+	const uint32_t step_ref = (uint32_t)stride_ref, step_dst = (uint32_t)stride_dst;
 	Stream rs[NREF];
 #pragma unroll
 	for (int r = 0; r < NREF; ++r)
 	{
-		const uint8_t *base = (r ? ref1 : ref0) + (r ? ref1_off : ref0_off)[pu];
 		const int frac = (r ? frac1 : frac0)[pu];
 		const bool fx = (frac & 15) != 0, fy = (frac >> 4) != 0;
 		// the columns / rows the reference reads for this fraction: the filter margins only where it filters
@@ -284,14 +294,16 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 		int over = natural_end > window ? natural_end - window : 0;
 		rs[r].bytewise = NARROW && window < CPL;
 		if (NARROW && window < CPL) over = CPL * j;                       // byte loads start at the block's first column
-		rs[r].p = base + (ptrdiff_t)(y_first - before_y) * stride_ref - before_x + CPL * j - over;
-		rs[r].shift = (uint32_t)min(8 * over, 32 * NDW - 8);
-		if (NARROW && window < CPL) rs[r].shift = 0;
-		rs[r].step = stride_ref;
-		rs[r].step_last = fy ? stride_ref : 0;
+		rs[r].plane = r ? ref1 : ref0;
+		const uint32_t first = (r ? ref1_off : ref0_off)[pu] + (uint32_t)(y_first - before_y) * step_ref + (uint32_t)(CPL * j - over - before_x);
+		const uint32_t last = first + (uint32_t)last_row * step_ref;
+		rs[r].off = first;
+		rs[r].lo = fy ? 0u : min(first, last);
+		rs[r].hi = fy ? 0xffffffffu : max(first, last);
+		rs[r].shift = (NARROW && window < CPL) ? 0u : (uint32_t)min(8 * over, 32 * NDW - 8);
 		rs[r].c.load(frac);
 	}
-	uint8_t *out = dst + dst_off[pu] + (ptrdiff_t)y_first * stride_dst + CPL * j;
+	uint32_t out_off = dst_off[pu] + (uint32_t)y_first * step_dst + (uint32_t)(CPL * j);
 	const int rows = H + TAPS - 1;                    // window rows
 
 	// prologue: window rows 0 .. T-2 into slots 0 .. T-2, and the load of row T-1 in flight
@@ -300,7 +312,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	{
 		uint32_t first[TAPS - 1][NDW];
 #pragma unroll
-		for (int q = 0; q < TAPS - 1; ++q) rs[r].template next_row<NARROW>(first[q], q, last_row, W);   // rows = H + T - 1 >= T: the first T - 1 window rows always exist (a yFrac == 0 stream repeats the PU's last row)
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].template next_row<NARROW>(first[q], step_ref, W);   // rows = H + T - 1 >= T: the first T - 1 window rows always exist (a yFrac == 0 stream repeats the PU's last row)
 #pragma unroll
 		for (int q = 0; q < TAPS - 1; ++q)
 		{
@@ -312,14 +324,14 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 		if (H >= AHEAD)
 		{
 #pragma unroll
-			for (int a = 0; a < AHEAD; ++a) rs[r].template next_row<NARROW>(rs[r].pending[a], TAPS - 1 + a, last_row, W);
+			for (int a = 0; a < AHEAD; ++a) rs[r].template next_row<NARROW>(rs[r].pending[a], step_ref, W);
 		}
 		else
 		{
 #pragma unroll
 			for (int a = 0; a < AHEAD; ++a)
 			{
-				if (a < H) rs[r].template next_row<NARROW>(rs[r].pending[a], TAPS - 1 + a, last_row, W); else rs[r].zero_row(rs[r].pending[a]);
+				if (a < H) rs[r].template next_row<NARROW>(rs[r].pending[a], step_ref, W); else rs[r].zero_row(rs[r].pending[a]);
 			}
 		}
 	}
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 					uint32_t newest[NDW];
 #pragma unroll
 					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
-					if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], y + TAPS - 1 + AHEAD, last_row, W);     // window row (y + AHEAD) + T - 1
+					if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);     // window row (y + AHEAD) + T - 1
 					rs[r].realign(newest);
 					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
 					uint32_t ve[Stream::NX], vo[Stream::NX];
@@ -369,6 +381,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 				}
 				if (stores)
 				{
+					uint8_t *out = dst + (size_t)out_off;
 					if (cols >= CPL)
 					{
 						if (NDW == 1) reinterpret_cast<U1 *>(out)->v = px[0];
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 						for (int b = 0; b < cols; ++b) out[b] = (uint8_t)(px[b >> 2] >> (8 * (b & 3)));
 					}
 				}
-				out += stride_dst;
+				out_off += step_dst;
 			}
 		}
 	}

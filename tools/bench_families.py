@@ -28,11 +28,13 @@ def report(name, n, bytes_per_block, ms, **kw):
                           algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK, 4), **kw)), flush=True)
 
 
-def bench_pred(frames=64):
+def bench_pred(frames=64, only=None):
     """Config #3: 1920x1080 luma tiled by each PU size (chroma planes 960x540, 4-tap), all phases,
     `frames` frames per launch so that the launch is far above the launch floor."""
     for taps, fw, fh in ((8, 1920, 1080), (4, 960, 540)):
         for (w, h) in wl.PU_SIZES:
+            if only and (w, h) not in only:
+                continue
             pw, ph = w * taps // 8, h * taps // 8
             n = (fw // pw) * (fh // ph) * frames
             for bi in (False, True):
@@ -226,6 +228,9 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
+        if w == "predq":                                  # a quick subset of PU sizes for same-box A/B runs (tools/ab.py)
+            bench_pred(only=((8, 8), (16, 16), (32, 32), (64, 64), (16, 64), (64, 16), (8, 32)))
+            continue
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
