@@ -19,6 +19,8 @@
 
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace hevc {
 
 // Lane mapping of one W x H block: LPR = W / C lanes side by side cover a row, R such rows are
@@ -94,6 +96,26 @@ template <int C, int OP> struct Acc
 	}
 	__device__ __forceinline__ uint32_t value() const { return OP == OP_SAD ? a : a - 2u * b; }
 };
+
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi)
+{
+	int r;
+	asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "v"(hi));
+	return r;
+}
+
+// Sum over the 64 lanes of a wave with DPP adds (no LDS crossbar): quad, row of 16, then the row broadcasts; the total
+// is in lane 63.
+__device__ __forceinline__ uint32_t wave_sum_to_lane63(uint32_t v)
+{
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e /* quad_perm [2,3,0,1] */, 0xf, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xe, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xc, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+	v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+	return v;
+}
 
 // Sum `v` over the LPR x R lanes of a block (lane j = r * LPR + c); valid in the block's lane 0.
 template <int LPR, int R> __device__ __forceinline__ uint32_t reduce_block(uint32_t v)
@@ -194,26 +216,20 @@ template <int C, int LPR> struct OverlapRefChunk
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 // LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
 // TIGHT: the reference rows of an 8-wide block are less than 8 bytes apart (see OverlapRefChunk, one lane to a row)
+// One wave's work: lane `lane` belongs to sub-block lane / LPB of the wave and handles block `blk` (every lane of a
+// sub-block is given the same, valid, block index); only the leaders of `live` sub-blocks store.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
-__global__ __launch_bounds__(kThreads) void block_cost_kernel(
+__device__ __forceinline__ void block_cost_body(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, int H, uint32_t n_blocks)
+	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live)
 {
 	typedef Tiling<W, C, R> T;
 	constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
 
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
-	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t sub = lane / LPB, j = lane - sub * LPB;
 	const uint32_t row0 = j / LPR, chunk = j - row0 * LPR;
-	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
-	// block so that every lane executes the same loads and shuffles; only real leaders store.
-	uint32_t blk = wave * BPW + (sub < (uint32_t)BPW ? sub : BPW - 1);
-	const bool live = sub < (uint32_t)BPW && blk < n_blocks;
-	if (blk >= n_blocks) blk = n_blocks - 1;
 
 	// descriptor loads first: independent, one memory round trip
 	const uint32_t so = src_off[blk];
@@ -404,16 +420,275 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	}
 }
 
+template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
+__global__ __launch_bounds__(kThreads) void block_cost_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
+	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+	int *__restrict__ out, int H, uint32_t n_blocks)
+{
+	typedef Tiling<W, C, R> T;
+	constexpr int LPB = T::LPB, BPW = T::BPW;
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t sub = lane / LPB;
+	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
+	// block so that every lane executes the same loads and shuffles; only real leaders store.
+	uint32_t blk = wave * BPW + (sub < (uint32_t)BPW ? sub : BPW - 1);
+	const bool live = sub < (uint32_t)BPW && blk < n_blocks;
+	if (blk >= n_blocks) blk = n_blocks - 1;
+	block_cost_body<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live);
+}
+
+// ---- 4-way SAD of wide blocks whose candidates lie close together: the union window goes through LDS ----------------
+//
+// The four candidates of a motion-search step usually overlap: in config #2 of the benchmark they all lie within +-7
+// pixels of one position.  The generic kernel above loads each candidate's rows separately -- 1 + 4 x 2.5 vector-L1
+// accesses per 64-byte block row -- and runs at the L1's access rate, not at HBM's.  This kernel
+// loads the candidates' UNION window once (at most (H + 16) rows of (W + 16 + 3) bytes, dword-aligned 16-byte lane
+// loads: about 2.3 accesses per window row), parks it in LDS, and lets each lane read its 16 (12) bytes of every
+// candidate row from there (dword reads + v_alignbyte_b32, as the generic kernel realigns its global loads).
+//   * one block per wave, 4 lanes to a block row, 16 rows per trip; the descriptors are wave-uniform, so they arrive
+//     by scalar loads (not queued behind other waves' row loads) and the window geometry is scalar arithmetic;
+//   * a block qualifies when all four candidates lie within 16 rows and 16 columns of each other (decided from the
+//     offsets alone: offset differences are split into rows and columns with the row stride); for any other block the
+//     wave writes the sentinel -1 (no SAD is negative) into its four results and block_cost_rescan_kernel, launched
+//     right behind on the same stream, computes it with the generic code;
+//   * memory touched: exactly the 4-byte-aligned words that hold a byte of some candidate's row -- per window row the
+//     staged range is the hull of the candidates that cover this row (they overlap horizontally, so the hull has no
+//     holes), and a lane whose 16 bytes would stick out of it is moved inside (its neighbour's bytes, stored twice).
+template <int W, int H>
+__global__ __launch_bounds__(kThreads) void sad4_window_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
+	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+	int *__restrict__ out, uint32_t n_blocks, uint32_t inv_stride /* floor(2^32 / stride_ref) + 1 */)
+{
+	constexpr int C = W == 48 ? 12 : 16;             // bytes per lane and row in the compute phase: 4 lanes to a row
+	constexpr int CD = C / 4;
+	constexpr int SPAN = 16;                          // candidates at most this far apart, in rows and in columns
+	constexpr int WIN_DW = (W + SPAN + 3 + 3) / 4;    // dwords of the widest window row (3 more bytes of misalignment): 21, 17
+	constexpr int LROW = W == 64 ? 21 : 20;           // LDS row pitch in dwords (the compute phase's reads: 2-way / no bank conflicts)
+	constexpr int LPRW = (WIN_DW + 3) / 4;            // staging: lanes (16 bytes each) per window row: 6, 5
+	constexpr int ROWS = H + SPAN;
+	constexpr int NI = (ROWS * LPRW + kWave - 1) / kWave;   // staging instructions: lane l of instruction i holds piece 64 i + l of the window
+	constexpr int TRIPS = H / 16;
+	static_assert(H % 16 == 0 && WIN_DW <= LROW && LPRW * 4 >= WIN_DW, "window row must fit its LDS row and its staging lanes");
+	__shared__ uint32_t lds_all[(kThreads / kWave) * ROWS * LROW];
+
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const uint32_t wave_in_wg = threadIdx.x >> 6;
+	const uint32_t blk = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + wave_in_wg);
+	if (blk >= n_blocks) return;
+	const uint32_t lane = threadIdx.x & 63;
+	uint32_t *lds = lds_all + wave_in_wg * (ROWS * LROW);
+
+	// descriptors and window geometry: wave-uniform (scalar loads, scalar arithmetic)
+	const uint32_t ref_mis = (uint32_t)(reinterpret_cast<uintptr_t>(ref) & 3u);
+	const uint8_t *const ref_al = ref - ref_mis;
+	const uint32_t sr32 = (uint32_t)stride_ref, ss32 = (uint32_t)stride_src;
+	const uint32_t so = src_off[blk];
+	uint32_t o[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) o[k] = ref_off[(size_t)blk * 4 + k] + ref_mis;
+	const uint32_t m = min(min(o[0], o[1]), min(o[2], o[3]));
+	bool close = true;
+	int dx[4]; uint32_t Y[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+	{
+		const uint32_t d = o[k] - m;                              // candidate k lies d bytes above the lowest one:
+		close = close && d <= (uint32_t)SPAN * sr32 + 32u;       // dy rows and dx columns, dx in [-32, stride - 32)
+		const uint32_t nn = d + 32u;
+		uint32_t q = __umulhi(nn, inv_stride);                   // nn / stride, or one more
+		int r = (int)(nn - q * sr32);
+		if (r < 0) { q -= 1; r += (int)sr32; }
+		dx[k] = r - 32;
+		Y[k] = q;
+	}
+	const int xmin = min(min(dx[0], dx[1]), min(dx[2], dx[3])), xmax = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
+	const uint32_t ymax = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
+	close = close && (xmax - xmin) <= SPAN && ymax <= (uint32_t)SPAN;
+	if (!close)
+	{
+		if (lane == 0)
+		{
+			u32x4 v; v.x = v.y = v.z = v.w = 0xffffffffu;
+			reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
+		}
+		return;
+	}
+	const uint32_t wo = m + (uint32_t)xmin;          // byte offset (from ref_al) of the window's top-left corner; modulo 2^32 like everything below
+	const uint32_t wbase = wo & ~3u;
+	uint32_t X[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) X[k] = (uint32_t)(dx[k] - xmin) + (wo & 3u);     // 0 .. 19
+	const uint32_t last_row = (uint32_t)H + ymax - 1u;
+	// The lowest and the highest aligned word that hold a byte of any candidate: every staged piece is moved inside
+	// [a_min, a_max] (its LDS position moves with it), so nothing outside the candidates' own address range is ever read.
+	const uint32_t a_min = m & ~3u;
+	const uint32_t a_max = (max(max(o[0], o[1]), max(o[2], o[3])) + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1)) & ~3u;
+
+	// ---- stage the window: global -> registers (every load in flight before anything else), source rows, registers -> LDS.
+	// Lane l of instruction i holds piece 64 i + l of the window (LPRW pieces of 16 bytes per row; the last piece of a row
+	// is pulled in to end with the LDS row).  No lane is ever switched off: a piece past the window's last row repeats that
+	// row, a piece below a_min / above a_max repeats its neighbour (same bytes to the same LDS words).
+	u32x4 st[NI];
+	uint32_t spos[NI];
+#pragma unroll
+	for (int i = 0; i < NI; ++i)
+	{
+		const uint32_t piece = (uint32_t)(i * kWave) + lane, srow = piece / LPRW;
+		const uint32_t scol = min((piece - srow * LPRW) * 4u, (uint32_t)(LROW - 4));
+		const uint32_t row = min(srow, last_row);
+		// the piece's address relative to a_min (a small number of either sign on row 0, positive below it: stride <= 2^20),
+		// moved inside [0, a_max - 12 - a_min]; rows are word-aligned with each other (stride % 4 == 0: window_stride_ok)
+		const int rel = (int)(__umul24(row, sr32) + 4u * scol) + (int)(wbase - a_min);
+		const int rel_in = med3_i32(rel, 0, (int)(a_max - 12u - a_min));
+		const uint32_t a = a_min + (uint32_t)rel, a_in = a_min + (uint32_t)rel_in;
+		st[i] = reinterpret_cast<const U4 *>(ref_al + (size_t)a_in)->v;
+		spos[i] = __umul24(row, (uint32_t)LROW) + scol + ((uint32_t)(a_in - a) >> 2);     // (a_in - a) is a small multiple of 4 of either sign: the sum is exact modulo 2^30
+	}
+	const uint32_t y0 = lane >> 2, j = lane & 3u;
+	Chunk<C> s[TRIPS];
+#pragma unroll
+	for (int t = 0; t < TRIPS; ++t)
+	{
+		const uint8_t *p = src + (size_t)(so + ((uint32_t)(t * 16) + y0) * ss32 + j * (uint32_t)C);
+		if (W == 64) s[t].load_stream(p); else s[t].load(p);       // as the generic kernel: streaming where waves cover whole lines
+	}
+	__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+	for (int i = 0; i < NI; ++i)
+	{
+		uint32_t *d = lds + (spos[i] & 0x3fffffffu);
+		d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
+	}
+	// the wave's own LDS writes are in order before its reads (one wave, one LDS queue); keep the compiler from reordering them
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+	// ---- four SADs per source chunk, candidates read from LDS (the trip's row offset is an immediate of the ds_read)
+	uint32_t acc[4] = { 0, 0, 0, 0 };
+	const uint32_t *rk[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) rk[k] = lds + (__umul24(y0 + Y[k], (uint32_t)LROW) + (X[k] >> 2) + j * (uint32_t)CD);
+#pragma unroll
+	for (int t = 0; t < TRIPS; ++t)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const uint32_t *r = rk[k] + t * 16 * LROW;
+			uint32_t w[CD + 1];
+#pragma unroll
+			for (int q = 0; q <= CD; ++q) w[q] = r[q];
+			const uint32_t sh = X[k] & 3u;
+#pragma unroll
+			for (int q = 0; q < CD; ++q)
+				acc[k] = __builtin_amdgcn_sad_u8(s[t].d[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), acc[k]);
+		}
+		__builtin_amdgcn_sched_barrier(0);    // one trip's LDS reads live at a time
+	}
+	uint32_t total[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) total[k] = wave_sum_to_lane63(acc[k]);
+	if (lane == 63)
+	{
+		u32x4 v; v.x = total[0]; v.y = total[1]; v.z = total[2]; v.w = total[3];
+		reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
+	}
+}
+
+// Second pass behind sad4_window_kernel: every wave owns a contiguous range of the batch, finds the blocks that carry the
+// sentinel and runs the generic code on them, BPW at a time.  A batch whose candidates all lay close together costs one
+// sweep over the results (4 bytes per block); a batch of far-apart candidates is computed here at the generic kernel's pace
+// (the grid is what its register budget keeps resident anyway).
+template <int W, int C, int R, int U, bool LOOP>
+__global__ __launch_bounds__(kThreads) void sad4_rescan_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
+	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+	int *out, int H, uint32_t n_blocks, uint32_t blocks_per_wave)
+{
+	typedef Tiling<W, C, R> T;
+	constexpr int LPB = T::LPB, BPW = T::BPW;
+	const uint32_t wave = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t sub = min(lane / LPB, (uint32_t)BPW - 1u);
+	const uint64_t first64 = (uint64_t)wave * blocks_per_wave;
+	if (first64 >= n_blocks) return;
+	const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)n_blocks, first64 + blocks_per_wave);
+	for (uint32_t base = first; base < last; base += kWave)
+	{
+		const uint32_t mine = base + lane;
+		const bool pending = mine < last && reinterpret_cast<const volatile int *>(out)[(size_t)mine * 4] == -1;
+		uint64_t mask = __builtin_amdgcn_ballot_w64(pending);
+		while (mask)      // wave-uniform
+		{
+			uint32_t blk = 0; bool live = false;
+			uint32_t any = 0;
+#pragma unroll
+			for (int b = 0; b < BPW; ++b)
+			{
+				if (mask)
+				{
+					const uint32_t bit = (uint32_t)__builtin_ctzll(mask);
+					mask &= mask - 1;
+					any = base + bit;
+					if (sub == (uint32_t)b) { blk = base + bit; live = true; }
+				}
+			}
+			if (!live) blk = any;       // sub-blocks left over redo a valid block and store nothing
+			live = live && lane / LPB < (uint32_t)BPW;
+			block_cost_body<W, C, R, U, 4, OP_SAD, LOOP, false>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live);
+		}
+	}
+}
+
 struct Args
 {
 	const uint8_t *src; ptrdiff_t ss; const uint8_t *ref; ptrdiff_t sr;
 	const uint32_t *so; const uint32_t *ro; int *out; int H; size_t n; hipStream_t st;
 };
 
+// strides for which sad4_window_kernel applies: its row / column split of an offset difference is exact and unambiguous, and
+// the rows of a window are word-aligned with each other (so that "the aligned words that hold a candidate's bytes" means the
+// same in every row)
+static bool window_stride_ok(ptrdiff_t sr, int W) { return sr >= W + 64 && sr <= (1 << 20) && (sr & 3) == 0; }
+
+template <int W, int C, int R, int U, bool LOOP> static int launch_window(const Args &a)
+{
+	const uint32_t inv = (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;
+	const uint32_t grid1 = ceil_div(a.n, kThreads / kWave);
+#define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM>), dim3(grid1), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
+	if (a.H == 16) WINDOW(16); else if (a.H == 32) WINDOW(32); else if (a.H == 48) WINDOW(48); else WINDOW(64);
+#undef WINDOW
+	if (int e = launch_status("sad4_window_kernel")) return e;
+	// second pass: as many waves as the generic code keeps resident (2 - 4 per SIMD), each sweeping a contiguous range
+	const uint32_t waves = 256u * 4u * 4u;
+	uint32_t per_wave = (uint32_t)((a.n + waves - 1) / waves);
+	per_wave = (per_wave + kWave - 1) / kWave * kWave;
+	const uint32_t grid2 = ceil_div(ceil_div(a.n, per_wave), kThreads / kWave);
+	hipLaunchKernelGGL((sad4_rescan_kernel<W, C, R, U, LOOP>), dim3(grid2), dim3(kThreads), 0, a.st,
+			a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n, per_wave);
+	return launch_status("sad4_rescan_kernel");
+}
+
 template <int W, int C, int R, int U, int WAYS, int OP, bool TIGHT> static int launch_cfg(const Args &a)
 {
 	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
 	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
+	if constexpr (WAYS == 4 && OP == OP_SAD && (W == 64 || W == 48) && !TIGHT && U <= 6)
+	{
+		if (a.H % 16 == 0 && a.H <= 64 && window_stride_ok(a.sr, W) && !getenv("HEVCASM_SAD4_GENERIC"))
+		{
+			if (a.H == R * U) return launch_window<W, C, R, U, false>(a);
+			if constexpr (U <= 4) return launch_window<W, C, R, U, true>(a);
+		}
+	}
 	if (a.H == R * U)
 		hipLaunchKernelGGL((block_cost_kernel<W, C, R, U, WAYS, OP, false, TIGHT>), dim3(grid), dim3(kThreads), 0, a.st,
 				a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n);
