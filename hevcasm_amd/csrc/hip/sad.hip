@@ -216,14 +216,14 @@ template <int C, int LPR> struct OverlapRefChunk
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 // LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
 // TIGHT: the reference rows of an 8-wide block are less than 8 bytes apart (see OverlapRefChunk, one lane to a row)
-// One wave's work: lane `lane` belongs to sub-block lane / LPB of the wave and handles block `blk` (every lane of a
-// sub-block is given the same, valid, block index); only the leaders of `live` sub-blocks store.
+// One wave's sums: lane `lane` belongs to sub-block lane / LPB of the wave and works on block `blk` (every lane of a
+// sub-block is given the same, valid, block index); rows [row_first, row_first + H) of it; the sums arrive in the sub-block's lane 0.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
-__device__ __forceinline__ void block_cost_body(
+__device__ __forceinline__ void block_cost_sums(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live)
+	int H /* rows of this part */, uint32_t lane, uint32_t blk, uint32_t row_first /* the part starts at this row of the block */, uint32_t (&total)[WAYS])
 {
 	typedef Tiling<W, C, R> T;
 	constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
@@ -245,10 +245,10 @@ __device__ __forceinline__ void block_cost_body(
 	const uint8_t *const ref_al = ref - ref_mis;
 	const uint32_t ss32 = (uint32_t)stride_src, sr32 = (uint32_t)stride_ref;
 	const uint32_t step_src = R * ss32, step_ref = R * sr32;
-	uint32_t os = so + row0 * ss32 + chunk * C;
+	uint32_t os = so + (row_first + row0) * ss32 + chunk * C;
 	uint32_t orf[WAYS];
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) orf[k] = ro[k] + ref_mis + row0 * sr32 + chunk * C;
+	for (int k = 0; k < WAYS; ++k) orf[k] = ro[k] + ref_mis + (row_first + row0) * sr32 + chunk * C;
 
 	Acc<C, OP> acc[WAYS];
 
@@ -400,10 +400,23 @@ __device__ __forceinline__ void block_cost_body(
 #pragma unroll
 	for (int u = 0; u < U; ++u) drain(u);
 
-	uint32_t total[WAYS];
 #pragma unroll
 	for (int k = 0; k < WAYS; ++k) total[k] = reduce_block<LPR, R>(acc[k].value());
+}
 
+// One wave's work: lane `lane` belongs to sub-block lane / LPB of the wave and handles block `blk` (every lane of a
+// sub-block is given the same, valid, block index); only the leaders of `live` sub-blocks store.
+template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
+__device__ __forceinline__ void block_cost_body(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
+	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live)
+{
+	constexpr int LPB = Tiling<W, C, R>::LPB;
+	uint32_t total[WAYS];
+	block_cost_sums<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, total);
+	const uint32_t j = lane % LPB;
 	if (live && j == 0)
 	{
 		if (WAYS == 4)
@@ -452,198 +465,266 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 //   * one block per wave, 4 lanes to a block row, 16 rows per trip; the descriptors are wave-uniform, so they arrive
 //     by scalar loads (not queued behind other waves' row loads) and the window geometry is scalar arithmetic;
 //   * a block qualifies when all four candidates lie within 16 rows and 16 columns of each other (decided from the
-//     offsets alone: offset differences are split into rows and columns with the row stride); for any other block the
-//     wave writes the sentinel -1 (no SAD is negative) into its four results and block_cost_rescan_kernel, launched
-//     right behind on the same stream, computes it with the generic code;
+//     offsets alone: offset differences are split into rows and columns with the row stride); any other block is computed
+//     by the same wave with the generic code (block_cost_body at this kernel's one-block-per-wave mapping);
 //   * memory touched: exactly the 4-byte-aligned words that hold a byte of some candidate's row -- per window row the
 //     staged range is the hull of the candidates that cover this row (they overlap horizontally, so the hull has no
 //     holes), and a lane whose 16 bytes would stick out of it is moved inside (its neighbour's bytes, stored twice).
+template <int W, int H> struct WindowPlan
+{
+	static constexpr int C = W / 4;                          // bytes per lane and row in the compute phase: 4 lanes to a row (16, 12, 8)
+	static constexpr int CD = C / 4;
+	static constexpr int SPAN = 16;                          // candidates at most this far apart, in rows and in columns
+	static constexpr int WIN_DW = (W + SPAN + 3 + 3) / 4;    // dwords of the widest window row (3 more bytes of misalignment): 21, 17, 13
+	static constexpr int LROW = W == 64 ? 21 : W == 48 ? 20 : 13;   // LDS row pitch in dwords (the compute phase's reads: 2-way / none / 2-way bank conflicts)
+	static constexpr int LPRW = (WIN_DW + 3) / 4;            // staging: lanes (16 bytes each) per window row: 6, 5, 4
+	static constexpr int ROWS = H + SPAN;
+	static constexpr int NI = (ROWS * LPRW + kWave - 1) / kWave;   // staging instructions: lane l of instruction i holds piece 64 i + l of the window
+	static constexpr int TRIPS = H / 16;
+	static_assert(H % 16 == 0 && WIN_DW <= LROW && LPRW * 4 >= WIN_DW, "window row must fit its LDS row and its staging lanes");
+};
+
+// Where one block's four candidates lie: wave-uniform, so all of this is scalar loads and scalar arithmetic.
+struct WindowGeometry
+{
+	bool close;            // all four candidates within SPAN rows and SPAN columns of each other
+	uint32_t so;           // source offset
+	uint32_t a_min, span;  // the lowest aligned word that holds a byte of a candidate (offset from the word-aligned plane base) and the
+	                       // distance from it to the last 16-byte piece that ends inside the highest such word
+	int rel0;              // window origin (top-left corner, word-aligned) relative to a_min: -(SPAN + 3) .. 0
+	uint32_t last_row;     // last window row = H - 1 + the largest row displacement
+	uint32_t X[4], Y[4];   // candidate k starts at byte X[k] (0 .. SPAN + 3) of window row Y[k] (0 .. SPAN)
+};
+
 template <int W, int H>
+__device__ __forceinline__ WindowGeometry window_geometry(const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+		uint32_t blk, uint32_t ref_mis, uint32_t sr32, uint32_t inv_stride)
+{
+	typedef WindowPlan<W, H> P;
+	WindowGeometry g;
+	g.so = src_off[blk];
+	uint32_t o[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) o[k] = ref_off[(size_t)blk * 4 + k] + ref_mis;
+	const uint32_t m = min(min(o[0], o[1]), min(o[2], o[3]));
+	bool close = true;
+	int dx[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+	{
+		const uint32_t d = o[k] - m;                                 // candidate k lies d bytes above the lowest one:
+		close = close && d <= (uint32_t)P::SPAN * sr32 + 32u;       // dy rows and dx columns, dx in [-32, stride - 32)
+		const uint32_t nn = d + 32u;
+		uint32_t q = __umulhi(nn, inv_stride);                      // nn / stride, or one more
+		int r = (int)(nn - q * sr32);
+		if (r < 0) { q -= 1; r += (int)sr32; }
+		dx[k] = r - 32;
+		g.Y[k] = q;
+	}
+	const int xmin = min(min(dx[0], dx[1]), min(dx[2], dx[3])), xmax = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
+	const uint32_t ymax = max(max(g.Y[0], g.Y[1]), max(g.Y[2], g.Y[3]));
+	g.close = close && (xmax - xmin) <= P::SPAN && ymax <= (uint32_t)P::SPAN && inv_stride != 0u;
+	const uint32_t wo = m + (uint32_t)xmin;          // byte offset of the window's top-left corner; modulo 2^32 like everything derived from it
+	const uint32_t wbase = wo & ~3u;
+#pragma unroll
+	for (int k = 0; k < 4; ++k) g.X[k] = (uint32_t)(dx[k] - xmin) + (wo & 3u);
+	g.last_row = (uint32_t)H + ymax - 1u;
+	g.a_min = m & ~3u;
+	const uint32_t a_max = (max(max(o[0], o[1]), max(o[2], o[3])) + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1)) & ~3u;
+	g.span = a_max - 12u - g.a_min;
+	g.rel0 = (int)(wbase - g.a_min);
+	return g;
+}
+
+// Issue every load of one block: the window pieces (global -> registers; lane l of instruction i holds piece 64 i + l of the
+// window, LPRW pieces of 16 bytes per row, the last piece of a row pulled in to end with the LDS row) and the source rows.
+// No lane is ever switched off: a piece past the window's last row repeats that row, a piece below a_min / above a_max
+// repeats its neighbour (same bytes to the same LDS words) -- nothing outside the candidates' own address range is read.
+template <int W, int H>
+__device__ __forceinline__ void window_issue(const WindowGeometry &g, const uint8_t *ref_al, const uint8_t *src, uint32_t sr32, uint32_t ss32, uint32_t lane,
+		u32x4 (&st)[WindowPlan<W, H>::NI], uint32_t (&spos)[WindowPlan<W, H>::NI], Chunk<WindowPlan<W, H>::C> (&s)[WindowPlan<W, H>::TRIPS])
+{
+	typedef WindowPlan<W, H> P;
+#pragma unroll
+	for (int i = 0; i < P::NI; ++i)
+	{
+		const uint32_t piece = (uint32_t)(i * kWave) + lane, srow = piece / P::LPRW;
+		const uint32_t scol = min((piece - srow * P::LPRW) * 4u, (uint32_t)(P::LROW - 4));
+		const uint32_t row = min(srow, g.last_row);
+		// the piece's address relative to a_min (a small number of either sign on row 0, positive below it: stride <= 2^20),
+		// moved inside [0, span]; rows are word-aligned with each other (stride % 4 == 0: window_stride_ok)
+		const int rel = (int)(__umul24(row, sr32) + 4u * scol) + g.rel0;
+		const int rel_in = med3_i32(rel, 0, (int)g.span);
+		st[i] = reinterpret_cast<const U4 *>(ref_al + (size_t)(g.a_min + (uint32_t)rel_in))->v;
+		spos[i] = (__umul24(row, (uint32_t)P::LROW) + scol + ((uint32_t)(rel_in - rel) >> 2)) & 0x3fffffffu;     // (rel_in - rel): a small multiple of 4 of either sign
+	}
+	const uint32_t y0 = lane >> 2, j = lane & 3u;
+#pragma unroll
+	for (int t = 0; t < P::TRIPS; ++t)
+	{
+		const uint8_t *p = src + (size_t)(g.so + ((uint32_t)(t * 16) + y0) * ss32 + j * (uint32_t)P::C);
+		if (W != 48) s[t].load_stream(p); else s[t].load(p);       // as the generic kernel: streaming where waves cover whole lines
+	}
+}
+
+// Four SADs per source chunk, candidates read from LDS (the trip's row offset is an immediate of the ds_read); totals in lane 63.
+template <int W, int H>
+__device__ __forceinline__ void window_compute(const WindowGeometry &g, const uint32_t *lds, uint32_t lane,
+		const Chunk<WindowPlan<W, H>::C> (&s)[WindowPlan<W, H>::TRIPS], uint32_t (&total)[4])
+{
+	typedef WindowPlan<W, H> P;
+	const uint32_t y0 = lane >> 2, j = lane & 3u;
+	uint32_t acc[4] = { 0, 0, 0, 0 };
+	const uint32_t *rk[4];
+#pragma unroll
+	for (int k = 0; k < 4; ++k) rk[k] = lds + (__umul24(y0 + g.Y[k], (uint32_t)P::LROW) + (g.X[k] >> 2) + j * (uint32_t)P::CD);
+#pragma unroll
+	for (int t = 0; t < P::TRIPS; ++t)
+	{
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const uint32_t *r = rk[k] + t * 16 * P::LROW;
+			uint32_t w[P::CD + 1];
+#pragma unroll
+			for (int q = 0; q <= P::CD; ++q) w[q] = r[q];
+			const uint32_t sh = g.X[k] & 3u;
+#pragma unroll
+			for (int q = 0; q < P::CD; ++q)
+				acc[k] = __builtin_amdgcn_sad_u8(s[t].d[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), acc[k]);
+		}
+		__builtin_amdgcn_sched_barrier(0);    // one trip's LDS reads live at a time
+	}
+#pragma unroll
+	for (int k = 0; k < 4; ++k) total[k] = wave_sum_to_lane63(acc[k]);
+}
+
+// BPWV consecutive blocks per wave, one after the other: while block b is computed out of LDS, the loads of block b + 1 are
+// already in flight (its descriptors arrived during block b - 1), so a wave never sits through a memory round trip idle.
+template <int W, int H, int BPWV>
 __global__ __launch_bounds__(kThreads) void sad4_window_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
 	int *__restrict__ out, uint32_t n_blocks, uint32_t inv_stride /* floor(2^32 / stride_ref) + 1 */)
 {
-	constexpr int C = W == 48 ? 12 : 16;             // bytes per lane and row in the compute phase: 4 lanes to a row
-	constexpr int CD = C / 4;
-	constexpr int SPAN = 16;                          // candidates at most this far apart, in rows and in columns
-	constexpr int WIN_DW = (W + SPAN + 3 + 3) / 4;    // dwords of the widest window row (3 more bytes of misalignment): 21, 17
-	constexpr int LROW = W == 64 ? 21 : 20;           // LDS row pitch in dwords (the compute phase's reads: 2-way / no bank conflicts)
-	constexpr int LPRW = (WIN_DW + 3) / 4;            // staging: lanes (16 bytes each) per window row: 6, 5
-	constexpr int ROWS = H + SPAN;
-	constexpr int NI = (ROWS * LPRW + kWave - 1) / kWave;   // staging instructions: lane l of instruction i holds piece 64 i + l of the window
-	constexpr int TRIPS = H / 16;
-	static_assert(H % 16 == 0 && WIN_DW <= LROW && LPRW * 4 >= WIN_DW, "window row must fit its LDS row and its staging lanes");
-	__shared__ uint32_t lds_all[(kThreads / kWave) * ROWS * LROW];
+	typedef WindowPlan<W, H> P;
+	__shared__ uint32_t lds_all[(kThreads / kWave) * P::ROWS * P::LROW];
 
+	// A workgroup owns 4 BPWV consecutive blocks; its four waves take them round-robin, so that at any time the workgroup is on
+	// four NEIGHBOURING blocks (they share the 128-byte lines of their source rows and of the overlap of their windows).
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave_in_wg = threadIdx.x >> 6;
-	const uint32_t blk = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + wave_in_wg);
-	if (blk >= n_blocks) return;
+	constexpr uint32_t STEP = kThreads / kWave;
+	const uint32_t first = __builtin_amdgcn_readfirstlane(wg * (STEP * BPWV) + wave_in_wg);
+	if (first >= n_blocks) return;
+	const uint32_t end = min(first + STEP * (uint32_t)(BPWV - 1) + 1u, n_blocks);      // this wave's blocks: first, first + STEP, ... < end
 	const uint32_t lane = threadIdx.x & 63;
-	uint32_t *lds = lds_all + wave_in_wg * (ROWS * LROW);
+	uint32_t *lds = lds_all + wave_in_wg * (P::ROWS * P::LROW);
 
-	// descriptors and window geometry: wave-uniform (scalar loads, scalar arithmetic)
 	const uint32_t ref_mis = (uint32_t)(reinterpret_cast<uintptr_t>(ref) & 3u);
 	const uint8_t *const ref_al = ref - ref_mis;
 	const uint32_t sr32 = (uint32_t)stride_ref, ss32 = (uint32_t)stride_src;
-	const uint32_t so = src_off[blk];
-	uint32_t o[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) o[k] = ref_off[(size_t)blk * 4 + k] + ref_mis;
-	const uint32_t m = min(min(o[0], o[1]), min(o[2], o[3]));
-	bool close = true;
-	int dx[4]; uint32_t Y[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k)
+
+	u32x4 st[P::NI];
+	uint32_t spos[P::NI];
+	Chunk<P::C> sa[P::TRIPS], sb[P::TRIPS];
+
+	auto park = [&]()
 	{
-		const uint32_t d = o[k] - m;                              // candidate k lies d bytes above the lowest one:
-		close = close && d <= (uint32_t)SPAN * sr32 + 32u;       // dy rows and dx columns, dx in [-32, stride - 32)
-		const uint32_t nn = d + 32u;
-		uint32_t q = __umulhi(nn, inv_stride);                   // nn / stride, or one more
-		int r = (int)(nn - q * sr32);
-		if (r < 0) { q -= 1; r += (int)sr32; }
-		dx[k] = r - 32;
-		Y[k] = q;
-	}
-	const int xmin = min(min(dx[0], dx[1]), min(dx[2], dx[3])), xmax = max(max(dx[0], dx[1]), max(dx[2], dx[3]));
-	const uint32_t ymax = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
-	close = close && (xmax - xmin) <= SPAN && ymax <= (uint32_t)SPAN;
-	if (!close)
-	{
-		if (lane == 0)
+#pragma unroll
+		for (int i = 0; i < P::NI; ++i)
 		{
-			u32x4 v; v.x = v.y = v.z = v.w = 0xffffffffu;
+			uint32_t *d = lds + spos[i];
+			d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
+		}
+		// the wave's own LDS accesses are in order (one wave, one LDS queue); keep the compiler from reordering them
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
+	auto finish = [&](const WindowGeometry &g, uint32_t blk, Chunk<P::C> (&s)[P::TRIPS])
+	{
+		uint32_t total[4];
+		window_compute<W, H>(g, lds, lane, s, total);
+		if (lane == 63)
+		{
+			u32x4 v; v.x = total[0]; v.y = total[1]; v.z = total[2]; v.w = total[3];
 			reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+	};
+
+	// Do all of this wave's blocks qualify?  (The usual case: a batch is one search step, its candidate patterns alike.)
+	bool all_close = first + STEP * (uint32_t)(BPWV - 1) < n_blocks;
+#pragma unroll
+	for (int b = 0; b < BPWV; ++b)
+		if (first + STEP * b < end) all_close = all_close && window_geometry<W, H>(src_off, ref_off, first + STEP * b, ref_mis, sr32, inv_stride).close;
+
+	if (all_close)
+	{
+		// Straight-line pipeline, no branch anywhere between a load and its use (the compiler's wait counts are exact only
+		// along straight code: one conditional issue in the loop made every compute phase wait for ALL loads in flight, and
+		// the kernel ran 1.3 - 2.2x slower than with one block per wave).
+		WindowGeometry g[2];
+		g[0] = window_geometry<W, H>(src_off, ref_off, first, ref_mis, sr32, inv_stride);
+		window_issue<W, H>(g[0], ref_al, src, sr32, ss32, lane, st, spos, sa);
+#pragma unroll
+		for (int b = 0; b < BPWV; ++b)
+		{
+			park();                                     // block b's window: registers -> LDS (waits for its pieces only)
+			if (b + 1 < BPWV)
+			{
+				g[(b + 1) & 1] = window_geometry<W, H>(src_off, ref_off, first + STEP * (b + 1), ref_mis, sr32, inv_stride);
+				window_issue<W, H>(g[(b + 1) & 1], ref_al, src, sr32, ss32, lane, st, spos, (b & 1) ? sa : sb);
+			}
+			__builtin_amdgcn_sched_barrier(0);
+			finish(g[b & 1], first + STEP * b, (b & 1) ? sb : sa);
 		}
 		return;
 	}
-	const uint32_t wo = m + (uint32_t)xmin;          // byte offset (from ref_al) of the window's top-left corner; modulo 2^32 like everything below
-	const uint32_t wbase = wo & ~3u;
-	uint32_t X[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) X[k] = (uint32_t)(dx[k] - xmin) + (wo & 3u);     // 0 .. 19
-	const uint32_t last_row = (uint32_t)H + ymax - 1u;
-	// The lowest and the highest aligned word that hold a byte of any candidate: every staged piece is moved inside
-	// [a_min, a_max] (its LDS position moves with it), so nothing outside the candidates' own address range is ever read.
-	const uint32_t a_min = m & ~3u;
-	const uint32_t a_max = (max(max(o[0], o[1]), max(o[2], o[3])) + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1)) & ~3u;
-
-	// ---- stage the window: global -> registers (every load in flight before anything else), source rows, registers -> LDS.
-	// Lane l of instruction i holds piece 64 i + l of the window (LPRW pieces of 16 bytes per row; the last piece of a row
-	// is pulled in to end with the LDS row).  No lane is ever switched off: a piece past the window's last row repeats that
-	// row, a piece below a_min / above a_max repeats its neighbour (same bytes to the same LDS words).
-	u32x4 st[NI];
-	uint32_t spos[NI];
-#pragma unroll
-	for (int i = 0; i < NI; ++i)
+	// Mixed or ragged group: block by block, nothing overlapped.  A block whose candidates lie far apart is computed by the
+	// generic code at this kernel's mapping (one block per wave: 16 rows in flight, a single trip of H / 16 rows per lane).
+	for (uint32_t blk = first; blk < end; blk += STEP)
 	{
-		const uint32_t piece = (uint32_t)(i * kWave) + lane, srow = piece / LPRW;
-		const uint32_t scol = min((piece - srow * LPRW) * 4u, (uint32_t)(LROW - 4));
-		const uint32_t row = min(srow, last_row);
-		// the piece's address relative to a_min (a small number of either sign on row 0, positive below it: stride <= 2^20),
-		// moved inside [0, a_max - 12 - a_min]; rows are word-aligned with each other (stride % 4 == 0: window_stride_ok)
-		const int rel = (int)(__umul24(row, sr32) + 4u * scol) + (int)(wbase - a_min);
-		const int rel_in = med3_i32(rel, 0, (int)(a_max - 12u - a_min));
-		const uint32_t a = a_min + (uint32_t)rel, a_in = a_min + (uint32_t)rel_in;
-		st[i] = reinterpret_cast<const U4 *>(ref_al + (size_t)a_in)->v;
-		spos[i] = __umul24(row, (uint32_t)LROW) + scol + ((uint32_t)(a_in - a) >> 2);     // (a_in - a) is a small multiple of 4 of either sign: the sum is exact modulo 2^30
-	}
-	const uint32_t y0 = lane >> 2, j = lane & 3u;
-	Chunk<C> s[TRIPS];
-#pragma unroll
-	for (int t = 0; t < TRIPS; ++t)
-	{
-		const uint8_t *p = src + (size_t)(so + ((uint32_t)(t * 16) + y0) * ss32 + j * (uint32_t)C);
-		if (W == 64) s[t].load_stream(p); else s[t].load(p);       // as the generic kernel: streaming where waves cover whole lines
-	}
-	__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-	for (int i = 0; i < NI; ++i)
-	{
-		uint32_t *d = lds + (spos[i] & 0x3fffffffu);
-		d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
-	}
-	// the wave's own LDS writes are in order before its reads (one wave, one LDS queue); keep the compiler from reordering them
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-	// ---- four SADs per source chunk, candidates read from LDS (the trip's row offset is an immediate of the ds_read)
-	uint32_t acc[4] = { 0, 0, 0, 0 };
-	const uint32_t *rk[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) rk[k] = lds + (__umul24(y0 + Y[k], (uint32_t)LROW) + (X[k] >> 2) + j * (uint32_t)CD);
-#pragma unroll
-	for (int t = 0; t < TRIPS; ++t)
-	{
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
+		const WindowGeometry g = window_geometry<W, H>(src_off, ref_off, blk, ref_mis, sr32, inv_stride);
+		if (g.close)
 		{
-			const uint32_t *r = rk[k] + t * 16 * LROW;
-			uint32_t w[CD + 1];
-#pragma unroll
-			for (int q = 0; q <= CD; ++q) w[q] = r[q];
-			const uint32_t sh = X[k] & 3u;
-#pragma unroll
-			for (int q = 0; q < CD; ++q)
-				acc[k] = __builtin_amdgcn_sad_u8(s[t].d[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), acc[k]);
+			window_issue<W, H>(g, ref_al, src, sr32, ss32, lane, st, spos, sa);
+			park();
+			finish(g, blk, sa);
 		}
-		__builtin_amdgcn_sched_barrier(0);    // one trip's LDS reads live at a time
-	}
-	uint32_t total[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k) total[k] = wave_sum_to_lane63(acc[k]);
-	if (lane == 63)
-	{
-		u32x4 v; v.x = total[0]; v.y = total[1]; v.z = total[2]; v.w = total[3];
-		reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
-	}
-}
-
-// Second pass behind sad4_window_kernel: every wave owns a contiguous range of the batch, finds the blocks that carry the
-// sentinel and runs the generic code on them, BPW at a time.  A batch whose candidates all lay close together costs one
-// sweep over the results (4 bytes per block); a batch of far-apart candidates is computed here at the generic kernel's pace
-// (the grid is what its register budget keeps resident anyway).
-template <int W, int C, int R, int U, bool LOOP>
-__global__ __launch_bounds__(kThreads) void sad4_rescan_kernel(
-	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
-	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
-	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *out, int H, uint32_t n_blocks, uint32_t blocks_per_wave)
-{
-	typedef Tiling<W, C, R> T;
-	constexpr int LPB = T::LPB, BPW = T::BPW;
-	const uint32_t wave = blockIdx.x * (kThreads / kWave) + (threadIdx.x >> 6);
-	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t sub = min(lane / LPB, (uint32_t)BPW - 1u);
-	const uint64_t first64 = (uint64_t)wave * blocks_per_wave;
-	if (first64 >= n_blocks) return;
-	const uint32_t first = (uint32_t)first64, last = (uint32_t)min((uint64_t)n_blocks, first64 + blocks_per_wave);
-	for (uint32_t base = first; base < last; base += kWave)
-	{
-		const uint32_t mine = base + lane;
-		const bool pending = mine < last && reinterpret_cast<const volatile int *>(out)[(size_t)mine * 4] == -1;
-		uint64_t mask = __builtin_amdgcn_ballot_w64(pending);
-		while (mask)      // wave-uniform
+		else
 		{
-			uint32_t blk = 0; bool live = false;
-			uint32_t any = 0;
-#pragma unroll
-			for (int b = 0; b < BPW; ++b)
+			// (64 rows in two parts of 2 rows per lane: as one part of 4 this path needs 161 registers and takes the window path's
+			// occupancy from 5 waves per SIMD to 3: +6 % on close candidates)
+			uint32_t sum[4] = { 0, 0, 0, 0 }, part[4];
+			if constexpr (H == 64)
 			{
-				if (mask)
-				{
-					const uint32_t bit = (uint32_t)__builtin_ctzll(mask);
-					mask &= mask - 1;
-					any = base + bit;
-					if (sub == (uint32_t)b) { blk = base + bit; live = true; }
-				}
+				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
+				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 32u, part);
+#pragma unroll
+				for (int k = 0; k < 4; ++k) sum[k] += part[k];
 			}
-			if (!live) blk = any;       // sub-blocks left over redo a valid block and store nothing
-			live = live && lane / LPB < (uint32_t)BPW;
-			block_cost_body<W, C, R, U, 4, OP_SAD, LOOP, false>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live);
+			else if constexpr (H == 48)
+			{
+				// (as one part of 3 rows per lane: 124 registers, 4 waves per SIMD instead of 5 -- close candidates +4 %, far ones -13 %;
+				// holding that part to 96 registers with launch bounds spills: close +15 %, far +46 %)
+				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
+				block_cost_sums<W, P::C, 16, 1, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 16, lane, blk, 32u, part);
+#pragma unroll
+				for (int k = 0; k < 4; ++k) sum[k] += part[k];
+			}
+			else
+			{
+				block_cost_sums<W, P::C, 16, H / 16, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, sum);
+			}
+			if (lane == 0)
+			{
+				u32x4 v; v.x = sum[0]; v.y = sum[1]; v.z = sum[2]; v.w = sum[3];
+				reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
+			}
 		}
 	}
 }
@@ -659,34 +740,34 @@ struct Args
 // same in every row)
 static bool window_stride_ok(ptrdiff_t sr, int W) { return sr >= W + 64 && sr <= (1 << 20) && (sr & 3) == 0; }
 
-template <int W, int C, int R, int U, bool LOOP> static int launch_window(const Args &a)
+template <int W> static int launch_window(const Args &a)
 {
-	const uint32_t inv = (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;
-	const uint32_t grid1 = ceil_div(a.n, kThreads / kWave);
-#define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM>), dim3(grid1), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
+	const uint32_t inv = getenv("HEVCASM_SAD4_NOWINDOW") ? 0u : (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;    // (0: every block takes the generic code -- measurements only)
+	// Blocks per wave of the window kernel.  More than one (the next block's loads in flight while this one is computed, blocks dealt
+	// round-robin over the workgroup's waves) was measured slower: 4 per wave +11 % (+34 % with each wave on consecutive blocks) against
+	// one block per wave -- many short waves on neighbouring blocks beat fewer, deeper ones (gpurun_out/ab2_sad4_window[34].txt).
+	constexpr int BPWV = 1;
+	const uint32_t grid1 = ceil_div(a.n, BPWV * (kThreads / kWave));
+#define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM, BPWV>), dim3(grid1), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
 	if (a.H == 16) WINDOW(16); else if (a.H == 32) WINDOW(32); else if (a.H == 48) WINDOW(48); else WINDOW(64);
 #undef WINDOW
-	if (int e = launch_status("sad4_window_kernel")) return e;
-	// second pass: as many waves as the generic code keeps resident (2 - 4 per SIMD), each sweeping a contiguous range
-	const uint32_t waves = 256u * 4u * 4u;
-	uint32_t per_wave = (uint32_t)((a.n + waves - 1) / waves);
-	per_wave = (per_wave + kWave - 1) / kWave * kWave;
-	const uint32_t grid2 = ceil_div(ceil_div(a.n, per_wave), kThreads / kWave);
-	hipLaunchKernelGGL((sad4_rescan_kernel<W, C, R, U, LOOP>), dim3(grid2), dim3(kThreads), 0, a.st,
-			a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, a.H, (uint32_t)a.n, per_wave);
-	return launch_status("sad4_rescan_kernel");
+	return launch_status("sad4_window_kernel");
 }
 
 template <int W, int C, int R, int U, int WAYS, int OP, bool TIGHT> static int launch_cfg(const Args &a)
 {
 	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
 	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
+	// 64- and 48-wide blocks of 16 / 32 / 48 / 64 rows go through sad4_window_kernel, which decides per block: candidates close together ->
+	// union window through LDS (same-box A/B against the generic kernel below, config #2's +-7 pixels: 64x64 -2 %, 64x48 -3 %, 64x32 -4 %,
+	// 64x16 -12 %, 48x64 -6 %); far apart -> generic code, one block per wave (-12 ... +10 %).  32-wide blocks stay here: their window
+	// path measured +2 ... +21 % on close candidates (the window is 1.6x the block's width) although the far path gained 15 %
+	// (gpurun_out/ab2_sad4_w32*.txt, ab2_sad4_window6.txt, ab2_sad4_far40c.txt).
 	if constexpr (WAYS == 4 && OP == OP_SAD && (W == 64 || W == 48) && !TIGHT && U <= 6)
 	{
 		if (a.H % 16 == 0 && a.H <= 64 && window_stride_ok(a.sr, W) && !getenv("HEVCASM_SAD4_GENERIC"))
 		{
-			if (a.H == R * U) return launch_window<W, C, R, U, false>(a);
-			if constexpr (U <= 4) return launch_window<W, C, R, U, true>(a);
+			return launch_window<W>(a);
 		}
 	}
 	if (a.H == R * U)

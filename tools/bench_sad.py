@@ -9,11 +9,12 @@ import bench
 from hevcasm_amd import workload as wl
 
 args = sys.argv[1:]
-ways_list, blocks, disp = (1, 4), 1 << 20, None
+ways_list, blocks, disp, far = (1, 4), 1 << 20, None, 0
 while args and args[0].startswith("--"):
     if args[0] == "--ways": ways_list = (int(args[1]),)
     if args[0] == "--blocks": blocks = int(args[1])
     if args[0] == "--disp": disp = int(args[1])
+    if args[0] == "--far": far = int(args[1])      # candidates 1..3 moved up to this many rows up or down (the generic path of the 4-way entry)
     args = args[2:]
 sizes = [tuple(int(v) for v in s.split("x")) for s in args] or wl.SAD_BENCH_SIZES
 torch.cuda.set_device(0)
@@ -26,6 +27,16 @@ if disp is not None:      # another displacement range than config #2's +-7 (exp
     wl.sad_case = sad_case
 for (w, h) in sizes:
     sets = [bench.SizeBatch(w, h, blocks, 1000 + 7 * i, torch.device("cuda", 0)) for i in range(2)]
+    if far:
+        for b in sets:
+            for c in b.chunks:
+                g = torch.Generator(device="cuda"); g.manual_seed(5)
+                d = torch.randint(-far, far + 1, (c["n"], 4), generator=g, device="cuda", dtype=torch.int64) * c["stride_ref"]
+                d[:, 0] = 0
+                ro = (c["ref_off4"].view(-1, 4).to(torch.int64) & 0xffffffff) + d
+                hi = c["ref"].numel() - (h * c["stride_ref"] + w) - 64
+                ro = ro.clamp_(64, hi)
+                c["ref_off4"] = (((ro + 2 ** 31) % 2 ** 32) - 2 ** 31).to(torch.int32).contiguous().view(-1)     # u32 bit patterns
     for ways in ways_list:
         ts = []
         for i in range(7):
