@@ -40,15 +40,17 @@ namespace hevc {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
-// packed coefficient tables: V pass wants (c, c); H pass wants (c[k], c[k + 2]) pairs
-struct PredTables
+// Filter taps (HEVC 8.5.3.3.3: luma quarter-pel, chroma eighth-pel).  Every tap fits a signed byte, so tap k of all phases is one
+// packed literal -- luma: 4 phases in a dword; chroma: 8 phases in two -- and a lane picks its phase with one v_bfe_i32: no table
+// in memory, no load (the coefficient loads used to be a second dependent memory round trip in every wave's prologue, behind the
+// descriptors and in front of the first window rows).  Phase 0 is the single tap {64} at filter position 0 (see Footprint).
+struct PredTaps
 {
-	uint32_t luma_v[4][8], luma_h[4][4], chroma_v[8][4], chroma_h[8][2];
+	uint32_t luma[8];          // luma[k]: byte f = tap k of phase f
+	uint32_t chroma[4][2];     // chroma[k][h]: byte f & 3 = tap k of phase 4 h + (f & 3)
 };
 
-constexpr uint32_t pk(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
-
-constexpr PredTables make_pred_tables()
+constexpr PredTaps make_pred_taps()
 {
 	constexpr int luma[4][8] = {
 		{ 64, 0, 0, 0, 0, 0, 0, 0 } /* window starts at the block */, { -1, 4, -10, 58, 17, -5, 1, 0 },
@@ -56,35 +58,42 @@ constexpr PredTables make_pred_tables()
 	constexpr int chroma[8][4] = {
 		{ 64, 0, 0, 0 } /* window starts at the block */, { -2, 58, 10, -2 }, { -4, 54, 16, -2 }, { -6, 46, 28, -4 },
 		{ -4, 36, 36, -4 }, { -4, 28, 46, -6 }, { -2, 16, 54, -4 }, { -2, 10, 58, -2 } };
-	PredTables t = {};
-	for (int f = 0; f < 4; ++f)
-	{
-		for (int k = 0; k < 8; ++k) t.luma_v[f][k] = pk(luma[f][k], luma[f][k]);
-		t.luma_h[f][0] = pk(luma[f][0], luma[f][2]);
-		t.luma_h[f][1] = pk(luma[f][1], luma[f][3]);
-		t.luma_h[f][2] = pk(luma[f][4], luma[f][6]);
-		t.luma_h[f][3] = pk(luma[f][5], luma[f][7]);
-	}
-	for (int f = 0; f < 8; ++f)
-	{
-		for (int k = 0; k < 4; ++k) t.chroma_v[f][k] = pk(chroma[f][k], chroma[f][k]);
-		t.chroma_h[f][0] = pk(chroma[f][0], chroma[f][2]);
-		t.chroma_h[f][1] = pk(chroma[f][1], chroma[f][3]);
-	}
+	PredTaps t = {};
+	for (int k = 0; k < 8; ++k)
+		for (int f = 0; f < 4; ++f) t.luma[k] |= ((uint32_t)luma[f][k] & 0xffu) << (8 * f);
+	for (int k = 0; k < 4; ++k)
+		for (int f = 0; f < 8; ++f) t.chroma[k][f >> 2] |= ((uint32_t)chroma[f][k] & 0xffu) << (8 * (f & 3));
 	return t;
 }
 
-__constant__ PredTables kPred = make_pred_tables();
+static constexpr PredTaps kTaps = make_pred_taps();
 
 __device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
 {
 	const s16x2 r = __builtin_bit_cast(s16x2, a) * __builtin_bit_cast(s16x2, b) + __builtin_bit_cast(s16x2, c);
 	return __builtin_bit_cast(uint32_t, r);
 }
+// the same as single instructions the compiler may not take apart: pk_mad with a register addend (left to itself it moves the seed of a
+// sum to the end as a separate v_pk_add), and the non-accumulating dot product that starts a chain (v_dot2c needs its start value moved
+// into the destination first)
+__device__ __forceinline__ uint32_t pk_mad_fused(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ int dot2_first(uint32_t a, uint32_t b)
+{
+	int r;
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
 	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b), c, false);
 }
+// (bi-prediction keeps the compiler's own choice: with the single instructions its two streams need 174 registers, 2 waves per SIMD instead of 3)
+template <bool LEAN> __device__ __forceinline__ int first_dot(uint32_t a, uint32_t b) { return LEAN ? dot2_first(a, b) : dot2(a, b, 0); }
 __device__ __forceinline__ uint32_t med3_u32(uint32_t x, uint32_t lo, uint32_t hi)
 {
 	uint32_t r;
@@ -101,13 +110,30 @@ template <int TAPS> struct Coefs
 {
 	uint32_t v[TAPS];        // (cy[k], cy[k])
 	uint32_t h[TAPS / 2];    // (cx[0], cx[2]) (cx[1], cx[3]) [(cx[4], cx[6]) (cx[5], cx[7])]
+	// tap k of phase f, sign-extended
+	static __device__ __forceinline__ int tap(int k, int f)
+	{
+		if (TAPS == 8) return __builtin_amdgcn_sbfe((int)kTaps.luma[k], (uint32_t)(8 * (f & 3)), 8u);
+		const uint32_t packed = (f & 4) ? kTaps.chroma[k & 3][1] : kTaps.chroma[k & 3][0];
+		return __builtin_amdgcn_sbfe((int)packed, (uint32_t)(8 * (f & 3)), 8u);
+	}
 	__device__ __forceinline__ void load(int frac)
 	{
 		const int xf = frac & 15, yf = frac >> 4;
+		int cx[TAPS];
 #pragma unroll
-		for (int k = 0; k < TAPS; ++k) v[k] = TAPS == 8 ? kPred.luma_v[yf & 3][k] : kPred.chroma_v[yf & 7][k];
+		for (int k = 0; k < TAPS; ++k)
+		{
+			const uint32_t c = (uint32_t)tap(k, yf);
+			v[k] = __builtin_amdgcn_perm(c, c, 0x01000100);                 // (c, c) as two int16
+			cx[k] = tap(k, xf);
+		}
 #pragma unroll
-		for (int k = 0; k < TAPS / 2; ++k) h[k] = TAPS == 8 ? kPred.luma_h[xf & 3][k] : kPred.chroma_h[xf & 7][k];
+		for (int k = 0; k < TAPS / 2; ++k)
+		{
+			const int lo = TAPS == 8 ? (k < 2 ? k : k + 2) : k;              // pairs (0, 2) (1, 3) [(4, 6) (5, 7)]
+			h[k] = __builtin_amdgcn_perm((uint32_t)cx[lo + 2], (uint32_t)cx[lo], 0x05040100);
+		}
 	}
 };
 
@@ -184,14 +210,26 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 		}
 	}
 	// vertical filter for the output row whose oldest window row sits in slot `first`
-	__device__ __forceinline__ void vertical(int first, uint32_t (&ve)[NX], uint32_t (&vo)[NX]) const
+	// `seed` (the same 16-bit value in both halves) starts every sum: the horizontal taps add up to 64 whatever the phase, so a
+	// seed of 32 comes out of the horizontal pass as the uni-prediction rounding constant 32 * 64 = 2048, for free -- seeding the
+	// horizontal sums themselves costs a register move per output column (v_dot2c accumulates in place).  |sum| <= 88 * 255 + 32 < 2^15.
+	template <bool SEEDED> __device__ __forceinline__ void vertical(int first, uint32_t seed, uint32_t (&ve)[NX], uint32_t (&vo)[NX]) const
 	{
 #pragma unroll
 		for (int m = 0; m < NDW; ++m)
 		{
-			ve[m] = 0; vo[m] = 0;
+			if (SEEDED)
+			{
+				ve[m] = pk_mad_fused(e[first % TAPS][m], c.v[0], seed);
+				vo[m] = pk_mad_fused(o[first % TAPS][m], c.v[0], seed);
+			}
+			else
+			{
+				ve[m] = pk_mad(e[first % TAPS][m], c.v[0], 0);
+				vo[m] = pk_mad(o[first % TAPS][m], c.v[0], 0);
+			}
 #pragma unroll
-			for (int k = 0; k < TAPS; ++k)
+			for (int k = 1; k < TAPS; ++k)
 			{
 				ve[m] = pk_mad(e[(first + k) % TAPS][m], c.v[k], ve[m]);
 				vo[m] = pk_mad(o[(first + k) % TAPS][m], c.v[k], vo[m]);
@@ -199,9 +237,9 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 		}
 	}
 	// horizontal filter: exact 2-D sums S for this lane's 4 * NDW output columns.  ve/vo[0..NDW) are
-	// this lane's vertical results; the rest is fetched from the lanes to the right.  `bias` seeds
-	// every sum (the uni-prediction rounding constant rides along for free).
-	__device__ __forceinline__ void horizontal(uint32_t (&ve)[NX], uint32_t (&vo)[NX], int bias, int (&s)[4 * NDW]) const
+	// this lane's vertical results; the rest is fetched from the lanes to the right.  (The uni-prediction rounding constant is
+	// already inside: vertical()'s seed.)
+	template <bool LEAN> __device__ __forceinline__ void horizontal(uint32_t (&ve)[NX], uint32_t (&vo)[NX], int (&s)[4 * NDW]) const
 	{
 #pragma unroll
 		for (int m = NDW; m < NX; ++m)
@@ -222,17 +260,17 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 		{
 			if (TAPS == 8)
 			{
-				s[4 * m + 0] = dot2(vo[m + 1], c.h[3], dot2(ve[m + 1], c.h[2], dot2(vo[m], c.h[1], dot2(ve[m], c.h[0], bias))));
-				s[4 * m + 1] = dot2(a[m + 1], c.h[3], dot2(vo[m + 1], c.h[2], dot2(a[m], c.h[1], dot2(vo[m], c.h[0], bias))));
-				s[4 * m + 2] = dot2(b[m + 1], c.h[3], dot2(a[m + 1], c.h[2], dot2(b[m], c.h[1], dot2(a[m], c.h[0], bias))));
-				s[4 * m + 3] = dot2(ve[m + 2], c.h[3], dot2(b[m + 1], c.h[2], dot2(ve[m + 1], c.h[1], dot2(b[m], c.h[0], bias))));
+				s[4 * m + 0] = dot2(vo[m + 1], c.h[3], dot2(ve[m + 1], c.h[2], dot2(vo[m], c.h[1], first_dot<LEAN>(ve[m], c.h[0]))));
+				s[4 * m + 1] = dot2(a[m + 1], c.h[3], dot2(vo[m + 1], c.h[2], dot2(a[m], c.h[1], first_dot<LEAN>(vo[m], c.h[0]))));
+				s[4 * m + 2] = dot2(b[m + 1], c.h[3], dot2(a[m + 1], c.h[2], dot2(b[m], c.h[1], first_dot<LEAN>(a[m], c.h[0]))));
+				s[4 * m + 3] = dot2(ve[m + 2], c.h[3], dot2(b[m + 1], c.h[2], dot2(ve[m + 1], c.h[1], first_dot<LEAN>(b[m], c.h[0]))));
 			}
 			else
 			{
-				s[4 * m + 0] = dot2(vo[m], c.h[1], dot2(ve[m], c.h[0], bias));
-				s[4 * m + 1] = dot2(a[m], c.h[1], dot2(vo[m], c.h[0], bias));
-				s[4 * m + 2] = dot2(b[m], c.h[1], dot2(a[m], c.h[0], bias));
-				s[4 * m + 3] = dot2(ve[m + 1], c.h[1], dot2(b[m], c.h[0], bias));
+				s[4 * m + 0] = dot2(vo[m], c.h[1], first_dot<LEAN>(ve[m], c.h[0]));
+				s[4 * m + 1] = dot2(a[m], c.h[1], first_dot<LEAN>(vo[m], c.h[0]));
+				s[4 * m + 2] = dot2(b[m], c.h[1], first_dot<LEAN>(a[m], c.h[0]));
+				s[4 * m + 3] = dot2(ve[m + 1], c.h[1], first_dot<LEAN>(b[m], c.h[0]));
 			}
 		}
 	}
@@ -355,15 +393,25 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 #pragma unroll
 				for (int r = 0; r < NREF; ++r)
 				{
-					uint32_t newest[NDW];
+					if (!BI)
+					{
+						// consume the ring slot in place, then refill it: the other order needs a copy of the slot per row
+						rs[r].realign(rs[r].pending[i % AHEAD]);
+						rs[r].unpack((i + TAPS - 1) % TAPS, rs[r].pending[i % AHEAD]);           // window row y + T - 1
+						if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);     // window row (y + AHEAD) + T - 1
+					}
+					else
+					{
+						uint32_t newest[NDW];
 #pragma unroll
-					for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
-					if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);     // window row (y + AHEAD) + T - 1
-					rs[r].realign(newest);
-					rs[r].unpack((i + TAPS - 1) % TAPS, newest);           // window row y + T - 1
+						for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
+						if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);
+						rs[r].realign(newest);
+						rs[r].unpack((i + TAPS - 1) % TAPS, newest);
+					}
 					uint32_t ve[Stream::NX], vo[Stream::NX];
-					rs[r].vertical(i, ve, vo);
-					rs[r].horizontal(ve, vo, BI ? 0 : 2048, s[r]);
+					rs[r].template vertical<!BI>(i, 0x00200020u, ve, vo);
+					rs[r].template horizontal<!BI>(ve, vo, s[r]);
 				}
 				// shift, saturate to [0, 255] and pack: v_ashr_pk_u8_i32 does two pixels per instruction
 				uint32_t px[NDW];
@@ -373,7 +421,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 					int t[4];
 #pragma unroll
 					for (int b = 0; b < 4; ++b)
-						t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside
+						t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside (vertical()'s seed)
 					constexpr int SHIFT = BI ? 7 : 12;
 					const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
 					const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);

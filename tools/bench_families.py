@@ -22,10 +22,17 @@ def timed(fn, reps=5):
     return float(np.median(ts))
 
 
+SINK = None      # bench.py collects the rows instead of printing them
+
+
 def report(name, n, bytes_per_block, ms, **kw):
     gbs = n * bytes_per_block / (ms * 1e-3) / 1e9
-    print(json.dumps(dict(kernel=name, blocks=n, ms=round(ms, 4), mblocks_per_s=round(n / ms / 1e3, 1), bytes_per_block=bytes_per_block,
-                          algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK, 4), **kw)), flush=True)
+    row = dict(kernel=name, blocks=n, ms=round(ms, 4), mblocks_per_s=round(n / ms / 1e3, 1), bytes_per_block=bytes_per_block,
+               algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / PEAK, 4), **kw)
+    if SINK is not None:
+        SINK.append(row)
+    else:
+        print(json.dumps(row), flush=True)
 
 
 def bench_pred(frames=64, only=None):
@@ -63,8 +70,10 @@ def bench_pred(frames=64, only=None):
                 torch.cuda.empty_cache()
 
 
-def bench_transform(coeffs_per_launch=1 << 26):
+def bench_transform(coeffs_per_launch=1 << 26, only=None):
     for tr, lg in wl.TRANSFORMS:
+        if only and (tr, lg) not in only:
+            continue
         size = 1 << lg
         n = coeffs_per_launch >> (2 * lg)
         tag = "dst4" if tr else "dct%d" % size
