@@ -281,7 +281,7 @@ __device__ __forceinline__ void block_cost_sums(
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
 	constexpr bool OVERLAP1 = C == 8 && LPR == 1 && !LOOP && !TIGHT;
-	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;
+	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;      // (one reference, 48-wide, aligned: +1 % -- round 2, gpurun_out/ab2_sad1_al48.txt)
 	const bool last = chunk == LPR - 1;
 
 	// Source rows are read exactly once.  Where the blocks of a wave cover whole 128-byte lines of a frame row between

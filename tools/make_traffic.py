@@ -16,8 +16,8 @@ for size in ("64x64", "16x16", "64x48", "48x64"):
         for p in glob.glob(os.path.join(prof, "pmc_%s_%s" % (size, counter), "*", "*_counter_collection.csv")):
             for r in csv.DictReader(open(p)):
                 m = re.search(r"hevc::block_cost_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)[,>]", r["Kernel_Name"])
-                if m and r["Counter_Name"] == counter:
-                    ways = int(m.group(5))
+                ways = int(m.group(5)) if m else (4 if "hevc::sad4_window_kernel<" in r["Kernel_Name"] else None)     # the 4-way kernel of 64-/48-wide blocks
+                if ways and r["Counter_Name"] == counter:
                     vals.setdefault((ways, counter), []).append(float(r["Counter_Value"]))
     bench = json.load(open(os.path.join(prof, "bench_%s.json" % size)))
     for ways, name in ((1, "sad"), (4, "sad_multiref_4")):
