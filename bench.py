@@ -285,7 +285,12 @@ def main():
                        "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1)},
             "roofline": {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4)},
+                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
+                         "bytes_per_block": algorithmic_bytes(*dom_key),
+                         "note": "4-way kernels are priced at their COMPULSORY bytes (source block + the block's share of the reference plane + "
+                                 "descriptors and results): the four candidates overlap and HBM sees each plane byte once (traffic = measured HBM "
+                                 "bytes per launch, rocprofv3 PMC passes); SURVEY 8(d)'s 5WH+16 counts the candidates as disjoint and would read %.0f GB/s"
+                                 % ((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9) if dom_key[2] == 4 else None},
             "cpu_baseline": cpu,
             "headline": {"sad_16x16_single_ref": head[0] if head else None, "inter_pred_and_idct": others,
                          "note": "value = config #2 (the SAD mix) only; the other kernels the metric names are measured in the same run on configs #3 / #4 "

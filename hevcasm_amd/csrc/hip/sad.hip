@@ -804,6 +804,8 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	{
 		if (a.sr < 8 && a.sr > -8) return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, true>(a);
 	}
+	// (one reference, 64-/48-/32-wide, 16 rows in flight and one block per wave -- the mapping that wins for four far-apart candidates:
+	// +18 ... +27 % slower on all seven sizes tried, round 2: profiles/r02_sad4_window_ab.txt)
 	// four references, 16x64: 8 rows in flight make it a single trip of 8 (-3 %)
 	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP, false>(a);
