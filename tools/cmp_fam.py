@@ -8,7 +8,7 @@ def load(p):
         if l.startswith("{"):
             r = json.loads(l); d[(r["kernel"], str(r.get("size", "")))] = r
     return d
-files = [load(p) for p in sys.argv[1:]]
+files = [load(p) for p in sys.argv[1:] if p != "-q"]
 means = [collections.defaultdict(list) for _ in files]
 for k in files[0]:
     row = [f.get(k, {}).get("algorithmic_gb_per_s") for f in files]
