@@ -477,6 +477,8 @@ template <int W, int H> struct WindowPlan
 	static constexpr int SPAN = 16;                          // candidates at most this far apart, in rows and in columns
 	static constexpr int WIN_DW = (W + SPAN + 3 + 3) / 4;    // dwords of the widest window row (3 more bytes of misalignment): 21, 17, 13
 	static constexpr int LROW = W == 64 ? 21 : W == 48 ? 20 : 13;   // LDS row pitch in dwords (the compute phase's reads: 2-way / none / 2-way bank conflicts)
+	// (64-wide at a pitch of 24 with three aligned ds_read_b64 per lane, row and candidate -- conflict-free: 12 y + 2 j mod 32 -- measured
+	// 3 - 6 % SLOWER than the 2-way conflicts of dword reads at 21: the bank conflicts are not what holds this kernel; profiles/r02_sad4_window_ab.txt)
 	static constexpr int LPRW = (WIN_DW + 3) / 4;            // staging: lanes (16 bytes each) per window row: 6, 5, 4
 	static constexpr int ROWS = H + SPAN;
 	static constexpr int NI = (ROWS * LPRW + kWave - 1) / kWave;   // staging instructions: lane l of instruction i holds piece 64 i + l of the window
