@@ -538,8 +538,8 @@ __device__ __forceinline__ WindowGeometry window_geometry(const uint32_t *__rest
 	return g;
 }
 
-// Issue every load of one block: the window pieces (global -> registers; lane l of instruction i holds piece 64 i + l of the
-// window, LPRW pieces of 16 bytes per row, the last piece of a row pulled in to end with the LDS row) and the source rows.
+// Issue every load of one block: the source rows and the window pieces (global -> registers; lane l of instruction i holds piece
+// 64 i + l of the window, LPRW pieces of 16 bytes per row, the last piece of a row pulled in to end with the LDS row).
 // No lane is ever switched off: a piece past the window's last row repeats that row, a piece below a_min / above a_max
 // repeats its neighbour (same bytes to the same LDS words) -- nothing outside the candidates' own address range is read.
 template <int W, int H>
@@ -547,11 +547,25 @@ __device__ __forceinline__ void window_issue(const WindowGeometry &g, const uint
 		u32x4 (&st)[WindowPlan<W, H>::NI], uint32_t (&spos)[WindowPlan<W, H>::NI], Chunk<WindowPlan<W, H>::C> (&s)[WindowPlan<W, H>::TRIPS])
 {
 	typedef WindowPlan<W, H> P;
+	// the source rows go first: loads return in issue order, and the first trip of the arithmetic starts as soon as ITS window rows have
+	// landed (sad4_window_kernel), which must not have to wait for loads issued behind them
+	const uint32_t y0 = lane >> 2, j = lane & 3u;
+	auto load_src = [&]()
+	{
+#pragma unroll
+		for (int t = 0; t < P::TRIPS; ++t)
+		{
+			const uint8_t *p = src + (size_t)(g.so + ((uint32_t)(t * 16) + y0) * ss32 + j * (uint32_t)P::C);
+			if (W != 48) s[t].load_stream(p); else s[t].load(p);       // as the generic kernel: streaming where waves cover whole lines
+		}
+	};
+	constexpr bool SRC_FIRST = true;
+	if (SRC_FIRST) load_src();
 #pragma unroll
 	for (int i = 0; i < P::NI; ++i)
 	{
 		const uint32_t piece = (uint32_t)(i * kWave) + lane, srow = piece / P::LPRW;
-		const uint32_t scol = min((piece - srow * P::LPRW) * 4u, (uint32_t)(P::LROW - 4));
+		const uint32_t scol = min((piece - srow * P::LPRW) * 4u, (uint32_t)(P::WIN_DW - 4));
 		const uint32_t row = min(srow, g.last_row);
 		// the piece's address relative to a_min (a small number of either sign on row 0, positive below it: stride <= 2^20),
 		// moved inside [0, span]; rows are word-aligned with each other (stride % 4 == 0: window_stride_ok)
@@ -560,67 +574,52 @@ __device__ __forceinline__ void window_issue(const WindowGeometry &g, const uint
 		st[i] = reinterpret_cast<const U4 *>(ref_al + (size_t)(g.a_min + (uint32_t)rel_in))->v;
 		spos[i] = (__umul24(row, (uint32_t)P::LROW) + scol + ((uint32_t)(rel_in - rel) >> 2)) & 0x3fffffffu;     // (rel_in - rel): a small multiple of 4 of either sign
 	}
-	const uint32_t y0 = lane >> 2, j = lane & 3u;
-#pragma unroll
-	for (int t = 0; t < P::TRIPS; ++t)
-	{
-		const uint8_t *p = src + (size_t)(g.so + ((uint32_t)(t * 16) + y0) * ss32 + j * (uint32_t)P::C);
-		if (W != 48) s[t].load_stream(p); else s[t].load(p);       // as the generic kernel: streaming where waves cover whole lines
-	}
+	if (!SRC_FIRST) load_src();
 }
 
-// Four SADs per source chunk, candidates read from LDS (the trip's row offset is an immediate of the ds_read); totals in lane 63.
+// One trip (16 block rows) of the four SADs: candidates read from LDS (the trip's row offset is an immediate of the ds_read).
 template <int W, int H>
-__device__ __forceinline__ void window_compute(const WindowGeometry &g, const uint32_t *lds, uint32_t lane,
-		const Chunk<WindowPlan<W, H>::C> (&s)[WindowPlan<W, H>::TRIPS], uint32_t (&total)[4])
+__device__ __forceinline__ void window_trip(const WindowGeometry &g, const uint32_t *const (&rk)[4], int t,
+		const Chunk<WindowPlan<W, H>::C> &s, uint32_t (&acc)[4])
 {
 	typedef WindowPlan<W, H> P;
-	const uint32_t y0 = lane >> 2, j = lane & 3u;
-	uint32_t acc[4] = { 0, 0, 0, 0 };
-	const uint32_t *rk[4];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) rk[k] = lds + (__umul24(y0 + g.Y[k], (uint32_t)P::LROW) + (g.X[k] >> 2) + j * (uint32_t)P::CD);
-#pragma unroll
-	for (int t = 0; t < P::TRIPS; ++t)
+	for (int k = 0; k < 4; ++k)
 	{
+		const uint32_t *r = rk[k] + t * 16 * P::LROW;
+		uint32_t w[P::CD + 1];
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			const uint32_t *r = rk[k] + t * 16 * P::LROW;
-			uint32_t w[P::CD + 1];
+		for (int q = 0; q <= P::CD; ++q) w[q] = r[q];
+		const uint32_t sh = g.X[k] & 3u;
 #pragma unroll
-			for (int q = 0; q <= P::CD; ++q) w[q] = r[q];
-			const uint32_t sh = g.X[k] & 3u;
-#pragma unroll
-			for (int q = 0; q < P::CD; ++q)
-				acc[k] = __builtin_amdgcn_sad_u8(s[t].d[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), acc[k]);
-		}
-		__builtin_amdgcn_sched_barrier(0);    // one trip's LDS reads live at a time
+		for (int q = 0; q < P::CD; ++q)
+			acc[k] = __builtin_amdgcn_sad_u8(s.d[q], __builtin_amdgcn_alignbyte(w[q + 1], w[q], sh), acc[k]);
 	}
-#pragma unroll
-	for (int k = 0; k < 4; ++k) total[k] = wave_sum_to_lane63(acc[k]);
 }
 
-// BPWV consecutive blocks per wave, one after the other: while block b is computed out of LDS, the loads of block b + 1 are
-// already in flight (its descriptors arrived during block b - 1), so a wave never sits through a memory round trip idle.
-template <int W, int H, int BPWV>
+// One block per wave.  (More than one -- the next block's loads in flight while this one is computed -- measured slower: 4 consecutive
+// blocks per wave +34 %, 4 blocks dealt round-robin over the workgroup's waves +11 %: many short waves on NEIGHBOURING blocks, which
+// share the 128-byte lines of their source rows and of the overlap of their windows, beat fewer, deeper ones.  And every branch
+// between a load and its use makes the compiler's wait counts conservative: a conditionally issued prefetch in a loop made every
+// compute phase wait for ALL loads in flight, 1.3 - 2.2x slower.  profiles/r02_sad4_window_ab.txt)
+template <int W, int H>
 __global__ __launch_bounds__(kThreads) void sad4_window_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, uint32_t n_blocks, uint32_t inv_stride /* floor(2^32 / stride_ref) + 1 */)
+	int *__restrict__ out, uint32_t n_blocks, uint32_t inv_stride /* floor(2^32 / stride_ref) + 1; 0: every block takes the generic code */)
 {
 	typedef WindowPlan<W, H> P;
-	__shared__ uint32_t lds_all[(kThreads / kWave) * P::ROWS * P::LROW];
+	// 64 rows: the LDS allocation is rounded up to 40 KiB, i.e. four workgroups per CU instead of five (same-box sweep at 64x64 / 48x64:
+	// five +2 %, three +13 %, two +34 % against four; 48 rows prefer their natural six; profiles/r02_sad4_window_ab.txt)
+	// (32 / 48 rows rounded up to 32 KiB -- five workgroups per CU instead of seven: close candidates +7 ... +8 %, far ones -3 ... -10 %: left alone)
+	__shared__ uint32_t lds_all[H == 64 ? 10240 : (kThreads / kWave) * P::ROWS * P::LROW];
 
-	// A workgroup owns 4 BPWV consecutive blocks; its four waves take them round-robin, so that at any time the workgroup is on
-	// four NEIGHBOURING blocks (they share the 128-byte lines of their source rows and of the overlap of their windows).
+	// the four waves of a workgroup are on four neighbouring blocks
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave_in_wg = threadIdx.x >> 6;
-	constexpr uint32_t STEP = kThreads / kWave;
-	const uint32_t first = __builtin_amdgcn_readfirstlane(wg * (STEP * BPWV) + wave_in_wg);
-	if (first >= n_blocks) return;
-	const uint32_t end = min(first + STEP * (uint32_t)(BPWV - 1) + 1u, n_blocks);      // this wave's blocks: first, first + STEP, ... < end
+	const uint32_t blk = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + wave_in_wg);
+	if (blk >= n_blocks) return;
 	const uint32_t lane = threadIdx.x & 63;
 	uint32_t *lds = lds_all + wave_in_wg * (P::ROWS * P::LROW);
 
@@ -628,106 +627,82 @@ __global__ __launch_bounds__(kThreads) void sad4_window_kernel(
 	const uint8_t *const ref_al = ref - ref_mis;
 	const uint32_t sr32 = (uint32_t)stride_ref, ss32 = (uint32_t)stride_src;
 
-	u32x4 st[P::NI];
-	uint32_t spos[P::NI];
-	Chunk<P::C> sa[P::TRIPS], sb[P::TRIPS];
+	const WindowGeometry g = window_geometry<W, H>(src_off, ref_off, blk, ref_mis, sr32, inv_stride);
+	if (g.close)
+	{
+		u32x4 st[P::NI];
+		uint32_t spos[P::NI];
+		Chunk<P::C> s[P::TRIPS];
+		window_issue<W, H>(g, ref_al, src, sr32, ss32, lane, st, spos, s);
 
-	auto park = [&]()
-	{
+		const uint32_t y0 = lane >> 2, j = lane & 3u;
+		const uint32_t *rk[4];
 #pragma unroll
-		for (int i = 0; i < P::NI; ++i)
+		for (int k = 0; k < 4; ++k) rk[k] = lds + (__umul24(y0 + g.Y[k], (uint32_t)P::LROW) + (g.X[k] >> 2) + j * (uint32_t)P::CD);
+		uint32_t acc[4] = { 0, 0, 0, 0 };
+		// Trip t reads window rows up to 16 t + 15 + SPAN: as soon as the pieces that hold them have landed they are parked in LDS and the
+		// trip runs, while the rest of the window is still on its way (straight-line code: the wait counts are exact).
+		int parked = 0;
+#pragma unroll
+		for (int t = 0; t < P::TRIPS; ++t)
 		{
-			uint32_t *d = lds + spos[i];
-			d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
+			// (16 / 32 rows: -9 % / -4 % against parking the whole window first; 48 / 64 rows: +1 ... +5 %, so they park everything at once)
+			constexpr bool PIPELINED = H <= 32;
+			const int need = PIPELINED ? min(P::NI, ((t * 16 + 16 + P::SPAN) * P::LPRW + kWave - 1) / kWave) : P::NI;   // staging instructions that cover those rows
+#pragma unroll
+			for (int i = 0; i < P::NI; ++i)
+			{
+				if (i >= parked && i < need)
+				{
+					uint32_t *d = lds + spos[i];
+					d[0] = st[i].x; d[1] = st[i].y; d[2] = st[i].z; d[3] = st[i].w;
+				}
+			}
+			parked = need;
+			// the wave's own LDS accesses are in order (one wave, one LDS queue); keep the compiler from reordering them
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			window_trip<W, H>(g, rk, t, s[t], acc);
+			__builtin_amdgcn_sched_barrier(0);    // one trip's LDS reads live at a time
 		}
-		// the wave's own LDS accesses are in order (one wave, one LDS queue); keep the compiler from reordering them
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-	};
-	auto finish = [&](const WindowGeometry &g, uint32_t blk, Chunk<P::C> (&s)[P::TRIPS])
-	{
 		uint32_t total[4];
-		window_compute<W, H>(g, lds, lane, s, total);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) total[k] = wave_sum_to_lane63(acc[k]);
 		if (lane == 63)
 		{
 			u32x4 v; v.x = total[0]; v.y = total[1]; v.z = total[2]; v.w = total[3];
 			reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-	};
-
-	// Do all of this wave's blocks qualify?  (The usual case: a batch is one search step, its candidate patterns alike.)
-	bool all_close = first + STEP * (uint32_t)(BPWV - 1) < n_blocks;
-#pragma unroll
-	for (int b = 0; b < BPWV; ++b)
-		if (first + STEP * b < end) all_close = all_close && window_geometry<W, H>(src_off, ref_off, first + STEP * b, ref_mis, sr32, inv_stride).close;
-
-	if (all_close)
-	{
-		// Straight-line pipeline, no branch anywhere between a load and its use (the compiler's wait counts are exact only
-		// along straight code: one conditional issue in the loop made every compute phase wait for ALL loads in flight, and
-		// the kernel ran 1.3 - 2.2x slower than with one block per wave).
-		WindowGeometry g[2];
-		g[0] = window_geometry<W, H>(src_off, ref_off, first, ref_mis, sr32, inv_stride);
-		window_issue<W, H>(g[0], ref_al, src, sr32, ss32, lane, st, spos, sa);
-#pragma unroll
-		for (int b = 0; b < BPWV; ++b)
-		{
-			park();                                     // block b's window: registers -> LDS (waits for its pieces only)
-			if (b + 1 < BPWV)
-			{
-				g[(b + 1) & 1] = window_geometry<W, H>(src_off, ref_off, first + STEP * (b + 1), ref_mis, sr32, inv_stride);
-				window_issue<W, H>(g[(b + 1) & 1], ref_al, src, sr32, ss32, lane, st, spos, (b & 1) ? sa : sb);
-			}
-			__builtin_amdgcn_sched_barrier(0);
-			finish(g[b & 1], first + STEP * b, (b & 1) ? sb : sa);
-		}
 		return;
 	}
-	// Mixed or ragged group: block by block, nothing overlapped.  A block whose candidates lie far apart is computed by the
-	// generic code at this kernel's mapping (one block per wave: 16 rows in flight, a single trip of H / 16 rows per lane).
-	for (uint32_t blk = first; blk < end; blk += STEP)
+	// Candidates far apart: the generic code at this kernel's mapping (one block per wave: 16 rows in flight, a single trip).
+	// (64 rows in two parts of 2 rows per lane: as one part of 4 this path needs 161 registers and takes the window path's occupancy
+	// from 5 waves per SIMD to 3: +6 % on close candidates.  48 rows as one part of 3: 124 registers, 4 waves instead of 5 -- close
+	// candidates +4 %, far ones -13 %; holding that to 96 registers with launch bounds spills: close +15 %, far +46 %.)
+	uint32_t sum[4] = { 0, 0, 0, 0 }, part[4];
+	if constexpr (H == 64)
 	{
-		const WindowGeometry g = window_geometry<W, H>(src_off, ref_off, blk, ref_mis, sr32, inv_stride);
-		if (g.close)
-		{
-			window_issue<W, H>(g, ref_al, src, sr32, ss32, lane, st, spos, sa);
-			park();
-			finish(g, blk, sa);
-		}
-		else
-		{
-			// (64 rows in two parts of 2 rows per lane: as one part of 4 this path needs 161 registers and takes the window path's
-			// occupancy from 5 waves per SIMD to 3: +6 % on close candidates)
-			uint32_t sum[4] = { 0, 0, 0, 0 }, part[4];
-			if constexpr (H == 64)
-			{
-				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
-				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 32u, part);
+		block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
+		block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 32u, part);
 #pragma unroll
-				for (int k = 0; k < 4; ++k) sum[k] += part[k];
-			}
-			else if constexpr (H == 48)
-			{
-				// (as one part of 3 rows per lane: 124 registers, 4 waves per SIMD instead of 5 -- close candidates +4 %, far ones -13 %;
-				// holding that part to 96 registers with launch bounds spills: close +15 %, far +46 %)
-				block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
-				block_cost_sums<W, P::C, 16, 1, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 16, lane, blk, 32u, part);
+		for (int k = 0; k < 4; ++k) sum[k] += part[k];
+	}
+	else if constexpr (H == 48)
+	{
+		block_cost_sums<W, P::C, 16, 2, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 32, lane, blk, 0u, sum);
+		block_cost_sums<W, P::C, 16, 1, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, 16, lane, blk, 32u, part);
 #pragma unroll
-				for (int k = 0; k < 4; ++k) sum[k] += part[k];
-			}
-			else
-			{
-				block_cost_sums<W, P::C, 16, H / 16, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, sum);
-			}
-			if (lane == 0)
-			{
-				u32x4 v; v.x = sum[0]; v.y = sum[1]; v.z = sum[2]; v.w = sum[3];
-				reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
-			}
-		}
+		for (int k = 0; k < 4; ++k) sum[k] += part[k];
+	}
+	else
+	{
+		block_cost_sums<W, P::C, 16, H / 16, 4, OP_SAD, false, false>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, sum);
+	}
+	if (lane == 0)
+	{
+		u32x4 v; v.x = sum[0]; v.y = sum[1]; v.z = sum[2]; v.w = sum[3];
+		reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
 	}
 }
 
@@ -745,12 +720,8 @@ static bool window_stride_ok(ptrdiff_t sr, int W) { return sr >= W + 64 && sr <=
 template <int W> static int launch_window(const Args &a)
 {
 	const uint32_t inv = getenv("HEVCASM_SAD4_NOWINDOW") ? 0u : (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;    // (0: every block takes the generic code -- measurements only)
-	// Blocks per wave of the window kernel.  More than one (the next block's loads in flight while this one is computed, blocks dealt
-	// round-robin over the workgroup's waves) was measured slower: 4 per wave +11 % (+34 % with each wave on consecutive blocks) against
-	// one block per wave -- many short waves on neighbouring blocks beat fewer, deeper ones (gpurun_out/ab2_sad4_window[34].txt).
-	constexpr int BPWV = 1;
-	const uint32_t grid1 = ceil_div(a.n, BPWV * (kThreads / kWave));
-#define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM, BPWV>), dim3(grid1), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
+	const uint32_t grid = ceil_div(a.n, kThreads / kWave);
+#define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM>), dim3(grid), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
 	if (a.H == 16) WINDOW(16); else if (a.H == 32) WINDOW(32); else if (a.H == 48) WINDOW(48); else WINDOW(64);
 #undef WINDOW
 	return launch_status("sad4_window_kernel");
