@@ -140,6 +140,45 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
                 sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3))
 
 
+def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
+    """This library's own host table entries with the HIP bit masked off -- what a codec that keeps calling per block gets:
+    the SSE2 / AVX2 intrinsics kernels of csrc/host/sad_x86.c where the reference has x86 assembly, the C path elsewhere -- timed by
+    hevcasm_amd/lib/hevcasm_host_bench, one process per core, on the same size mix.  (The reference's assembly itself cannot be
+    assembled in this image: no yasm / nasm.)"""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from hevcasm_amd import capi
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "hevcasm_host_bench")
+    if not os.path.exists(exe):
+        return None
+    procs_n = max(1, min(max_procs, os.cpu_count() or 1))
+    mask = capi.lib().hevcasm_instruction_set_support() & ~capi.HIP
+    ms_each = max(20, int(1000.0 * budget_s / (2 * len(sizes))))
+    want = set((w, h) for (w, h) in sizes)
+
+    def worker(i):
+        out = subprocess.run([exe, "%x" % mask, str(ms_each), str(sample_blocks), str(1234 + i)], capture_output=True, text=True,
+                             env=dict(os.environ, HEVCASM_DISABLE_HIP="1"), timeout=600)
+        if out.returncode != 0:
+            raise RuntimeError("hevcasm_host_bench failed: " + out.stderr[-500:])
+        rates = {}
+        for line in out.stdout.splitlines():
+            w, h, ways, blocks, secs = line.split()
+            if (int(w), int(h)) in want:
+                rates[(int(w), int(h), int(ways))] = int(blocks) / float(secs)
+        return rates
+
+    with ThreadPoolExecutor(procs_n) as ex:
+        per_proc = list(ex.map(worker, range(procs_n)))
+    combos = sorted(per_proc[0])
+    total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
+    names = [n for n, bit in (("SSE2", capi.SSE2), ("AVX2", capi.AVX2)) if mask & bit]
+    return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="port", value_per_core=round(total / procs_n / 1e6, 3),
+                sample="this library's host table entries (mask %#x: %s intrinsics kernels where the reference has x86 asm, C elsewhere), per-block calls, "
+                       "%d processes x %d (size, ways) combos x %d blocks repeated for %d ms each, same size mix" % (mask, "/".join(names) or "no SIMD", procs_n, len(combos), sample_blocks, ms_each),
+                sad16x16_single_ref_mblocks_per_s=round(sum(r.get((16, 16, 1), 0.0) for r in per_proc) / 1e6, 3))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -269,11 +308,14 @@ def main():
         fam.SINK = None
 
     if rank == 0:
-        cpu = None
+        cpu, simd = None, None
         if world == 1 and args.cpu_seconds > 0:
             cpu = cpu_baseline(sizes, 2048, args.cpu_seconds)
             if cpu:
                 cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
+            simd = host_simd_baseline(sizes, 2048, min(args.cpu_seconds, 8.0))
+            if simd:
+                simd["gpu_multiple"] = round(value / simd["value"], 1)
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -292,6 +334,7 @@ def main():
                                  "bytes per launch, rocprofv3 PMC passes); SURVEY 8(d)'s 5WH+16 counts the candidates as disjoint and would read %.0f GB/s"
                                  % ((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9) if dom_key[2] == 4 else None},
             "cpu_baseline": cpu,
+            "cpu_baseline_simd": simd,
             "headline": {"sad_16x16_single_ref": head[0] if head else None, "inter_pred_and_idct": others,
                          "note": "value = config #2 (the SAD mix) only; the other kernels the metric names are measured in the same run on configs #3 / #4 "
                                  "(64 frames of 1080p tiled by 16x16 PUs; 2^26 coefficients per launch), outside the timed region"},

@@ -2,47 +2,66 @@
  * sad.c -- selectors and self-tests for SAD and 4-way multi-reference SAD.
  *
  * Selection rule (reference sad.c:63-98, :128-180): a table slot gets the best implementation
- * whose instruction-set bit is in `mask`, or NULL when none is.  Here "best" is the HIP
- * per-block entry when HEVCASM_HIP is set, else the C function when C_REF or C_OPT is set; the
- * x86 SIMD bits select nothing.  Self-tests follow reference sad.c:184-340: 23 partitions,
- * 128x128 random planes, strides 64, references deliberately misaligned.
+ * whose instruction-set bit is in `mask`, or NULL when none is: the HIP per-block entry when
+ * HEVCASM_HIP is set; else, where the reference has x86 assembly, the same kernel written with
+ * intrinsics (sad_x86.c) -- HEVCASM_SSE2: the eleven named sizes, one reference (sad.c:65-78) and four
+ * (sad.c:134-147); HEVCASM_AVX2: four references at every width, keyed on the width, except that at
+ * width 8 an SSE2 entry is kept when there is one (sad.c:149-159), and one reference at widths 32 and 64;
+ * else the C function when C_REF or C_OPT is set.  Self-tests follow reference sad.c:184-340: 23
+ * partitions, 128x128 random planes, strides 64, references deliberately misaligned.
  */
 #include "sad.h"
 #include "cpath.h"
 #include "perblock.h"
+#include "sad_x86.h"
 #include "hevcasm_test.h"
 
 #include <stdlib.h>
 
-static hevcasm_sad *select_sad(hevcasm_instruction_set mask)
+static int named_size(int w, int h)
+{
+	static const unsigned char named[11][2] = { { 64, 64 }, { 64, 32 }, { 32, 64 }, { 32, 32 }, { 32, 16 }, { 16, 32 }, { 16, 16 }, { 16, 8 }, { 8, 16 }, { 8, 8 }, { 8, 4 } };
+	for (int i = 0; i < 11; ++i)
+		if (named[i][0] == w && named[i][1] == h) return 1;
+	return 0;
+}
+
+static hevcasm_sad *select_sad(int w, int h, hevcasm_instruction_set mask)
 {
 	if (mask & HEVCASM_HIP) return hevcasm_hip1_sad;
+#if defined(__x86_64__) || defined(__i386__)
+	if ((mask & HEVCASM_AVX2) && (w == 64 || w == 32) && named_size(w, h)) return hevcasm_avx2_sad;
+	if ((mask & HEVCASM_SSE2) && named_size(w, h)) return hevcasm_sse2_sad;
+#endif
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) return hevcasm_c_sad;
 	return 0;
 }
 
 void hevcasm_populate_sad(hevcasm_table_sad *table, hevcasm_instruction_set mask)
 {
-	hevcasm_sad *f = select_sad(mask);
 	for (int h = 4; h <= 64; h += 4)
 		for (int w = 4; w <= 64; w += 4)
-			*hevcasm_get_sad(table, w, h) = f;
+			*hevcasm_get_sad(table, w, h) = select_sad(w, h, mask);
 }
 
-static hevcasm_sad_multiref *select_sad_multiref(hevcasm_instruction_set mask)
+static hevcasm_sad_multiref *select_sad_multiref(int w, int h, hevcasm_instruction_set mask)
 {
+	hevcasm_sad_multiref *f = 0;
 	if (mask & HEVCASM_HIP) return hevcasm_hip1_sad_multiref_4;
-	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) return hevcasm_c_sad_multiref_4;
-	return 0;
+#if defined(__x86_64__) || defined(__i386__)
+	if ((mask & HEVCASM_SSE2) && named_size(w, h)) f = hevcasm_sse2_sad_multiref_4;
+	if ((mask & HEVCASM_AVX2) && !(w == 8 && f)) f = hevcasm_avx2_sad_multiref_4;      /* reference sad.c:157: case 8: if (!f) */
+#endif
+	if (!f && (mask & (HEVCASM_C_REF | HEVCASM_C_OPT))) f = hevcasm_c_sad_multiref_4;
+	return f;
 }
 
 void hevcasm_populate_sad_multiref(hevcasm_table_sad_multiref *table, hevcasm_instruction_set mask)
 {
-	hevcasm_sad_multiref *f = select_sad_multiref(mask);
 	for (int h = 4; h <= 64; h += 4)
 		for (int w = 4; w <= 64; w += 4)
-			*hevcasm_get_sad_multiref(table, 4, w, h) = f;
-	table->sadGeneric_4 = f;
+			*hevcasm_get_sad_multiref(table, 4, w, h) = select_sad_multiref(w, h, mask);
+	table->sadGeneric_4 = select_sad_multiref(4, 4, mask & ~HEVCASM_SSE2);
 }
 
 /* the partitions of reference sad.c:231-240 */

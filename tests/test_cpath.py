@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import cases
-from hevcasm_amd import capi
+from hevcasm_amd import capi, workload as wl
 
 PD = C.c_ssize_t
 VP = C.c_void_p
@@ -51,6 +51,51 @@ def test_sad_and_multiref_and_ssd(oracle_lib):
             f = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD, C.c_int, C.c_int)(_slot("hevcasm_populate_ssd", 5, int(np.log2(w)) - 2))
             got = [f(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, c["ref_off"][i]), c["stride_ref"], w, h) for i in range(n)]
             assert np.array_equal(np.array(got), want), name
+
+
+def test_sad_x86_simd_entries(oracle_lib):
+    """The SSE2 / AVX2 table entries (csrc/host/sad_x86.c: the reference's x86 kernels written with intrinsics) against the
+    oracle, selected with single-bit masks as the reference's self-test does; every size and, for the 4-way AVX2 kernel, every
+    multiple-of-4 width; misaligned planes; NULL where the reference's table has no entry for the bit."""
+    L = capi.lib()
+    have = L.hevcasm_instruction_set_support()
+    if not (have & capi.SSE2):
+        pytest.skip("not an x86 host")
+    named = [(64, 64), (64, 32), (32, 64), (32, 32), (32, 16), (16, 32), (16, 16), (16, 8), (8, 16), (8, 8), (8, 4)]
+    sizes = wl.SAD_PARTITIONS + [(w, 20) for w in range(4, 68, 4)]
+    for (w, h) in sizes:
+        c = wl.sad_case(w, h, 9, 7000 + 64 * w + h, ways=4)
+        src, ref = np.ascontiguousarray(c["src"]), np.ascontiguousarray(c["ref"])
+        want4 = cases.run_oracle("sad4", c)[0]
+        ro = c["ref_off"].reshape(-1, 4)
+        for mask in (capi.SSE2, capi.AVX2):
+            if not (have & mask):
+                continue
+            # four references
+            buf = (C.c_void_p * 257)()
+            L.hevcasm_populate_sad_multiref(buf, mask)
+            slot = buf[((w >> 2) - 1) * 16 + (h >> 2) - 1]
+            expect_entry = (w, h) in named if mask == capi.SSE2 else True
+            assert bool(slot) == expect_entry, (w, h, mask)
+            if slot:
+                f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP, C.c_uint32)(slot)
+                for i in range(c["n"]):
+                    refs = (C.c_void_p * 4)(*[_ptr(ref, ro[i, k]) for k in range(4)])
+                    out = (C.c_int * 4)()
+                    f(_ptr(src, c["src_off"][i]), c["stride_src"], refs, c["stride_ref"], out, capi.rect(w, h))
+                    assert list(out) == list(want4[i]), (w, h, mask, i)
+            # one reference
+            buf1 = (C.c_void_p * 12)()
+            L.hevcasm_populate_sad(buf1, mask)
+            if (w, h) in named:
+                slot1 = buf1[_sad_slot_index(w, h)]
+                assert bool(slot1) == (mask == capi.SSE2 or w >= 32), (w, h, mask)
+                if slot1:
+                    f1 = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD, C.c_uint32)(slot1)
+                    got = [f1(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, ro[i, 0]), c["stride_ref"], capi.rect(w, h)) for i in range(c["n"])]
+                    assert got == [int(v) for v in want4[:, 0]], (w, h, mask)
+            else:
+                assert not buf1[11], "sadGeneric must be NULL for an x86-only mask"   # reference sad.c:80-85: only a C bit fills it
 
 
 def test_hadamard_satd(oracle_lib):
