@@ -71,8 +71,9 @@ def test_table_layouts_match_reference_abi():
 @pytest.mark.parametrize("name", ["sad", "sad_multiref", "ssd", "hadamard_satd", "pred_uni_8to8", "pred_bi_8to8", "transform",
                                   "quantize_inverse", "quantize", "quantize_reconstruct"])
 def test_selector_masks(name):
-    """NULL = unsupported (reference convention): x86 SIMD bits alone select nothing here;
-    C bits select the C path; the HIP bit selects different (per-block HIP) entries."""
+    """NULL = unsupported (reference convention): x86 SIMD bits alone select nothing, except for SAD and 4-way SAD, where
+    they select the intrinsics kernels of csrc/host/sad_x86.c exactly where the reference selects its assembly (reference
+    sad.c:63-86, :128-167); C bits select the C path; the HIP bit selects different (per-block HIP) entries."""
     L = capi.lib()
     slots = 300
 
@@ -81,9 +82,15 @@ def test_selector_masks(name):
         getattr(L, "hevcasm_populate_" + name)(buf, mask)
         return [buf[i] for i in range(slots)]
 
-    none = pop(capi.SSE2 | capi.AVX2)
-    assert not any(none)
+    simd = pop(capi.SSE2 | capi.AVX2)
     c_ref, c_opt, hip = pop(capi.C_REF), pop(capi.C_OPT), pop(capi.HIP)
+    if name in ("sad", "sad_multiref") and (L.hevcasm_instruction_set_support() & capi.SSE2):
+        assert any(simd) and all(s != c for s, c in zip(simd, c_ref) if s)
+        if name == "sad":
+            assert sum(bool(x) for x in simd) == 11      # the eleven named sizes; the shared generic slot only ever gets the C function
+            assert pop(capi.C_REF | capi.SSE2)[:11] == pop(capi.SSE2)[:11] and pop(capi.C_REF | capi.SSE2)[11] == c_ref[11]
+    else:
+        assert not any(simd)
     assert any(c_ref) and c_ref == c_opt
     assert any(hip) and [bool(x) for x in hip] == [bool(x) for x in c_ref]
     assert all(h != c for h, c in zip(hip, c_ref) if h)
