@@ -313,7 +313,9 @@ def main():
             cpu = cpu_baseline(sizes, 2048, args.cpu_seconds)
             if cpu:
                 cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
-            simd = host_simd_baseline(sizes, 2048, min(args.cpu_seconds, 8.0))
+            # 16 Ki blocks per size and process: 16 processes x up to 260 MB of frames, beyond the host's last-level cache, so that this
+            # column is a memory-resident figure like the GPU's (with 2 Ki blocks everything sits in L3 and the figure doubles)
+            simd = host_simd_baseline(sizes, 16384, min(args.cpu_seconds, 8.0))
             if simd:
                 simd["gpu_multiple"] = round(value / simd["value"], 1)
         line = {
