@@ -38,6 +38,14 @@
 
 namespace hevc {
 
+// Diagnostic build only (-DPRED_STAMPS, tools/pred_timeline.py): per-wave s_memtime stamps into a buffer that nothing else reads
+#ifdef PRED_STAMPS
+__device__ unsigned long long *g_pred_stamps = nullptr;
+#define STAMP(i) do { if (stamps && lane == 0) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 // Filter taps (HEVC 8.5.3.3.3: luma quarter-pel, chroma eighth-pel).  Every tap fits a signed byte, so tap k of all phases is one
@@ -312,6 +320,10 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 
 	const int cols = min(CPL, W - CPL * j);           // output columns this lane stores (<= 0: none)
 	const bool stores = in_batch && !spare && cols > 0;
+#ifdef PRED_STAMPS
+	unsigned long long *stamps = g_pred_stamps ? g_pred_stamps + (size_t)wave * 32 : nullptr;
+#endif
+	STAMP(0);
 
 	// Every byte a block touches lies within 4 GiB above its plane's base pointer (hevcasm_hip.h), so rows are addressed as
 	// uniform base + 32-bit lane offset: one VGPR and one add per row and plane instead of a 64-bit pointer.
@@ -343,6 +355,10 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	}
 	uint32_t out_off = dst_off[pu] + (uint32_t)y_first * step_dst + (uint32_t)(CPL * j);
 	const int rows = H + TAPS - 1;                    // window rows
+#ifdef PRED_STAMPS
+	if (stamps && lane == 0 && (rs[0].off + out_off) == 0xdeadbeefu) stamps[31] = 1;     // forces the descriptors to have arrived
+	STAMP(1);
+#endif
 
 	// prologue: window rows 0 .. T-2 into slots 0 .. T-2, and the load of row T-1 in flight
 #pragma unroll
@@ -356,7 +372,13 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 		{
 			rs[r].realign(first[q]);
 			rs[r].unpack(q, first[q]);
+#ifdef PRED_STAMPS
+			if (r == 0 && q == 0) { if (stamps && lane == 0 && rs[0].e[0][0] == 0xdeadbeefu) stamps[31] = 2; STAMP(2); }
+#endif
 		}
+#ifdef PRED_STAMPS
+		if (r == 0) { if (stamps && lane == 0 && rs[0].e[TAPS - 2][0] == 0xdeadbeefu) stamps[31] = 3; STAMP(3); }
+#endif
 		// window rows T-1 .. T-2+AHEAD; row T-1+a has ring slot a (output row a consumes it).  One branch around the whole
 		// group when the PU has that many rows (a branch around every single load keeps them from being issued back to back)
 		if (H >= AHEAD)
@@ -447,6 +469,9 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 					}
 				}
 				out_off += step_dst;
+#ifdef PRED_STAMPS
+				if (y < 24) { if (stamps && lane == 0 && px[0] == 0xdeadbeefu && y == 99) stamps[31] = 4; STAMP(4 + y); }
+#endif
 			}
 		}
 	}
@@ -507,6 +532,13 @@ static int check_pred_args(int taps, int W, int H, size_t n)
 }  // namespace hevc
 
 using namespace hevc;
+
+#ifdef PRED_STAMPS
+extern "C" int hevcasm_hip_debug_pred_stamps(unsigned long long *buf)
+{
+	return (int)hipMemcpyToSymbol(HIP_SYMBOL(hevc::g_pred_stamps), &buf, sizeof(buf));
+}
+#endif
 
 extern "C" int hevcasm_hip_pred_uni_8to8_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
