@@ -34,7 +34,7 @@ for i in range(3):
     res = (ms, s)
 ms, s = res
 rows = int((s[0, 4:28] != 0).sum())      # output rows this wave stored (tall PUs of small launches are cut into row segments)
-print("%s %d-tap %dx%d: %d waves of %d output rows, %.4f ms with instrumentation (the stamps make the kernel 2-4x slower; read the SHAPE, shader-clock cycles)" % (kind, taps, w, h, len(s), rows, ms))
+print("%s %d-tap %dx%d: %d waves of %d output rows, %.4f ms with instrumentation (includes the tool's descriptor uploads; shader-clock cycles below)" % (kind, taps, w, h, len(s), rows, ms))
 def pct(a): return "med %7d  p10 %7d  p90 %7d" % (np.median(a), np.percentile(a, 10), np.percentile(a, 90))
 print("  lifetime (entry -> last row stored)", pct(s[:, 4 + rows - 1] - s[:, 0]))
 print("  entry -> descriptors               ", pct(s[:, 1] - s[:, 0]))
