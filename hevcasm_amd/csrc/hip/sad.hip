@@ -466,10 +466,10 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 //     by scalar loads (not queued behind other waves' row loads) and the window geometry is scalar arithmetic;
 //   * a block qualifies when all four candidates lie within 16 rows and 16 columns of each other (decided from the
 //     offsets alone: offset differences are split into rows and columns with the row stride); any other block is computed
-//     by the same wave with the generic code (block_cost_body at this kernel's one-block-per-wave mapping);
-//   * memory touched: exactly the 4-byte-aligned words that hold a byte of some candidate's row -- per window row the
-//     staged range is the hull of the candidates that cover this row (they overlap horizontally, so the hull has no
-//     holes), and a lane whose 16 bytes would stick out of it is moved inside (its neighbour's bytes, stored twice).
+//     by the same wave with the generic code (block_cost_sums at this kernel's one-block-per-wave mapping);
+//   * memory touched: 4-byte-aligned words between the lowest and the highest word that hold a byte of any of the four
+//     candidates, and nothing outside that range (hevcasm_hip.h): a 16-byte piece of the window that would start below the
+//     first or end above the last of them is moved inside (and its LDS position with it: its neighbour's bytes, stored twice).
 template <int W, int H> struct WindowPlan
 {
 	static constexpr int C = W / 4;                          // bytes per lane and row in the compute phase: 4 lanes to a row (16, 12, 8)

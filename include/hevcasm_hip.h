@@ -79,7 +79,10 @@ int hevcasm_hip_sad_batch(
 
 /* Batched hevcasm_sad_multiref, 4 ways (reference sad.h:95, C body sad.c:101-121).
  * ref_off and sad hold 4 consecutive entries per block; all four candidates share `ref`
- * and stride_ref, as the reference's ref[] pointers share stride_ref. */
+ * and stride_ref, as the reference's ref[] pointers share stride_ref.
+ * Memory touched in the reference plane: whole 4-byte-aligned words, never below the lowest nor above the highest word that
+ * holds a byte of any of the block's four candidates (when the candidates lie within 16 pixels of each other the kernel reads
+ * their common window once, including words between them that belong to none). */
 int hevcasm_hip_sad_multiref_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *sad,
