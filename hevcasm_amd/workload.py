@@ -58,12 +58,18 @@ class Plane:
 
 
 def fill_u8(size, seed, kind="noise", device=None):
-    """``size`` bytes.  kind: 'noise' (uniform 0..255), 'zeros', 'max' (all 255)."""
+    """``size`` bytes.  kind: 'noise' (uniform 0..255), 'zeros', 'max' (all 255), 'video' (a smooth gradient plus noise of
+    sigma ~8, the second variant SURVEY.md 8(d) asks for config #2: neighbouring samples correlate as in real frames)."""
     if device is None:
         if kind == "zeros":
             return np.zeros(size, dtype=np.uint8)
         if kind == "max":
             return np.full(size, 255, dtype=np.uint8)
+        if kind == "video":
+            i = np.arange(size, dtype=np.int64)
+            base = 128 + 90 * np.sin(i / 97.0) * np.cos(i / 4099.0)
+            noise = np.random.default_rng(seed).normal(0.0, 8.0, size)
+            return np.clip(np.rint(base + noise), 0, 255).astype(np.uint8)
         return np.random.default_rng(seed).integers(0, 256, size=size, dtype=np.uint8)
     import torch
     if kind == "zeros":

@@ -31,6 +31,10 @@ def sad_cases(n=96, sizes=None, seed=100):
     out.append(("sad4_64x64_max", "sad4", c))
     c = wl.sad_case(16, 16, 8, seed + 97, kind="zeros")
     out.append(("sad_16x16_zero", "sad", c))
+    # video-like content (smooth gradient + noise): small, correlated differences instead of uniform noise
+    for (w, h) in [(64, 64), (16, 16), (32, 8), (48, 64), (8, 8)]:
+        out.append(("sad_%dx%d_video" % (w, h), "sad", wl.sad_case(w, h, 40, seed + 400 + w + h, kind="video")))
+        out.append(("sad4_%dx%d_video" % (w, h), "sad4", wl.sad_case(w, h, 40, seed + 450 + w + h, ways=4, kind="video")))
     # generic (non-table) sizes served by sadGeneric: every multiple of 4 is legal
     for (w, h) in [(4, 4), (20, 28), (36, 4), (44, 60), (52, 12), (60, 64), (28, 8), (40, 40), (56, 20)]:
         out.append(("sad_%dx%d" % (w, h), "sad", wl.sad_case(w, h, 40, seed + w + h)))
@@ -86,6 +90,8 @@ def pred_uni_cases(n=24, seed=300, sizes=None):
     # both clip rails: saturated inputs
     out.append(("uni8_max", "pred_uni", wl.pred_case(8, 32, 32, 8, seed + 70, kind="max")))
     out.append(("uni8_zero", "pred_uni", wl.pred_case(8, 32, 32, 8, seed + 71, kind="zeros")))
+    out.append(("uni8_video", "pred_uni", wl.pred_case(8, 16, 16, 12, seed + 74, kind="video")))
+    out.append(("uni4_video", "pred_uni", wl.pred_case(4, 8, 8, 12, seed + 75, kind="video")))
     out.append(("uni8_checker", "pred_uni", _checker(wl.pred_case(8, 64, 64, 6, seed + 72))))
     out.append(("uni4_checker", "pred_uni", _checker(wl.pred_case(4, 32, 32, 6, seed + 73))))
     return out
