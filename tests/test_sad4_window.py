@@ -10,7 +10,7 @@ from hevcasm_amd import workload as wl
 
 pytestmark = pytest.mark.gpu
 
-WIDE = [(64, 64), (64, 48), (64, 32), (64, 16), (48, 64), (32, 64), (32, 32), (32, 16), (48, 48), (48, 16)]
+WIDE = [(64, 64), (64, 48), (64, 32), (64, 16), (48, 64), (32, 64), (32, 32), (32, 16), (48, 48), (48, 16), (16, 64), (16, 32), (16, 16), (32, 48), (16, 48)]
 
 
 def _case(w, h, n, seed, disp, stride_pad=64):
@@ -66,7 +66,7 @@ def test_close_far_and_mixed(w, h):
     cases.assert_same("sad4 %dx%d row-wrapped" % (w, h), cases.run_hip("sad4", c), cases.run_oracle("sad4", c))
 
 
-@pytest.mark.parametrize("w,h", [(64, 64), (48, 64), (64, 16), (32, 32), (32, 64)])
+@pytest.mark.parametrize("w,h", [(64, 64), (48, 64), (64, 16), (32, 32), (32, 64), (16, 16), (16, 64)])
 def test_candidates_flush_with_the_plane_ends_and_tight_strides(w, h):
     """Planes that hold exactly the candidates' bounding box: the first block's window starts on byte 0 of the allocation,
     the last one's ends on its last byte; strides from the smallest the window path accepts downwards (generic path)."""
@@ -94,7 +94,7 @@ def test_candidates_flush_with_the_plane_ends_and_tight_strides(w, h):
 def test_misaligned_base_and_large_batch_equals_four_single_launches():
     import torch
     from hevcasm_amd import batch as B
-    for (w, h) in ((64, 64), (48, 64), (64, 32), (32, 32)):
+    for (w, h) in ((64, 64), (48, 64), (64, 32), (32, 32), (16, 32)):
         c = wl.sad_case(w, h, 4000, 900 + w + h, ways=4)
         so, ro4 = B.off32(c["src_off"]), B.off32(c["ref_off"])
         want = np.stack([B.sad(B.u8(c["src"]), c["stride_src"], B.u8(c["ref"]), c["stride_ref"], so, B.off32(c["ref_off"].reshape(-1, 4)[:, k].copy()), w, h).cpu().numpy()
