@@ -87,3 +87,27 @@ def test_executable_reports_instruction_sets():
     p.wait()
     text = "".join(head)
     assert "HEVCasm self test" in text and "[x] C_REF" in text and "[ ] HIP" in text
+
+
+def test_selftest_simd_columns_and_host_bench():
+    """With the host's x86 bits in the mask the SAD self-tests print SSE2 / AVX2 columns (csrc/host/sad_x86.c) and report no
+    mismatch; the per-block timing driver bench.py uses for its host-SIMD baseline runs and prints one row per size and way count."""
+    sys.path.insert(0, ROOT)
+    from hevcasm_amd import capi
+    mask = capi.lib().hevcasm_instruction_set_support() & ~capi.HIP
+    if not (mask & capi.SSE2):
+        import pytest
+        pytest.skip("not an x86 host")
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from hevcasm_amd import capi; L = capi.lib(); e = C.c_int(0)\n"
+            "L.hevcasm_test_sad(C.byref(e), %d); L.hevcasm_test_sad_multiref(C.byref(e), %d); print('ERRORS', e.value)" % (ROOT, mask, mask))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, HEVCASM_TEST_MAX_ITERATIONS="40"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ERRORS 0" in r.stdout and "MISMATCH" not in r.stdout
+    assert re.search(r"\t16x16: C_OPT:\d+ SSE2:\d+", r.stdout), r.stdout[:2000]
+    if mask & capi.AVX2:
+        assert re.search(r"4-way 64x48 :  C_OPT:\d+ AVX2:\d+", r.stdout), r.stdout[:2000]
+    exe = os.path.join(ROOT, "hevcasm_amd", "lib", "hevcasm_host_bench")
+    r = subprocess.run([exe, "%x" % mask, "1", "64"], capture_output=True, text=True, timeout=300, env=dict(os.environ, HEVCASM_DISABLE_HIP="1"))
+    assert r.returncode == 0, r.stderr[-500:]
+    rows = [l.split() for l in r.stdout.splitlines()]
+    assert len(rows) == 40 and all(len(x) == 5 and int(x[3]) >= 64 for x in rows), r.stdout
