@@ -35,6 +35,7 @@
 // Algorithmic bytes per PU: refs * (W + T - 1)(H + T - 1) + W * H (+ 4 (1 + refs) + refs descriptor bytes).
 
 #include "common.hpp"
+#include <cstdlib>
 
 namespace hevc {
 
@@ -284,7 +285,10 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	}
 };
 
-template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW>
+template <bool B> struct Flag { static constexpr bool value = B; };
+
+// FAST: W % 4 == 0 and (rows per wave) % TAPS == 0 -- the row loop then has no branch around any load or store (see the loop).
+template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW, bool FAST>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
@@ -381,7 +385,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 #endif
 		// window rows T-1 .. T-2+AHEAD; row T-1+a has ring slot a (output row a consumes it).  One branch around the whole
 		// group when the PU has that many rows (a branch around every single load keeps them from being issued back to back)
-		if (H >= AHEAD)
+		if (FAST || H >= AHEAD)
 		{
 #pragma unroll
 			for (int a = 0; a < AHEAD; ++a) rs[r].template next_row<NARROW>(rs[r].pending[a], step_ref, W);
@@ -403,75 +407,122 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	// 2985 / 3085 / 3105 / 3155, chroma uni 2460 / 2560 / 2600, chroma bi 2120 / 2195 / 2285 -- the kernel
 	// was latency-bound, and before the loads were left untouched until use (when the realigning shift
 	// made every load wait at issue) it ran at 2890 / 2430 / 2375 / 1905.
-	for (int y0 = 0; y0 < H; y0 += TAPS)
+	const bool store_full = stores && cols >= CPL;
+	const bool store_half = stores && NDW == 2 && cols == 4;         // FAST only: W % 8 == 4, the PU's last storing lane
+	// one output row: window row y + T - 1 leaves the ring into slot (i + T - 1) % T, its ring slot is refilled with window row
+	// y + T - 1 + AHEAD when LOADS, the two passes run and the lane stores its pixels.  i = y % TAPS, static after unrolling.
+	auto output_row = [&](auto loads_tag, auto fast_tag, const int i, const int y)
 	{
+		constexpr bool LOADS = decltype(loads_tag)::value, BRANCH_FREE = decltype(fast_tag)::value;
+		int s[NREF][CPL];
 #pragma unroll
-		for (int i = 0; i < TAPS; ++i)
+		for (int r = 0; r < NREF; ++r)
 		{
-			const int y = y0 + i;
-			if (y < H)   // wave-uniform
+			if (!BI)
 			{
-				int s[NREF][CPL];
+				// consume the ring slot in place, then refill it: the other order needs a copy of the slot per row
+				rs[r].realign(rs[r].pending[i % AHEAD]);
+				rs[r].unpack((i + TAPS - 1) % TAPS, rs[r].pending[i % AHEAD]);           // window row y + T - 1
+				if (LOADS && (BRANCH_FREE || y + TAPS - 1 + AHEAD < rows)) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);     // window row (y + AHEAD) + T - 1
+			}
+			else
+			{
+				uint32_t newest[NDW];
 #pragma unroll
-				for (int r = 0; r < NREF; ++r)
+				for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
+				if (LOADS && (BRANCH_FREE || y + TAPS - 1 + AHEAD < rows)) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);
+				rs[r].realign(newest);
+				rs[r].unpack((i + TAPS - 1) % TAPS, newest);
+			}
+			uint32_t ve[Stream::NX], vo[Stream::NX];
+			rs[r].template vertical<!BI>(i, 0x00200020u, ve, vo);
+			rs[r].template horizontal<!BI>(ve, vo, s[r]);
+		}
+		// shift, saturate to [0, 255] and pack: v_ashr_pk_u8_i32 does two pixels per instruction
+		uint32_t px[NDW];
+#pragma unroll
+		for (int m = 0; m < NDW; ++m)
+		{
+			int t[4];
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+				t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside (vertical()'s seed)
+			constexpr int SHIFT = BI ? 7 : 12;
+			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
+			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
+			px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);   // low halves of (hi, lo)
+		}
+		uint8_t *out = dst + (size_t)out_off;
+		if (BRANCH_FREE)
+		{
+			// two predicated single stores, no loop
+			if (NDW == 1) { if (store_full) reinterpret_cast<U1 *>(out)->v = px[0]; }
+			else
+			{
+				u32x2 v; v.x = px[0]; v.y = px[NDW - 1];
+				if (store_full) __builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
+				if (store_half) reinterpret_cast<U1 *>(out)->v = px[0];
+			}
+		}
+		else if (stores)
+		{
+			if (cols >= CPL)
+			{
+				if (NDW == 1) reinterpret_cast<U1 *>(out)->v = px[0];
+				else
 				{
-					if (!BI)
-					{
-						// consume the ring slot in place, then refill it: the other order needs a copy of the slot per row
-						rs[r].realign(rs[r].pending[i % AHEAD]);
-						rs[r].unpack((i + TAPS - 1) % TAPS, rs[r].pending[i % AHEAD]);           // window row y + T - 1
-						if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);     // window row (y + AHEAD) + T - 1
-					}
-					else
-					{
-						uint32_t newest[NDW];
-#pragma unroll
-						for (int m = 0; m < NDW; ++m) newest[m] = rs[r].pending[i % AHEAD][m];
-						if (y + TAPS - 1 + AHEAD < rows) rs[r].template next_row<NARROW>(rs[r].pending[i % AHEAD], step_ref, W);
-						rs[r].realign(newest);
-						rs[r].unpack((i + TAPS - 1) % TAPS, newest);
-					}
-					uint32_t ve[Stream::NX], vo[Stream::NX];
-					rs[r].template vertical<!BI>(i, 0x00200020u, ve, vo);
-					rs[r].template horizontal<!BI>(ve, vo, s[r]);
+					u32x2 v; v.x = px[0]; v.y = px[NDW - 1];
+					// written once and never read back: streaming store (uni 8-tap -2 % over the 24 PU sizes, 16x16 -7 %;
+					// chroma bi -7 %; nothing slower: profiles/r01_pred_ablation.txt)
+					__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
 				}
-				// shift, saturate to [0, 255] and pack: v_ashr_pk_u8_i32 does two pixels per instruction
-				uint32_t px[NDW];
-#pragma unroll
-				for (int m = 0; m < NDW; ++m)
-				{
-					int t[4];
-#pragma unroll
-					for (int b = 0; b < 4; ++b)
-						t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside (vertical()'s seed)
-					constexpr int SHIFT = BI ? 7 : 12;
-					const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
-					const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
-					px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);   // low halves of (hi, lo)
-				}
-				if (stores)
-				{
-					uint8_t *out = dst + (size_t)out_off;
-					if (cols >= CPL)
-					{
-						if (NDW == 1) reinterpret_cast<U1 *>(out)->v = px[0];
-						else
-						{
-							u32x2 v; v.x = px[0]; v.y = px[NDW - 1];
-							// written once and never read back: streaming store (uni 8-tap -2 % over the 24 PU sizes, 16x16 -7 %;
-							// chroma bi -7 %; nothing slower: profiles/r01_pred_ablation.txt)
-							__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
-						}
-					}
-					else
-					{
-						for (int b = 0; b < cols; ++b) out[b] = (uint8_t)(px[b >> 2] >> (8 * (b & 3)));
-					}
-				}
-				out_off += step_dst;
+			}
+			else
+			{
+				for (int b = 0; b < cols; ++b) out[b] = (uint8_t)(px[b >> 2] >> (8 * (b & 3)));
+			}
+		}
+		out_off += step_dst;
 #ifdef PRED_STAMPS
-				if (y < 24) { if (stamps && lane == 0 && px[0] == 0xdeadbeefu && y == 99) stamps[31] = 4; STAMP(4 + y); }
+		if (y < 24) { if (stamps && lane == 0 && px[0] == 0xdeadbeefu && y == 99) stamps[31] = 4; STAMP(4 + y); }
 #endif
+	};
+
+	// One row of output per trip; the loop is unrolled by T so that window slots are static.  The loads
+	// of the next AHEAD window rows are in flight while a row is computed (a ring of AHEAD * NDW registers
+	// per reference; nothing may touch them before their turn, see next_row()).  Measured on one box, mean
+	// algorithmic GB/s over all PU sizes, AHEAD = 1 / 2 / 4 / 8: luma uni 3075 / 3155 / 3260 / 3365, luma bi
+	// 2985 / 3085 / 3105 / 3155, chroma uni 2460 / 2560 / 2600, chroma bi 2120 / 2195 / 2285 -- the kernel
+	// was latency-bound, and before the loads were left untouched until use (when the realigning shift
+	// made every load wait at issue) it ran at 2890 / 2430 / 2375 / 1905.
+	if (FAST)
+	{
+		// H = n T rows with AHEAD = T: every row of the first n - 1 groups refills its ring slot, no row of the last group does.
+		// No branch stands between the loads, so the compiler knows how many are in flight at every use and waits for exactly the
+		// one it needs (s_waitcnt vmcnt(N)); with a branch around a load it waits for ALL of them at the top of every group of T
+		// rows -- the whole memory latency once per T rows (that is what the general loop below still does).
+		static_assert(AHEAD == TAPS, "the load pattern of the branch-free loop");
+		const int groups = H / TAPS;
+		int y = 0;
+		for (int g = 0; g < groups - 1; ++g)
+		{
+#pragma unroll
+			for (int i = 0; i < TAPS; ++i) output_row(Flag<true>(), Flag<true>(), i, y + i);
+			y += TAPS;
+		}
+#pragma unroll
+		for (int i = 0; i < TAPS; ++i) output_row(Flag<false>(), Flag<true>(), i, y + i);
+	}
+	else
+	{
+		for (int y0 = 0; y0 < H; y0 += TAPS)
+		{
+#pragma unroll
+			for (int i = 0; i < TAPS; ++i)
+			{
+				const int y = y0 + i;
+				if (y < H)   // wave-uniform
+					output_row(Flag<true>(), Flag<false>(), i, y);
 			}
 		}
 	}
@@ -498,11 +549,15 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	}
 	const uint32_t grid = ceil_div(waves, (size_t)(kThreads / kWave));
 	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
+	static const bool no_fast = getenv("HEVCASM_PRED_NOFAST") != nullptr;   // A/B switch for the measurements in profiles/
 	if (NDW == 1 && W < 4)   // a zero-xFrac window is narrower than the 4-byte lane load: those lanes load byte by byte
-		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1>), dim3(grid), dim3(kThreads), 0, st,
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1, false>), dim3(grid), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+	else if (W % 4 == 0 && (H >> log2_segments) % TAPS == 0 && !no_fast)
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, true>), dim3(grid), dim3(kThreads), 0, st,
 				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
 	else
-		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false>), dim3(grid), dim3(kThreads), 0, st,
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, false>), dim3(grid), dim3(kThreads), 0, st,
 				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
 	return launch_status("pred_stream_kernel");
 }
