@@ -237,6 +237,9 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
+        if w == "pred16":
+            bench_pred(only=((16, 16),))
+            continue
         if w == "predq":                                  # a quick subset of PU sizes for same-box A/B runs (tools/ab.py)
             bench_pred(only=((8, 8), (16, 16), (32, 32), (64, 64), (16, 64), (64, 16), (8, 32)))
             continue
