@@ -32,7 +32,12 @@ __global__ __launch_bounds__(256) void probe(const uint8_t *buf, uint32_t *out)
 	{
 		uint32_t v[UNROLL];
 #pragma unroll
-		for (int u = 0; u < UNROLL; ++u) v[u] = load<BYTES>(p + FOOT * u);   // FOOT = 0: the same lines again (L1 hits); 192: 8 lines per row (L2 hits for tall shapes)
+		for (int u = 0; u < UNROLL; ++u)
+		{
+			const uint8_t *q = p + FOOT * u;   // FOOT = 0: the same lines again (L1 hits); 192: 8 lines per row in play (22 KB for 22 rows: L1 / L2 mix)
+			asm volatile("" : "+v"(q));        // (or the compiler folds the identical loads into one)
+			v[u] = load<BYTES>(q);
+		}
 #pragma unroll
 		for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
 		asm volatile("" : "+v"(acc));
@@ -41,25 +46,26 @@ __global__ __launch_bounds__(256) void probe(const uint8_t *buf, uint32_t *out)
 }
 
 // stores: ACTIVE of every LPR lanes write BYTES (prediction's output rows: the margin lanes do not store); every wave its own rows
-template <int BYTES, int LPR, int ACTIVE>
+template <int BYTES, int LPR, int ACTIVE, bool SIDE>
 __global__ __launch_bounds__(256) void store_probe(uint8_t *buf)
 {
 	const size_t wave = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-	const int lane = threadIdx.x & 63, row = lane / LPR, c = lane % LPR;
-	uint8_t *p = buf + (wave % 2048) * (1 << 18) + (size_t)row * 1920 + c * BYTES;
+	const int lane = threadIdx.x & 63, pu = lane / LPR, c = lane % LPR;
+	// SIDE: the PUs of a wave lie side by side on one row (prediction's output: ACTIVE * BYTES contiguous bytes per PU); else one row per PU
+	uint8_t *p = buf + (wave % 2048) * (1 << 18) + (SIDE ? (size_t)pu * ACTIVE * BYTES : (size_t)pu * 1920) + c * BYTES;
 	for (int t = 0; t < TRIPS; ++t)
 	{
 #pragma unroll
 		for (int u = 0; u < UNROLL; ++u)
 			if (c < ACTIVE)
 			{
-				if (BYTES == 8) { u32x2 v; v.x = t; v.y = u; __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p + (size_t)(t * UNROLL + u) * 64)); }
-				else *reinterpret_cast<uint32_t *>(p + (size_t)(t * UNROLL + u) * 64) = t;
+				if (BYTES == 8) { u32x2 v; v.x = t; v.y = u; __builtin_nontemporal_store(v, reinterpret_cast<u32x2 *>(p + (size_t)((t * UNROLL + u) % 128) * 1920)); }
+				else *reinterpret_cast<uint32_t *>(p + (size_t)((t * UNROLL + u) % 128) * 1920) = t;
 			}
 	}
 }
 
-template <int BYTES, int LPR, int ACTIVE> void run_store(uint8_t *buf, const char *what)
+template <int BYTES, int LPR, int ACTIVE, bool SIDE> void run_store(uint8_t *buf, const char *what)
 {
 	const int wgs = 256 * 8;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -67,13 +73,13 @@ template <int BYTES, int LPR, int ACTIVE> void run_store(uint8_t *buf, const cha
 	for (int rep = 0; rep < 4; ++rep)
 	{
 		hipEventRecord(e0);
-		hipLaunchKernelGGL((store_probe<BYTES, LPR, ACTIVE>), dim3(wgs), dim3(256), 0, 0, buf);
+		hipLaunchKernelGGL((store_probe<BYTES, LPR, ACTIVE, SIDE>), dim3(wgs), dim3(256), 0, 0, buf);
 		hipEventRecord(e1); hipEventSynchronize(e1);
 		float ms; hipEventElapsedTime(&ms, e0, e1);
 		if (rep && ms < best) best = ms;
 	}
 	const double instrs_per_cu = (double)wgs * 4 * TRIPS * UNROLL / 256.0;
-	printf("STORE %2d bytes/lane, %d of %d lanes per row : %7.2f ns per wave-instruction per CU  (%s)\n", BYTES, ACTIVE, LPR, best * 1e6 / instrs_per_cu, what);
+	printf("STORE %2d bytes/lane, %d of %d lanes per PU, %s : %7.2f ns per wave-instruction per CU  (%s)\n", BYTES, ACTIVE, LPR, SIDE ? "PUs side by side on one row" : "one row per PU", best * 1e6 / instrs_per_cu, what);
 }
 
 template <int BYTES, int LPR, int MIS, int PITCH = BYTES, int FOOT = 0> void run(const uint8_t *buf, uint32_t *out, const char *what)
@@ -122,12 +128,11 @@ int main()
 	run<8, 3, 0, 8, 192>(buf, out, "the same, dword-aligned");
 	run<16, 2, 0, 16, 192>(buf, out, "32-byte rows as 2 aligned 16-byte lanes, 8 lines per row in play");
 	run<16, 4, 0, 16, 192>(buf, out, "64-byte rows as 4 aligned 16-byte lanes, 8 lines per row in play");
-	uint8_t *big; hipMalloc(&big, (size_t)2048 << 18);
-	run_store<8, 3, 2>(big, "prediction 16-wide output rows");
-	run_store<8, 3, 3>(big, "the same, every lane storing");
-	run_store<8, 9, 8>(big, "prediction 64-wide output rows");
-	run_store<8, 2, 2>(big, "16-byte rows, all lanes");
-	run_store<4, 3, 1>(big, "prediction 4-wide output rows");
-	run_store<8, 64, 64>(big, "one 512-byte row");
+	uint8_t *big; hipMalloc(&big, ((size_t)2048 << 18) + (1 << 20));
+	run_store<8, 3, 2, true>(big, "prediction 16-wide output rows");
+	run_store<8, 3, 2, false>(big, "the same bytes, every PU on a row of its own");
+	run_store<8, 9, 8, true>(big, "prediction 64-wide output rows");
+	run_store<4, 3, 1, true>(big, "prediction 4-wide output rows");
+	run_store<8, 64, 64, true>(big, "one 512-byte row");
 	return 0;
 }
