@@ -1,6 +1,8 @@
 """Seeded random sweep of the batch API against the oracle: sizes the fixed case lists do not name (every multiple
 of 4 for the block costs, odd prediction sizes, odd batch lengths), random frame geometry, random parameters.
 Deterministic (fixed seed) so that a failure reproduces; about 250 small cases."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,6 +11,10 @@ from hevcasm_amd import workload as wl
 
 pytestmark = pytest.mark.gpu
 
+# tools/soak.py re-runs these with other seeds and longer batches (several waves, row segments) in one process
+SEED = int(os.environ.get("HEVCASM_FUZZ_SEED", "0"))
+NMUL = int(os.environ.get("HEVCASM_FUZZ_NMUL", "1"))
+
 
 def _frame(rng, w, h):
     # frames that the block size tiles, of random extent
@@ -16,10 +22,10 @@ def _frame(rng, w, h):
 
 
 def test_block_costs_random_geometry():
-    rng = np.random.default_rng(20261004)
+    rng = np.random.default_rng(20261004 + SEED)
     for i in range(90):
         w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
-        n = int(rng.integers(1, 70))
+        n = int(rng.integers(1, 70)) * NMUL
         ways = int(rng.choice([1, 4]))
         c = wl.sad_case(w, h, n, 5000 + i, ways=ways, max_disp=int(rng.integers(0, 8)), frame=_frame(rng, w, h))
         fam = rng.choice(["sad", "ssd"]) if ways == 1 else "sad4"
@@ -27,12 +33,12 @@ def test_block_costs_random_geometry():
 
 
 def test_prediction_random_sizes_and_fractions():
-    rng = np.random.default_rng(20261005)
+    rng = np.random.default_rng(20261005 + SEED)
     for i in range(70):
         taps = int(rng.choice([8, 4]))
         lim = 64 if taps == 8 else 32
         w, h = int(rng.integers(1, lim + 1)), int(rng.integers(1, lim + 1))   # the C bodies take any size up to the limit
-        n = int(rng.integers(1, 40))
+        n = int(rng.integers(1, 40)) * NMUL
         bi = bool(rng.integers(0, 2))
         c = wl.pred_case(taps, w, h, n, 6000 + i, bi=bi, frame=(w * int(rng.integers(1, 4)), h * int(rng.integers(1, 4))))
         fam = "pred_bi" if bi else "pred_uni"
@@ -40,10 +46,10 @@ def test_prediction_random_sizes_and_fractions():
 
 
 def test_transforms_and_quantisers_random_parameters():
-    rng = np.random.default_rng(20261006)
+    rng = np.random.default_rng(20261006 + SEED)
     for i in range(60):
         tr, lg = wl.TRANSFORMS[int(rng.integers(0, len(wl.TRANSFORMS)))]
-        n = int(rng.integers(1, 50))
+        n = int(rng.integers(1, 50)) * NMUL
         size = 1 << lg
         frame = (size * int(rng.integers(1, 6)), size * int(rng.integers(1, 6)))
         kind = str(rng.choice(["full", "natural"]))
@@ -65,7 +71,7 @@ def test_transforms_and_quantisers_random_parameters():
 
 
 def test_search_operators_and_small_families_random_parameters():
-    rng = np.random.default_rng(20261007)
+    rng = np.random.default_rng(20261007 + SEED)
     for i in range(24):
         w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
         c = cases._subpel_case(w, h, int(rng.integers(1, 6)), 8000 + i, "noise") | dict(metric=int(rng.integers(0, 2)))
