@@ -331,6 +331,9 @@ def main():
                          "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
                          "bytes_per_block": algorithmic_bytes(*dom_key),
+                         # what a plain read stream reaches on this part (profiles/r01_hbm_stream.txt: tools/ubench/hbm_stream.hip, 4.3 GB, streaming loads)
+                         "measured_read_stream_gbs": 7043.6,
+                         "traffic_over_stream": round(traffic / dom_avg_s / 1e9 / 7043.6, 4) if traffic else None,
                          "note": "4-way kernels are priced at their COMPULSORY bytes (source block + the block's share of the reference plane + "
                                  "descriptors and results): the four candidates overlap and HBM sees each plane byte once (traffic = measured HBM "
                                  "bytes per launch, rocprofv3 PMC passes); SURVEY 8(d)'s 5WH+16 counts the candidates as disjoint and would read %.0f GB/s"

@@ -449,3 +449,47 @@ def test_selftest_hip_column():
     assert "ERRORS 0" in r.stdout, r.stdout[-3000:]
     assert "MISMATCH" not in r.stdout
     assert r.stdout.count(" HIP:") == 23 + 23 + 5 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4 + 5 + 5 + 7 + 1
+
+
+def test_bottom_up_planes_prediction_and_inverse_transform():
+    """The reference takes ptrdiff_t strides, so a codec may hand it bottom-up planes (negative strides).  The same PUs / TUs
+    with every plane flipped top to bottom, every stride negated and every offset moved to the flipped position of the
+    block's first row must give the same blocks -- from the kernels (32-bit offset arithmetic that wraps) and from the oracle."""
+    import cases
+    from hevcasm_amd import workload as wl
+
+    def flip_plane(a, stride):
+        rows = a.size // stride
+        assert rows * stride == a.size
+        return np.ascontiguousarray(a.reshape(rows, stride)[::-1]).reshape(-1), rows
+
+    def flip_off(off, stride, rows):
+        o = off.astype(np.int64)
+        return ((rows - 1 - o // stride) * stride + o % stride).astype(np.uint32)
+
+    for taps, w, h, bi in ((8, 16, 16, False), (8, 64, 64, True), (8, 8, 4, False), (4, 4, 8, True), (8, 12, 16, False), (4, 2, 4, False),
+                           (8, 5, 3, False), (8, 32, 32, True), (4, 16, 16, False)):
+        c = wl.pred_case(taps, w, h, 37, 4242 + w, bi=bi, frame=(max(2 * w, 64), max(3 * h, 64)))
+        fam = "pred_bi" if bi else "pred_uni"
+        f = dict(c)
+        for r in range(2 if bi else 1):
+            f["ref%d" % r], rows = flip_plane(c["ref%d" % r], c["stride_ref"])
+            f["ref%d_off" % r] = flip_off(c["ref%d_off" % r], c["stride_ref"], rows)
+        f["dst_off"] = flip_off(c["dst_off"], c["stride_dst"], c["dst_bytes"] // c["stride_dst"])
+        f["stride_ref"], f["stride_dst"] = -c["stride_ref"], -c["stride_dst"]
+        want = cases.run_oracle(fam, c)
+        cases.assert_same("%s %d-tap %dx%d top-down" % (fam, taps, w, h), cases.run_hip(fam, c), want)
+        cases.assert_same("%s %d-tap %dx%d bottom-up" % (fam, taps, w, h), cases.run_hip(fam, f), want)
+    for tr, lg in wl.TRANSFORMS:
+        size = 1 << lg
+        c = wl.inverse_case(tr, lg, 29, 5151 + lg, "natural", frame=(4 * size, 3 * size))
+        f = dict(c)
+        f["pred"], prow = flip_plane(c["pred"], c["stride_pred"])
+        f["pred_off"] = flip_off(c["pred_off"], c["stride_pred"], prow)
+        f["dst_off"] = flip_off(c["dst_off"], c["stride_dst"], c["dst_bytes"] // c["stride_dst"])
+        f["stride_pred"], f["stride_dst"] = -c["stride_pred"], -c["stride_dst"]
+        want = cases.run_oracle("inverse", c)
+        cases.assert_same("inverse %d/%d bottom-up" % (tr, lg), cases.run_hip("inverse", f), want)
+        c["scale"], c["shift"] = 51, 6
+        f["scale"], f["shift"] = 51, 6
+        cases.assert_same("dequant_inverse %d/%d bottom-up" % (tr, lg), cases.run_hip("dequant_inverse", f), cases.run_oracle("dequant_inverse", c))
