@@ -451,7 +451,7 @@ def test_selftest_hip_column():
     assert r.stdout.count(" HIP:") == 23 + 23 + 5 + 3 + 4 + 4 + 4 + 24 * 8 + 22 * 4 + 5 + 5 + 7 + 1
 
 
-def test_bottom_up_planes_prediction_and_inverse_transform():
+def test_bottom_up_planes_every_strided_family():
     """The reference takes ptrdiff_t strides, so a codec may hand it bottom-up planes (negative strides).  The same PUs / TUs
     with every plane flipped top to bottom, every stride negated and every offset moved to the flipped position of the
     block's first row must give the same blocks -- from the kernels (32-bit offset arithmetic that wraps) and from the oracle."""
@@ -493,3 +493,29 @@ def test_bottom_up_planes_prediction_and_inverse_transform():
         c["scale"], c["shift"] = 51, 6
         f["scale"], f["shift"] = 51, 6
         cases.assert_same("dequant_inverse %d/%d bottom-up" % (tr, lg), cases.run_hip("dequant_inverse", f), cases.run_oracle("dequant_inverse", c))
+        c = wl.forward_case(tr, lg, 23, 970 + lg, frame=(4 * size, 3 * size))
+        f = dict(c)
+        f["src"], rows = flip_plane(c["src"], c["src_stride"])
+        f["src_off"], f["src_stride"] = flip_off(c["src_off"], c["src_stride"], rows), -c["src_stride"]
+        cases.assert_same("forward %d/%d bottom-up" % (tr, lg), cases.run_hip("forward", f), cases.run_oracle("forward", c))
+
+    def flip_both(c):
+        f = dict(c)
+        for pl, st, of in (("src", "stride_src", "src_off"), ("ref", "stride_ref", "ref_off")):
+            f[pl], rows = flip_plane(c[pl], c[st])
+            f[of], f[st] = flip_off(c[of], c[st], rows), -c[st]
+        return f
+
+    for (w, h) in ((16, 16), (64, 64), (8, 8), (32, 24), (12, 16), (4, 4)):
+        c = wl.sad_case(w, h, 41, 900 + w, ways=1)
+        cases.assert_same("ssd %dx%d bottom-up" % (w, h), cases.run_hip("ssd", flip_both(c)), cases.run_oracle("ssd", c))
+    for size in (2, 4, 8):
+        c = wl.sad_case(max(size, 4), max(size, 4), 77, 950 + size) | dict(size=size)
+        cases.assert_same("satd %d bottom-up" % size, cases.run_hip("satd", flip_both(c)), cases.run_oracle("satd", c))
+    for (w, h, r) in ((64, 64, 8), (16, 16, 5), (32, 16, 16)):
+        c = cases._me_case(w, h, r, 3, 990 + w)
+        cases.assert_same("me %dx%d bottom-up" % (w, h), cases.run_hip("me", flip_both(c)), cases.run_oracle("me", c))
+    for (w, h) in ((16, 16), (8, 8), (64, 32)):
+        for metric in (0, 1):
+            c = cases._subpel_case(w, h, 4, 995 + w, "noise") | dict(metric=metric)
+            cases.assert_same("subpel %dx%d metric %d bottom-up" % (w, h, metric), cases.run_hip("subpel", flip_both(c)), cases.run_oracle("subpel", c))
