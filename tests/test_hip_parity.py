@@ -519,3 +519,78 @@ def test_bottom_up_planes_every_strided_family():
         for metric in (0, 1):
             c = cases._subpel_case(w, h, 4, 995 + w, "noise") | dict(metric=metric)
             cases.assert_same("subpel %dx%d metric %d bottom-up" % (w, h, metric), cases.run_hip("subpel", flip_both(c)), cases.run_oracle("subpel", c))
+
+
+def test_prediction_and_reconstruction_at_the_top_of_the_4gib_window():
+    """As for SAD: prediction, inverse transform + add and the forward transform address with base + 32-bit offset.  PUs / TUs whose
+    windows end just below 4 GiB - 64 above the plane's base (the last one ON the plane's last byte), reference and destination
+    planes alike, positive and negative strides."""
+    import torch
+    from oracle import pyoracle
+    from hevcasm_amd import batch as B
+    size = (1 << 32) - 64
+    tail = 1 << 20
+    base = size - tail
+    rng = np.random.default_rng(78)
+    ref_t = rng.integers(0, 256, tail, dtype=np.uint8)
+    ref = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    ref[base:] = torch.from_numpy(ref_t).cuda()
+    dst = torch.zeros(size, dtype=torch.uint8, device="cuda")
+    ref_o = np.concatenate([ref_t, np.zeros(1 << 16, dtype=np.uint8)])   # the oracle may walk the whole filter window (zero taps) past the plane's end
+    stride = 2048
+    rows_avail = tail // stride
+
+    def blocks(plane_rows, w, h, n):
+        # n non-overlapping w x h blocks in the tail, margins of 8 around them; the last one's window may be flush with the end
+        r = 8 + (np.arange(n) // 8) * (h + 16)
+        c = 8 + (np.arange(n) % 8) * 96 + rng.integers(0, 8, n)
+        assert r.max() + h + 8 < plane_rows
+        return (r * stride + c).astype(np.int64)
+
+    for taps, w, h in ((8, 16, 16), (8, 64, 64), (4, 8, 8), (8, 8, 4)):
+        n = 24
+        ro_t = blocks(rows_avail, w, h, n)
+        do_t = blocks(rows_avail, w, h, n)
+        frac = ((rng.integers(0, taps // 2 if taps == 8 else 8, n)) | (rng.integers(0, 4 if taps == 8 else 8, n) << 4)).astype(np.uint8)
+        after = taps // 2
+        # the last PU: integer vector, its block ends on the reference plane's last byte; the one before: a 2-D fraction whose window does
+        ro_t[-1], frac[-1] = tail - (h - 1) * stride - w, 0
+        ro_t[-2], frac[-2] = tail - (h - 1 + after) * stride - w - after, 0x11
+        do_t[-1] = tail - (h - 1) * stride - w
+        for sgn in (1, -1):
+            if sgn == 1:
+                ro, do = ro_t, do_t
+                want = pyoracle.pred_uni_batch(taps, tail, stride, ref_o, stride, do.astype(np.uint32), ro.astype(np.uint32), frac, w, h)
+                want_blocks = np.stack([want.reshape(-1, stride)[d // stride:d // stride + h, d % stride:d % stride + w] for d in do])
+            else:
+                # bottom-up: the same blocks, offsets name their first row = the highest address
+                ro, do = ro_t + (h - 1) * stride, do_t + (h - 1) * stride
+                ro[-2:] = ro_t[-2:]
+                ro, frac_n = ro[:-2], frac[:-2]
+                do = do[:-2]
+                want = pyoracle.pred_uni_batch(taps, tail, -stride, ref_o, -stride, do.astype(np.uint32), ro.astype(np.uint32), frac_n, w, h)
+                want_blocks = np.stack([want.reshape(-1, stride)[d // stride - h + 1:d // stride + 1, d % stride:d % stride + w][::-1] for d in do])
+            f = frac if sgn == 1 else frac[:-2]
+            dst.zero_()
+            B.pred_uni(dst, sgn * stride, ref, sgn * stride, B.off32((do + base).astype(np.uint32)), B.off32((ro + base).astype(np.uint32)), B.u8(f), taps, w, h)
+            got = dst[base:].cpu().numpy().reshape(-1, stride)
+            if sgn == 1:
+                got_blocks = np.stack([got[d // stride:d // stride + h, d % stride:d % stride + w] for d in do])
+            else:
+                got_blocks = np.stack([got[d // stride - h + 1:d // stride + 1, d % stride:d % stride + w][::-1] for d in do])
+            assert np.array_equal(got_blocks, want_blocks), (taps, w, h, sgn)
+    # inverse transform + add, and the forward transform reading a residual plane, at the top of the window
+    for lg in (2, 3, 4, 5):
+        nblk, s = 16, 1 << lg
+        po_t, do_t = blocks(rows_avail, s, s, nblk), blocks(rows_avail, s, s, nblk)
+        po_t[-1] = do_t[-1] = tail - (s - 1) * stride - s
+        coeffs = rng.integers(-300, 300, nblk * s * s).astype(np.int16)
+        want = pyoracle.inverse_transform_add_batch(0, lg, tail, stride, ref_o, stride, do_t.astype(np.uint32), po_t.astype(np.uint32), coeffs)
+        dst.zero_()
+        B.inverse_transform_add(dst, stride, ref, stride, B.off32((do_t + base).astype(np.uint32)), B.off32((po_t + base).astype(np.uint32)), B.i16(coeffs), 0, lg)
+        got = dst[base:].cpu().numpy().reshape(-1, stride)
+        w2 = want.reshape(-1, stride)
+        for d in do_t:
+            assert np.array_equal(got[d // stride:d // stride + s, d % stride:d % stride + s], w2[d // stride:d // stride + s, d % stride:d % stride + s]), (lg, d)
+    del ref, dst
+    torch.cuda.empty_cache()
