@@ -43,6 +43,24 @@ template <int W, int C, int R> struct Tiling
 	static_assert(LPB <= kWave, "a block must fit in one wave");
 };
 
+// Lane deal of a wave's BPW blocks.  Block-major: lane = (block, row, chunk) -- a block's lanes are neighbours.  ROW-major: lane = (row,
+// block, chunk) -- the same row of the wave's blocks lies in neighbouring lanes, so that a quad of lanes (what the address unit takes per
+// cycle) reads ONE frame row of two or four raster-neighbour blocks instead of two or four rows of one block: fewer vector-L1 accesses
+// and address translations for the source rows (the reference rows are displaced block by block either way).  Same-box A/B, row-major
+// against block-major (profiles/r02_sad_rowmajor_ab.txt): one reference 8x8 -13 %, 8x16 -6 %, 8x32 -8 %, 16x8 -3 %, 16x16 -1 %, 16x32 / 16x64
+// -1.5 %; four references 32x8 ... 32x64 -2 ... -4 %; but one reference 32-wide +1 ... +2 % and four references 16-wide +-0: those stay block-major.
+template <int W, int C, int R, int WAYS> struct Deal
+{
+	typedef Tiling<W, C, R> T;
+	static constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
+	static constexpr bool ROWMAJOR = BPW > 1 && LPB * BPW == kWave && (R & (R - 1)) == 0 && (LPR & (LPR - 1)) == 0 &&
+		((WAYS == 1 && (W == 8 || W == 16)) || (WAYS == 4 && W == 32));
+	static __device__ __forceinline__ uint32_t sub_block(uint32_t lane) { return ROWMAJOR ? (lane / LPR) % BPW : lane / LPB; }
+	static __device__ __forceinline__ uint32_t row(uint32_t lane) { return ROWMAJOR ? lane / (LPR * BPW) : (lane % LPB) / LPR; }
+	static __device__ __forceinline__ uint32_t chunk(uint32_t lane) { return lane % LPR; }   // LPR divides LPB
+	static __device__ __forceinline__ bool leader(uint32_t lane) { return ROWMAJOR ? lane < (uint32_t)(LPR * BPW) && lane % LPR == 0 : lane % LPB == 0; }
+};
+
 // Chunk bytes and rows in flight for a block width.  Among R = 8, 4, 2, 1 that fit a wave, take the
 // one with the best (lane utilisation x row-locality weight); narrow blocks stop at R = 4.
 constexpr int tiling_score(int lpr, int r)
@@ -213,10 +231,20 @@ template <int C, int LPR> struct OverlapRefChunk
 	}
 };
 
+// the same for the row-major lane deal: the block's lanes are LPR neighbours in each of R groups LPR * BPW lanes apart; valid in every lane
+template <int LPR, int R, int BPW> __device__ __forceinline__ uint32_t reduce_block_rowmajor(uint32_t v)
+{
+#pragma unroll
+	for (int d = LPR * BPW * R / 2; d >= LPR * BPW; d >>= 1) v += __shfl_xor(v, d, kWave);
+#pragma unroll
+	for (int d = LPR / 2; d >= 1; d >>= 1) v += __shfl_xor(v, d, kWave);
+	return v;
+}
+
 // U = rows per lane per trip (independent loads in flight: U * (1 + WAYS) per lane)
 // LOOP = false: the block is exactly one trip (H == R * U): no reload loop, and only one register set.
 // TIGHT: the reference rows of an 8-wide block are less than 8 bytes apart (see OverlapRefChunk, one lane to a row)
-// One wave's sums: lane `lane` belongs to sub-block lane / LPB of the wave and works on block `blk` (every lane of a
+// One wave's sums: lane `lane` belongs to sub-block Deal::sub_block(lane) of the wave and works on block `blk` (every lane of a
 // sub-block is given the same, valid, block index); rows [row_first, row_first + H) of it; the sums arrive in the sub-block's lane 0.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
 __device__ __forceinline__ void block_cost_sums(
@@ -226,10 +254,10 @@ __device__ __forceinline__ void block_cost_sums(
 	int H /* rows of this part */, uint32_t lane, uint32_t blk, uint32_t row_first /* the part starts at this row of the block */, uint32_t (&total)[WAYS])
 {
 	typedef Tiling<W, C, R> T;
-	constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
+	constexpr int LPR = T::LPR, BPW = T::BPW;
 
-	const uint32_t sub = lane / LPB, j = lane - sub * LPB;
-	const uint32_t row0 = j / LPR, chunk = j - row0 * LPR;
+	typedef Deal<W, C, R, WAYS> D;
+	const uint32_t row0 = D::row(lane), chunk = D::chunk(lane);
 
 	// descriptor loads first: independent, one memory round trip
 	const uint32_t so = src_off[blk];
@@ -401,10 +429,10 @@ __device__ __forceinline__ void block_cost_sums(
 	for (int u = 0; u < U; ++u) drain(u);
 
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) total[k] = reduce_block<LPR, R>(acc[k].value());
+	for (int k = 0; k < WAYS; ++k) total[k] = D::ROWMAJOR ? reduce_block_rowmajor<LPR, R, BPW>(acc[k].value()) : reduce_block<LPR, R>(acc[k].value());
 }
 
-// One wave's work: lane `lane` belongs to sub-block lane / LPB of the wave and handles block `blk` (every lane of a
+// One wave's work: lane `lane` belongs to sub-block Deal::sub_block(lane) of the wave and handles block `blk` (every lane of a
 // sub-block is given the same, valid, block index); only the leaders of `live` sub-blocks store.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
 __device__ __forceinline__ void block_cost_body(
@@ -413,11 +441,9 @@ __device__ __forceinline__ void block_cost_body(
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
 	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live)
 {
-	constexpr int LPB = Tiling<W, C, R>::LPB;
 	uint32_t total[WAYS];
 	block_cost_sums<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, total);
-	const uint32_t j = lane % LPB;
-	if (live && j == 0)
+	if (live && Deal<W, C, R, WAYS>::leader(lane))
 	{
 		if (WAYS == 4)
 		{
@@ -441,11 +467,11 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	int *__restrict__ out, int H, uint32_t n_blocks)
 {
 	typedef Tiling<W, C, R> T;
-	constexpr int LPB = T::LPB, BPW = T::BPW;
+	constexpr int BPW = T::BPW;
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
 	const uint32_t lane = threadIdx.x & 63;
-	const uint32_t sub = lane / LPB;
+	const uint32_t sub = Deal<W, C, R, WAYS>::sub_block(lane);
 	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
 	// block so that every lane executes the same loads and shuffles; only real leaders store.
 	uint32_t blk = wave * BPW + (sub < (uint32_t)BPW ? sub : BPW - 1);
