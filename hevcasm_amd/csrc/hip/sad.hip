@@ -806,6 +806,10 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// (one reference, 64-/48-/32-wide, 16 rows in flight and one block per wave -- the mapping that wins for four far-apart candidates:
 	// +18 ... +27 % slower on all seven sizes tried, round 2: profiles/r02_sad4_window_ab.txt)
 	// four references, 16x64: 8 rows in flight make it a single trip of 8 (-3 %)
+	// one reference, row-major 8- and 16-wide (see Deal), 8 rows: two rows in flight per instruction and twice the blocks per wave
+	// (a 256-byte run per frame row): 8x8 -6.4 %, 16x8 -6.1 %; taller blocks +-2 % (16x64 +32 %), eight rows in flight +14 ... +29 %
+	// (profiles/r02_sad_rowmajor_ab.txt)
+	if constexpr (WAYS == 1 && (W == 8 || W == 16)) { if (a.H == 8) return launch_rows<W, P::C, 2, WAYS, OP, false>(a); }
 	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP, false>(a);
 	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, false>(a);
