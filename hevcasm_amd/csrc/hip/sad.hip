@@ -54,7 +54,7 @@ template <int W, int C, int R, int WAYS> struct Deal
 	typedef Tiling<W, C, R> T;
 	static constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
 	static constexpr bool ROWMAJOR = BPW > 1 && LPB * BPW == kWave && (R & (R - 1)) == 0 && (LPR & (LPR - 1)) == 0 &&
-		((WAYS == 1 && (W == 8 || W == 16)) || (WAYS == 4 && W == 32));
+		((WAYS == 1 && (W == 8 || W == 12 || W == 16)) || (WAYS == 4 && W == 32));
 	static __device__ __forceinline__ uint32_t sub_block(uint32_t lane) { return ROWMAJOR ? (lane / LPR) % BPW : lane / LPB; }
 	static __device__ __forceinline__ uint32_t row(uint32_t lane) { return ROWMAJOR ? lane / (LPR * BPW) : (lane % LPB) / LPR; }
 	static __device__ __forceinline__ uint32_t chunk(uint32_t lane) { return lane % LPR; }   // LPR divides LPB
@@ -83,7 +83,9 @@ template <int W> struct Plan
 	// 48 = 4 lanes x 12 bytes (global_load_dwordx3): a row is exactly one quad of lanes, as at W = 64.
 	// With 3 x 16 bytes the quads of the address unit straddle rows: 1.64x the vector-L1 accesses per
 	// pixel of the 64-wide mapping, and 4-way 48x64 was the slowest kernel of the whole mix.
-	static constexpr int C = W == 48 ? 12 : (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
+	// 12 = ONE lane of 12 bytes per row, as 8-wide blocks are one lane of 8 (round 2: three lanes of 4 bytes cost the vector L1 three times the
+	// accesses per row -- 12x16 one reference -26 %, four references -38 %, 12x8 -26 / -37 %, 12x32 -26 %: profiles/r02_sad_rowmajor_ab.txt)
+	static constexpr int C = (W == 48 || W == 12) ? 12 : (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
 	static constexpr int LPR = W / C;
 	static constexpr int R_PREF = best_rows(LPR, W >= 32 ? 8 : 4);   // used when it divides H
 	static constexpr int R_SAFE = best_rows(LPR, 4);                  // H is always a multiple of 4
@@ -308,7 +310,7 @@ __device__ __forceinline__ void block_cost_sums(
 	// 8-wide blocks (one lane to a row), single trip: the same aligned 12-byte loads, see OverlapRefChunk -- 4-way 8x8
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
-	constexpr bool OVERLAP1 = C == 8 && LPR == 1 && !LOOP && !TIGHT;
+	constexpr bool OVERLAP1 = (C == 8 || C == 12) && LPR == 1 && !LOOP && !TIGHT;
 	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;      // (one reference, 48-wide, aligned: +1 % -- round 2, gpurun_out/ab2_sad1_al48.txt)
 	const bool last = chunk == LPR - 1;
 
@@ -787,9 +789,9 @@ template <int W, int C, int R, int WAYS, int OP, bool TIGHT> static int launch_r
 	// one reference, 8 rows per lane: one trip of 8 (source rows first, then reference rows) instead of two trips of 4 --
 	// 16x32 -8 %, 8x32 -9 %, 24x32 -7 %, 32x64 -4 %, 64x64 -1 %
 	// (four references: 8-byte chunks only -- 16x32 -6 %, 24x32 -6 %; 64x64 and 32x64 the same either way, 48x64 +6 %)
-	if constexpr (WAYS == 1 || C <= 8) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP, TIGHT>(a); }
+	if constexpr (WAYS == 1 || C <= 8 || W == 12) { if (rows_per_lane == 8) return launch_cfg<W, C, R, 8, WAYS, OP, TIGHT>(a); }    // (12x32 four references as one trip: -39 %)
 	if (rows_per_lane == 6) return launch_cfg<W, C, R, 6, WAYS, OP, TIGHT>(a);                                       // 64x48: -2 % (one and four references)
-	if constexpr (WAYS == 1 && C <= 8) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP, TIGHT>(a); }    // 16x64: -10 %
+	if constexpr (WAYS == 1 && (C <= 8 || W == 12)) { if (rows_per_lane == 16) return launch_cfg<W, C, R, 16, WAYS, OP, TIGHT>(a); }    // 16x64: -10 %, 12x64: -18 % -> -32 %
 	if (rows_per_lane % 4 == 0) return launch_cfg<W, C, R, 4, WAYS, OP, TIGHT>(a);
 	if (rows_per_lane % 3 == 0) return launch_cfg<W, C, R, 3, WAYS, OP, TIGHT>(a);   // heights 12, 24, 48
 	if (rows_per_lane % 2 == 0) return launch_cfg<W, C, R, 2, WAYS, OP, TIGHT>(a);
@@ -802,6 +804,14 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	if constexpr (W == 8)
 	{
 		if (a.sr < 8 && a.sr > -8) return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, true>(a);
+	}
+	if constexpr (W == 12)
+	{
+		if (a.sr < 12 && a.sr > -12) return launch_rows<W, 4, 4, WAYS, OP, false>(a);     // overlapping rows: the 4-byte-chunk kernels, which load at the byte address
+		// four references, heights that are not one trip of 1 / 2 / 3 / 4 / 6 / 8 rows per lane: the aligned loads of the one-lane-per-row mapping need a
+		// single trip (they must know which row is the block's highest), and at the byte address it is 3 - 6 % slower than three lanes of 4 bytes
+		const int rpl = a.H / 4;
+		if (WAYS == 4 && !(rpl <= 4 || rpl == 6 || rpl == 8)) return launch_rows<W, 4, 4, WAYS, OP, false>(a);
 	}
 	// (one reference, 64-/48-/32-wide, 16 rows in flight and one block per wave -- the mapping that wins for four far-apart candidates:
 	// +18 ... +27 % slower on all seven sizes tried, round 2: profiles/r02_sad4_window_ab.txt)
