@@ -54,7 +54,7 @@ template <int W, int C, int R, int WAYS> struct Deal
 	typedef Tiling<W, C, R> T;
 	static constexpr int LPR = T::LPR, LPB = T::LPB, BPW = T::BPW;
 	static constexpr bool ROWMAJOR = BPW > 1 && LPB * BPW == kWave && (R & (R - 1)) == 0 && (LPR & (LPR - 1)) == 0 &&
-		((WAYS == 1 && (W == 8 || W == 12 || W == 16)) || (WAYS == 4 && W == 32));
+		((WAYS == 1 && (W == 8 || W == 12 || W == 16 || W == 24)) || (WAYS == 4 && W == 32));
 	static __device__ __forceinline__ uint32_t sub_block(uint32_t lane) { return ROWMAJOR ? (lane / LPR) % BPW : lane / LPB; }
 	static __device__ __forceinline__ uint32_t row(uint32_t lane) { return ROWMAJOR ? lane / (LPR * BPW) : (lane % LPB) / LPR; }
 	static __device__ __forceinline__ uint32_t chunk(uint32_t lane) { return lane % LPR; }   // LPR divides LPB
@@ -85,7 +85,9 @@ template <int W> struct Plan
 	// pixel of the 64-wide mapping, and 4-way 48x64 was the slowest kernel of the whole mix.
 	// 12 = ONE lane of 12 bytes per row, as 8-wide blocks are one lane of 8 (round 2: three lanes of 4 bytes cost the vector L1 three times the
 	// accesses per row -- 12x16 one reference -26 %, four references -38 %, 12x8 -26 / -37 %, 12x32 -26 %: profiles/r02_sad_rowmajor_ab.txt)
-	static constexpr int C = (W == 48 || W == 12) ? 12 : (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
+	// 24 = two lanes of 12 bytes (aligned 16-byte loads that overlap by a dword, no tail load) instead of three of 8: one reference -5 ... -16 %,
+	// four references -2 ... -15 % (round 2; in round 1, before the other changes to these kernels, the two were equal)
+	static constexpr int C = (W == 48 || W == 12 || W == 24) ? 12 : (W >= 32 && W % 16 == 0) ? 16 : (W % 8 == 0 ? 8 : 4);
 	static constexpr int LPR = W / C;
 	static constexpr int R_PREF = best_rows(LPR, W >= 32 ? 8 : 4);   // used when it divides H
 	static constexpr int R_SAFE = best_rows(LPR, 4);                  // H is always a multiple of 4
@@ -306,12 +308,12 @@ __device__ __forceinline__ void block_cost_sums(
 	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
 	// (With the loads still alternating between source and reference rows, the short single-trip blocks lost 4-10 % to the
 	// realignment; since they issue source rows first they gain too: 4-way 16x12 0.140 -> 0.105, 16x8 0.100 -> 0.079.)
-	constexpr bool OVERLAP = (C == 8 || C == 4) && LPR >= 2;
+	constexpr bool OVERLAP = ((C == 8 || C == 4) && LPR >= 2) || (W == 24 && C == 12);
 	// 8-wide blocks (one lane to a row), single trip: the same aligned 12-byte loads, see OverlapRefChunk -- 4-way 8x8
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
 	constexpr bool OVERLAP1 = (C == 8 || C == 12) && LPR == 1 && !LOOP && !TIGHT;
-	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2;      // (one reference, 48-wide, aligned: +1 % -- round 2, gpurun_out/ab2_sad1_al48.txt)
+	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2 && W != 24;      // (one reference, 48-wide, aligned: +1 % -- round 2, gpurun_out/ab2_sad1_al48.txt)
 	const bool last = chunk == LPR - 1;
 
 	// Source rows are read exactly once.  Where the blocks of a wave cover whole 128-byte lines of a frame row between
@@ -821,6 +823,8 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// (profiles/r02_sad_rowmajor_ab.txt)
 	if constexpr (WAYS == 1 && (W == 8 || W == 16)) { if (a.H == 8) return launch_rows<W, P::C, 2, WAYS, OP, false>(a); }
 	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
+	// four references, 24-wide, 32 rows or more: 8 rows in flight (24x32 -4 % -> -12 %, 24x64 -3 % -> -14 % against round 1; shorter blocks and one reference lose with it)
+	if constexpr (WAYS == 4 && W == 24) { if (a.H >= 32 && a.H % 8 == 0) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	if (P::R_PREF != P::R_SAFE && a.H % P::R_PREF == 0) return launch_rows<W, P::C, P::R_PREF, WAYS, OP, false>(a);
 	return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, false>(a);
 }
