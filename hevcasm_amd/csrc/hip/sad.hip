@@ -822,6 +822,9 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// (a 256-byte run per frame row): 8x8 -6.4 %, 16x8 -6.1 %; taller blocks +-2 % (16x64 +32 %), eight rows in flight +14 ... +29 %
 	// (profiles/r02_sad_rowmajor_ab.txt)
 	if constexpr (WAYS == 1 && (W == 8 || W == 16)) { if (a.H == 8) return launch_rows<W, P::C, 2, WAYS, OP, false>(a); }
+	// four references, 32-wide, up to 32 rows: four lanes of 8 bytes (aligned 12-byte loads, no tail load), 4 rows in flight: 32x8 -6 %, 32x16 -9 %, 32x24 -5.5 %,
+	// 32x32 -5 % against two lanes of 16 bytes + tail load (which 32x64 keeps: +9 % with this; 8 rows in flight +1 ... +14 %) -- profiles/r02_sad_rowmajor_ab.txt
+	if constexpr (WAYS == 4 && W == 32) { if (a.H <= 32) return launch_rows<W, 8, 4, WAYS, OP, false>(a); }
 	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	// four references, 24-wide, 32 rows or more: 8 rows in flight (24x32 -4 % -> -12 %, 24x64 -3 % -> -14 % against round 1; shorter blocks and one reference lose with it)
 	if constexpr (WAYS == 4 && W == 24) { if (a.H >= 32 && a.H % 8 == 0) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
