@@ -813,7 +813,7 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 		// four references, heights that are not one trip of 1 / 2 / 3 / 4 / 6 / 8 rows per lane: the aligned loads of the one-lane-per-row mapping need a
 		// single trip (they must know which row is the block's highest), and at the byte address it is 3 - 6 % slower than three lanes of 4 bytes
 		const int rpl = a.H / 4;
-		if (WAYS == 4 && !(rpl <= 4 || rpl == 6 || rpl == 8)) return launch_rows<W, 4, 4, WAYS, OP, false>(a);
+		if (WAYS == 4 && !(rpl <= 4 || rpl == 6 || rpl == 8) && a.H != 48 && a.H != 64) return launch_rows<W, 4, 4, WAYS, OP, false>(a);
 	}
 	// (one reference, 64-/48-/32-wide, 16 rows in flight and one block per wave -- the mapping that wins for four far-apart candidates:
 	// +18 ... +27 % slower on all seven sizes tried, round 2: profiles/r02_sad4_window_ab.txt)
@@ -825,6 +825,9 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// four references, 32-wide, up to 32 rows: four lanes of 8 bytes (aligned 12-byte loads, no tail load), 4 rows in flight: 32x8 -6 %, 32x16 -9 %, 32x24 -5.5 %,
 	// 32x32 -5 % against two lanes of 16 bytes + tail load (which 32x64 keeps: +9 % with this; 8 rows in flight +1 ... +14 %) -- profiles/r02_sad_rowmajor_ab.txt
 	if constexpr (WAYS == 4 && W == 32) { if (a.H <= 32) return launch_rows<W, 8, 4, WAYS, OP, false>(a); }
+	// four references, one lane to a row (8- and 12-wide), 48 or 64 rows: 8 rows in flight make the block ONE trip of 6 or 8 rows per lane, which the aligned loads of
+	// that mapping need (see OVERLAP1): 8x64 -29 % against four trips at the byte address (one reference and shorter blocks lose 4 ... 27 % with 8 rows in flight)
+	if constexpr (WAYS == 4 && (W == 8 || W == 12)) { if (a.H == 48 || a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	if constexpr (WAYS == 4 && W == 16) { if (a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
 	// four references, 24-wide, 32 rows or more: 8 rows in flight (24x32 -4 % -> -12 %, 24x64 -3 % -> -14 % against round 1; shorter blocks and one reference lose with it)
 	if constexpr (WAYS == 4 && W == 24) { if (a.H >= 32 && a.H % 8 == 0) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
