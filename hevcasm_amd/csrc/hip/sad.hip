@@ -308,7 +308,8 @@ __device__ __forceinline__ void block_cost_sums(
 	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
 	// (With the loads still alternating between source and reference rows, the short single-trip blocks lost 4-10 % to the
 	// realignment; since they issue source rows first they gain too: 4-way 16x12 0.140 -> 0.105, 16x8 0.100 -> 0.079.)
-	constexpr bool OVERLAP = ((C == 8 || C == 4) && LPR >= 2) || (W == 24 && C == 12);
+	// (12-byte chunks, 24-wide, and 48-wide with one reference -- 48x64 -3.9 %, 48x32 -4.2 %, round 2 -- load 16 aligned bytes the same way)
+	constexpr bool OVERLAP = ((C == 8 || C == 4) && LPR >= 2) || (W == 24 && C == 12) || (W == 48 && WAYS == 1);
 	// 8-wide blocks (one lane to a row), single trip: the same aligned 12-byte loads, see OverlapRefChunk -- 4-way 8x8
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
