@@ -826,6 +826,8 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// four references, 32-wide, up to 32 rows: four lanes of 8 bytes (aligned 12-byte loads, no tail load), 4 rows in flight: 32x8 -6 %, 32x16 -9 %, 32x24 -5.5 %,
 	// 32x32 -5 % against two lanes of 16 bytes + tail load (which 32x64 keeps: +9 % with this; 8 rows in flight +1 ... +14 %) -- profiles/r02_sad_rowmajor_ab.txt
 	if constexpr (WAYS == 4 && W == 32) { if (a.H <= 32) return launch_rows<W, 8, 4, WAYS, OP, false>(a); }
+	// (one reference, 32-wide, the same mapping: -0.7 ... -2.4 % on all five heights, 8 rows in flight +14 ... +36 %)
+	if constexpr (WAYS == 1 && W == 32) return launch_rows<W, 8, 4, WAYS, OP, false>(a);
 	// four references, one lane to a row (8- and 12-wide), 48 or 64 rows: 8 rows in flight make the block ONE trip of 6 or 8 rows per lane, which the aligned loads of
 	// that mapping need (see OVERLAP1): 8x64 -29 % against four trips at the byte address (one reference and shorter blocks lose 4 ... 27 % with 8 rows in flight)
 	if constexpr (WAYS == 4 && (W == 8 || W == 12)) { if (a.H == 48 || a.H == 64) return launch_rows<W, P::C, 8, WAYS, OP, false>(a); }
