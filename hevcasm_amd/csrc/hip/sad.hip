@@ -820,9 +820,11 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	// +18 ... +27 % slower on all seven sizes tried, round 2: profiles/r02_sad4_window_ab.txt)
 	// four references, 16x64: 8 rows in flight make it a single trip of 8 (-3 %)
 	// one reference, row-major 8- and 16-wide (see Deal), 8 rows: two rows in flight per instruction and twice the blocks per wave
-	// (a 256-byte run per frame row): 8x8 -6.4 %, 16x8 -6.1 %; taller blocks +-2 % (16x64 +32 %), eight rows in flight +14 ... +29 %
-	// (profiles/r02_sad_rowmajor_ab.txt)
-	if constexpr (WAYS == 1 && (W == 8 || W == 16)) { if (a.H == 8) return launch_rows<W, P::C, 2, WAYS, OP, false>(a); }
+	// (a 256-byte run per frame row): 8x8 -6.4 %, 16x8 -6.1 %, 12x8 -20 %, 24x8 -4 %, 32x8 -7 %; taller blocks +-2 % (16x64 +32 %), eight rows in flight
+	// +14 ... +29 %; with four references it loses 2 ... 9 % (profiles/r02_sad_rowmajor_ab.txt)
+	if constexpr (WAYS == 1 && (W == 8 || W == 12 || W == 16 || W == 24 || W == 32)) { if (a.H == 8) return launch_rows<W, P::C == 16 ? 8 : P::C, 2, WAYS, OP, false>(a); }
+	// 4 rows: two in flight as well (one reference 16x4 -18 %, 8x4 -12 %, 4x4 -10 %; four references -3 ... -7 %; 12x4 +8 % with it, so not there)
+	if constexpr (W == 4 || W == 8 || W == 16) { if (a.H == 4) return launch_rows<W, P::C, 2, WAYS, OP, false>(a); }
 	// four references, 32-wide, up to 32 rows: four lanes of 8 bytes (aligned 12-byte loads, no tail load), 4 rows in flight: 32x8 -6 %, 32x16 -9 %, 32x24 -5.5 %,
 	// 32x32 -5 % against two lanes of 16 bytes + tail load (which 32x64 keeps: +9 % with this; 8 rows in flight +1 ... +14 %) -- profiles/r02_sad_rowmajor_ab.txt
 	if constexpr (WAYS == 4 && W == 32) { if (a.H <= 32) return launch_rows<W, 8, 4, WAYS, OP, false>(a); }
