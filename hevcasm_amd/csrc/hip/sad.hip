@@ -4,13 +4,16 @@
 // hevcasm_sad_multiref 4-way (sad.h:95, sad.c:101-121) and hevcasm_ssd (ssd.h:53, ssd.c:43-55).
 //
 // Layout: frames stay as the codec has them (row-strided u8 planes in HBM); a block is a base
-// pointer + u32 byte offset.  Mapping: each block row of W bytes is cut into chunks of C = 16 / 8 /
+// pointer + u32 byte offset.  Mapping: each block row of W bytes is cut into chunks of C = 16 / 12 / 8 /
 // 4 bytes, one lane per chunk, and R rows of the block are in flight per instruction, so
-// (W / C) * R adjacent lanes own one block (see Tiling below for the measurements behind the
-// choice) and a wave covers 64 / LPB blocks.  Consecutive blocks are normally horizontal
+// (W / C) * R lanes own one block (see Tiling, Plan and launch_w below for the measurements behind the
+// choices) and a wave covers 64 / LPB blocks.  Consecutive blocks are normally horizontal
 // neighbours in the frame, so the lanes of a wave read a few long runs of a few frame rows: no
-// LDS staging is needed.  Reference blocks sit at arbitrary byte alignment (motion vectors);
-// the loads carry no alignment promise (byte misalignment measured free on gfx950).
+// LDS staging is needed (the four-reference kernel of 64-/48-wide blocks further down is the exception).
+// Reference blocks sit at arbitrary byte alignment (motion vectors).  What round 2 measured about the vector L1 decides the
+// rest: it works per (quad of lanes, row) access and per dword when a load is not dword-aligned, so narrow blocks get FEW lanes to a
+// row, MANY rows to an instruction, loads of the aligned words that contain the lane's bytes (one dword wider than the chunk,
+// realigned with v_alignbyte_b32) and ONE trip; and the lanes of the narrowest are dealt row-major over the wave's blocks (Deal).
 // Arithmetic: v_sad_u8 accumulates 4 byte differences per instruction; SSD uses
 // sum(a-b)^2 = sum a^2 + sum b^2 - 2 sum ab with three v_dot4_u32_u8 (exact: every partial sum
 // is below 2^30 for blocks up to 64x64).  The LPB partial sums are combined with wave shuffles.
