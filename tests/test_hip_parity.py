@@ -243,6 +243,25 @@ def test_sad_narrow_blocks_bottom_up_and_tight_planes():
             ref2 = wl.fill_u8(4 * h * n + 8, 79)
             c = dict(src=src, stride_src=8, ref=ref2, stride_ref=4, src_off=so, ref_off=np.repeat((np.arange(n) * 4 * h).astype(np.uint32), ways), w=8, h=h, n=n, ways=ways)
             cases.assert_same("rows 4 bytes apart 8x%d x%d" % (h, ways), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+    # 12-wide blocks are one lane of 12 bytes per row with aligned 16-byte loads (round 2): planes that hold exactly the blocks, rows 12 bytes
+    # apart (every over-read must stay inside the block), 16 apart, and 8 apart (overlapping rows: the 4-byte-chunk kernels at the byte
+    # address); 24-wide (two lanes of 12) and 48-wide (four lanes of 12, one reference) with rows exactly W apart; both stride signs
+    for (w, tight) in ((12, 12), (12, 16), (12, 8), (24, 24), (48, 48), (32, 32), (16, 16)):
+        for h in (4, 8, 16, 32, 48, 64):
+            for ways in (1, 4):
+                fam = "sad4" if ways == 4 else "sad"
+                n = 7
+                src = wl.fill_u8(w * h * n, 81)
+                ref = wl.fill_u8(tight * (h - 1) * n + tight * n + w + 64, 82)[:tight * h * n + (w - tight if w > tight else 0)]
+                so = (np.arange(n) * w * h).astype(np.uint32)
+                ro = np.repeat((np.arange(n) * tight * h).astype(np.uint32), ways)
+                c = dict(src=src, stride_src=w, ref=ref, stride_ref=tight, src_off=so, ref_off=ro, w=w, h=h, n=n, ways=ways)
+                cases.assert_same("tight %dx%d rows %d apart x%d" % (w, h, tight, ways), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+                c2 = dict(c)
+                c2["src_off"] = (so.astype(np.int64) + (h - 1) * w).astype(np.uint32)
+                c2["ref_off"] = (ro.astype(np.int64) + (h - 1) * tight).astype(np.uint32)
+                c2["stride_src"], c2["stride_ref"] = -w, -tight
+                cases.assert_same("tight bottom-up %dx%d rows %d apart x%d" % (w, h, tight, ways), cases.run_hip(fam, c2), cases.run_oracle(fam, c2))
 
 
 def test_sad_offsets_at_the_top_of_the_4gib_window():
