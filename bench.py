@@ -18,6 +18,19 @@ roofline   = the kernel with the largest share of the timed region: algorithmic 
 cpu_baseline = the REFERENCE's own C path (oracle/_ref/refdrv, gcc -O3) timed on this host's
              cores on a bounded sample of the same mix (rank 0, N = 1 only).  Baseline, not target.
 Multi-GPU: weak scaling, each rank owns its own 1 Mi-block batch per size; no data-path collective.
+
+roofline.per_family = the other kernels BASELINE.json's metric names, measured in the same run after the
+             timed region (N = 1): SAD 16x16, uni / bi inter prediction (config #3: luma 16x16 8-tap, chroma 8x8
+             4-tap; 64 frames per launch, ONE frame per launch, and one frame's luma + Cb + Cr replayed as a HIP
+             graph), inverse / fused-dequantised / forward transforms 8x8..32x32 (config #4), and the full-search
+             frame of config #5 (VALU-bound: SAD evaluations/s against the v_qsad_pk_u16_u8 issue rate).
+
+    python bench.py --workload me5 [--gpus N ...]
+BASELINE.json configs[4] instead: full-search motion estimation, +-64, over 3840x2160 frames of 64x64 CTUs (bottom row
+64x48), every frame's CTU ROWS sharded across the ranks, each rank holding its rows + the +-64-row halo of the
+reference frame (hevcasm_amd/me_frame.py, shard.py).  A step = one frame; strong scaling; no data-path collective
+(after the timed region the 12-byte answers are collected and rank 0 checks a sample of them against the
+reference's hevcasm_sad composed per candidate).
 """
 import argparse
 import json
@@ -106,6 +119,27 @@ class SizeBatch:
             B.sad_multiref(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off4"], self.w, self.h, out=c["out4"])
 
 
+def host_cores(max_procs):
+    """(processes to run, description).  A GPU box gives one GPU's job a share of the host (16 cores per GPU on the
+    pool this was written on) whatever os.cpu_count() says, so the baselines run on min(cores usable, max_procs)."""
+    total = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = total
+    try:    # cgroup v2 CPU quota, if any
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = max(1, min(usable, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    n = max(1, min(max_procs, usable))
+    note = "%d processes: os.cpu_count() = %d, usable by this process = %d" % (n, total, usable)
+    if n < usable:
+        note += ", capped at %d (one GPU's share of the host on this pool; --cpu-procs to change)" % max_procs
+    return n, dict(host_cpus=total, usable_cpus=usable, note=note)
+
+
 def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     """The reference's C path on the host: one refdrv process per core, each timing every
     (size, ways) of the mix on `sample_blocks` blocks for an equal share of `budget_s`."""
@@ -114,7 +148,7 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     from oracle import pyref
     if not pyref.available():
         return None
-    procs_n = max(1, min(max_procs, os.cpu_count() or 1))
+    procs_n, cores_info = host_cores(max_procs)
     combos = [(w, h, ways) for (w, h) in sizes for ways in (1, 4)]
     ms_each = max(20, int(1000.0 * budget_s / len(combos)))
     cases = {(w, h): wl.sad_case(w, h, sample_blocks, 9000 + w * 64 + h, ways=4, frame=(wl.FRAME_W, wl.FRAME_H)) for (w, h) in sizes}
@@ -136,8 +170,9 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     sad16 = sum(r[(16, 16, 1)] for r in per_proc)
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference", value_per_core=round(total / procs_n / 1e6, 3),
                 sample="reference C path (gcc -O3, HEVCASM_C_REF tables) via oracle/_ref/refdrv: %d processes x %d (size, ways) combos x %d blocks "
+                       "(cache-resident: this path is compute-bound at ~1 Mblock/s per core, residency does not move it) "
                        "repeated for %d ms each, same size mix as the GPU step" % (procs_n, len(combos), sample_blocks, ms_each),
-                sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3))
+                sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3), **cores_info)
 
 
 def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
@@ -151,7 +186,7 @@ def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     exe = os.path.join(os.path.dirname(capi.LIB_PATH), "hevcasm_host_bench")
     if not os.path.exists(exe):
         return None
-    procs_n = max(1, min(max_procs, os.cpu_count() or 1))
+    procs_n, cores_info = host_cores(max_procs)
     mask = capi.lib().hevcasm_instruction_set_support() & ~capi.HIP
     ms_each = max(20, int(1000.0 * budget_s / (2 * len(sizes))))
     want = set((w, h) for (w, h) in sizes)
@@ -175,8 +210,9 @@ def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     names = [n for n, bit in (("SSE2", capi.SSE2), ("AVX2", capi.AVX2)) if mask & bit]
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="port", value_per_core=round(total / procs_n / 1e6, 3),
                 sample="this library's host table entries (mask %#x: %s intrinsics kernels where the reference has x86 asm, C elsewhere), per-block calls, "
-                       "%d processes x %d (size, ways) combos x %d blocks repeated for %d ms each, same size mix" % (mask, "/".join(names) or "no SIMD", procs_n, len(combos), sample_blocks, ms_each),
-                sad16x16_single_ref_mblocks_per_s=round(sum(r.get((16, 16, 1), 0.0) for r in per_proc) / 1e6, 3))
+                       "%d processes x %d (size, ways) combos x %d blocks (memory-resident, like the GPU's inputs) repeated for %d ms each, same size mix"
+                       % (mask, "/".join(names) or "no SIMD", procs_n, len(combos), sample_blocks, ms_each),
+                sad16x16_single_ref_mblocks_per_s=round(sum(r.get((16, 16, 1), 0.0) for r in per_proc) / 1e6, 3), **cores_info)
 
 
 def main():
@@ -187,8 +223,13 @@ def main():
     ap.add_argument("--blocks", type=int, default=1 << 20, help="blocks per size per GPU (config #2: 1 Mi)")
     ap.add_argument("--sizes", default="all", help="'all' (20 sizes >= 8x8) or a comma list like 16x16,64x64")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--no-families", action="store_true", help="skip the inter-prediction / IDCT headline measurements after the timed region")
+    ap.add_argument("--cpu-procs", type=int, default=16, help="host processes of the CPU baseline legs (one GPU's share of the host)")
+    ap.add_argument("--no-families", action="store_true", help="skip the per-family measurements (inter prediction, transforms, full search) after the timed region")
+    ap.add_argument("--workload", default="sad", choices=("sad", "me5"), help="sad = BASELINE.json configs[1] (the metric's configuration); me5 = configs[4], full search sharded by CTU rows")
     args = ap.parse_args()
+    stale = sorted(k for k in os.environ if k.startswith("HEVCASM_") and k not in ("HEVCASM_BENCH_ONE_DEVICE", "HEVCASM_DIST_BACKEND"))
+    if stale:
+        print("bench.py: WARNING: %s set in the environment -- the measurement is not of the default library configuration (recorded in config.env_switches)" % ", ".join(stale), file=sys.stderr)
 
     import torch
     import torch.distributed as dist
@@ -216,6 +257,9 @@ def main():
     L = capi.lib()
     if not L.hevcasm_hip_available():
         sys.exit("no usable gfx950 device: the HIP path has no fallback")
+
+    if args.workload == "me5":
+        return bench_me5(args, rank, world, device)
 
     sizes = wl.SAD_BENCH_SIZES if args.sizes == "all" else [tuple(int(v) for v in s.split("x")) for s in args.sizes.split(",")]
     t0 = time.time()
@@ -291,33 +335,37 @@ def main():
     n_launches = len(launches)
     value = world * blocks_per_step * args.steps / elapsed / 1e6
 
-    # The metric also names inter prediction and the IDCT: their headline kernels are measured here, outside the timed region, on the
-    # workloads of BASELINE.json configs #3 and #4 (tools/bench_families.py: HIP events, cold inputs), so that the one JSON line carries
-    # all three.  `value` stays the whole-job rate of config #2.
-    others = None
+    # The metric also names inter prediction and the IDCT, and BASELINE.json's last config is the full search: their kernels are
+    # measured here, outside the timed region, on the workloads of configs #3 / #4 / #5 (tools/bench_families.py: HIP events, cold
+    # inputs), so that the one JSON line carries all of it.  `value` stays the whole-job rate of config #2.
+    per_family, fam_error = None, None
     if rank == 0 and world == 1 and not args.no_families:
-        sys.path.insert(0, os.path.join(ROOT, "tools"))
-        import bench_families as fam
         del batches, launches
         torch.cuda.empty_cache()
-        fam.SINK = []
-        fam.bench_pred(frames=64, only=((16, 16),))            # luma 8-tap + chroma 4-tap (8x8), uni and bi, all fractional phases
-        fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32
-        others = {"%s %s" % (r["kernel"], r["size"]): {k: r[k] for k in ("ms", "blocks", "mblocks_per_s", "bytes_per_block", "algorithmic_gb_per_s", "frac_of_hbm_peak")}
-                  for r in fam.SINK}
-        fam.SINK = None
+        try:
+            per_family = measure_families()
+        except Exception as e:   # noqa: BLE001 -- a failure here must not cost the line its timed result
+            fam_error = repr(e)[:300]
 
     if rank == 0:
-        cpu, simd = None, None
+        cpu = None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(sizes, 2048, args.cpu_seconds)
+            cpu = cpu_baseline(sizes, 2048, args.cpu_seconds, args.cpu_procs)
             if cpu:
                 cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
-            # 16 Ki blocks per size and process: 16 processes x up to 260 MB of frames, beyond the host's last-level cache, so that this
-            # column is a memory-resident figure like the GPU's (with 2 Ki blocks everything sits in L3 and the figure doubles)
-            simd = host_simd_baseline(sizes, 16384, min(args.cpu_seconds, 8.0))
-            if simd:
-                simd["gpu_multiple"] = round(value / simd["value"], 1)
+                # 16 Ki blocks per size and process: 16 processes x up to 260 MB of frames, beyond the host's last-level cache, so that this
+                # column is a memory-resident figure like the GPU's (with 2 Ki blocks everything sits in L3 and the figure doubles)
+                try:
+                    simd = host_simd_baseline(sizes, 16384, min(args.cpu_seconds, 8.0), args.cpu_procs)
+                    if simd:
+                        simd["gpu_multiple"] = round(value / simd["value"], 1)
+                except Exception as e:   # noqa: BLE001 -- a host-side failure must not discard the GPU result
+                    simd = dict(value=None, error=repr(e)[:300])
+                cpu["simd"] = simd
+        head = head[0] if head else None
+        if per_family is not None and head:
+            per_family.insert(0, dict(family="sad", kernel="sad 16x16 single-ref", config="#2, inside the timed region", ms=head["ms_per_pass"], mblocks_per_s=head["mblocks_per_s"],
+                                      gbs=head["algorithmic_gb_per_s"], frac=head["frac_of_hbm_peak"], bytes_per_block=head["bytes_per_block"]))
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -326,7 +374,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: batched SAD + 4-way multiref SAD, %d block sizes %s, %d blocks per size per GPU, "
                                    "ref displaced +-7 px, device-resident frames" % (len(sizes), "8x8..64x64" if args.sizes == "all" else args.sizes, args.blocks),
                        "blocks_per_step_per_gpu": blocks_per_step, "launches_per_step": n_launches, "parallelism": "batch split x%d, no collectives" % world,
-                       "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1)},
+                       "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1), **library_record()},
             "roofline": {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
@@ -337,17 +385,229 @@ def main():
                          "note": "4-way kernels are priced at their COMPULSORY bytes (source block + the block's share of the reference plane + "
                                  "descriptors and results): the four candidates overlap and HBM sees each plane byte once (traffic = measured HBM "
                                  "bytes per launch, rocprofv3 PMC passes); SURVEY 8(d)'s 5WH+16 counts the candidates as disjoint and would read %.0f GB/s"
-                                 % ((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9) if dom_key[2] == 4 else None},
+                                 % ((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9) if dom_key[2] == 4 else None,
+                         # every other kernel the metric and BASELINE.json's configs name, same run, outside the timed region
+                         "per_family": per_family, "per_family_error": fam_error},
             "cpu_baseline": cpu,
-            "cpu_baseline_simd": simd,
-            "headline": {"sad_16x16_single_ref": head[0] if head else None, "inter_pred_and_idct": others,
-                         "note": "value = config #2 (the SAD mix) only; the other kernels the metric names are measured in the same run on configs #3 / #4 "
-                                 "(64 frames of 1080p tiled by 16x16 PUs; 2^26 coefficients per launch), outside the timed region"},
             "detail": detail,
         }
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def library_record():
+    """Which build of the library was measured, and any HEVCASM_* environment switch that was set (there should be none)."""
+    from hevcasm_amd import capi
+    return dict(library=os.path.relpath(capi.LIB_PATH, ROOT), env_switches={k: v for k, v in os.environ.items() if k.startswith("HEVCASM_")})
+
+
+# byte differences per second the chip can issue through v_qsad_pk_u16_u8 (16 per lane and instruction):
+# tools/ubench/qsad_rate.hip on MI355X, profiles/r03_qsad_rate.txt
+QSAD_PEAK_TBYTEDIFFS = None     # filled from profiles/r03_qsad_rate.json when present
+NOMINAL_QSAD_TBYTEDIFFS = 256 * 4 * 64 * 16 / 16.0 * 2.4e9 / 1e12     # quarter rate: 16 differences per lane per 16 cycles at 2.4 GHz = 157 T/s
+
+
+def qsad_peak():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_qsad_rate.json")) as f:
+            return float(json.load(f)["v_qsad_pk_u16_u8_tera_byte_differences_per_s"]), "measured: tools/ubench/qsad_rate.hip, profiles/r03_qsad_rate.txt"
+    except (OSError, ValueError, KeyError):
+        return NOMINAL_QSAD_TBYTEDIFFS, "nominal quarter rate: 16 byte differences per lane per 16 cycles, 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz"
+
+
+def measure_families():
+    """roofline.per_family: one compact row per kernel (ms per launch, algorithmic GB/s, fraction of the 8 TB/s peak)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_families as fam
+    rows = []
+
+    def collect(config, family_of):
+        for r in fam.SINK:
+            row = dict(family=family_of(r), kernel="%s %s" % (r["kernel"], r["size"]), config=config, ms=r["ms"], mblocks_per_s=r["mblocks_per_s"],
+                       gbs=r["algorithmic_gb_per_s"], frac=r["frac_of_hbm_peak"], bytes_per_block=r["bytes_per_block"])
+            for k in ("frames", "launches", "note"):
+                if k in r:
+                    row[k] = r[k]
+            rows.append(row)
+        fam.SINK = []
+
+    fam.SINK = []
+    fam.bench_pred(frames=64, only=((16, 16),))            # luma 8-tap 16x16 + chroma 4-tap 8x8, uni and bi, all fractional phases
+    collect("#3, 64 frames of 1080p per launch", lambda r: "inter_pred")
+    fam.bench_pred_latency()                                  # the same PUs, ONE frame per launch; and luma + Cb + Cr of a frame as one HIP graph
+    collect("#3, one 1080p frame", lambda r: "inter_pred_latency")
+    fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32
+    collect("#4, 2^26 coefficients per launch", lambda r: "idct" if "inverse" in r["kernel"] else "fdct")
+    fam.SINK = None
+    me = fam.bench_me_frame()
+    peak, src = qsad_peak()
+    rows.append(dict(family="full_search", kernel="me_full_search 64x64 (+ 64x48 row) +-64", config="#5, one 3840x2160 frame = 2040 CTUs, one launch",
+                     ms=me["ms"], mblocks_per_s=round(me["ctus"] / me["ms"] / 1e3, 3), frames_per_s=round(1e3 / me["ms"], 1),
+                     gbs=round(me["bytes"] / me["ms"] / 1e6, 1), frac=round(me["bytes"] / me["ms"] / 1e6 / HBM_PEAK_GBS, 4),
+                     bound="valu", gsad_evals_per_s=round(me["sad_evals"] / me["ms"] / 1e6, 2),
+                     achieved=round(me["byte_diffs"] / me["ms"] / 1e9, 2), peak=round(peak, 1), unit="T byte differences/s",
+                     frac_of_valu=round(me["byte_diffs"] / me["ms"] / 1e9 / peak, 4), peak_source=src))
+    torch.cuda.empty_cache()
+    return rows
+
+
+def gather_me_results(part, frame_w, frame_h, ctu, device="cpu"):
+    """Collect every rank's (row0, row1, results) into the frame's table on rank 0 (None elsewhere).  The answers are 12 bytes
+    per CTU, collected after the search: each rank writes its rows into a table of INT_MIN and its row ownership into a
+    vector of zeros; MAX / SUM all-reduces merge them, and the ownership vector proves every row had exactly one owner."""
+    import torch
+    import torch.distributed as dist
+    from hevcasm_amd import me_frame
+    if not (dist.is_available() and dist.is_initialized()):
+        return me_frame.assemble([part], frame_w, frame_h, ctu)
+    rows, cols = -(-frame_h // ctu), -(-frame_w // ctu)
+    row0, row1, res = part
+    table = torch.full((rows * cols, 3), -2 ** 31, dtype=torch.int32)
+    table[row0 * cols: row1 * cols] = torch.from_numpy(np.asarray(res, dtype=np.int32).reshape(-1, 3))
+    owners = torch.zeros(rows, dtype=torch.int32)
+    owners[row0:row1] = 1
+    table, owners = table.to(device), owners.to(device)
+    dist.all_reduce(table, op=dist.ReduceOp.MAX)
+    dist.all_reduce(owners, op=dist.ReduceOp.SUM)
+    assert bool((owners == 1).all()), "CTU rows without exactly one owner: %s" % owners.tolist()
+    return table.cpu().numpy() if dist.get_rank() == 0 else None
+
+
+def bench_me5(args, rank, world, device):
+    """BASELINE.json configs[4]: a step = full search (+-64) of one 3840x2160 frame, CTU rows sharded across the ranks."""
+    import torch
+    import torch.distributed as dist
+    from hevcasm_amd import batch as B, me_frame, shard
+    fw, fh, ctu, R = 3840, 2160, 64, 64
+    rows, cols = -(-fh // ctu), -(-fw // ctu)
+    row0, row1 = shard.ctu_row_range(rows, rank, world)
+    # a few distinct frame pairs, rotated over the steps; every rank builds the same frames from the seed and keeps only its slab
+    # (current rows + reference rows with the halo) -- its H2D copy is the slab, never the frame
+    n_pairs = 3
+    slabs, frames0 = [], None
+    for i in range(n_pairs):
+        f = me_frame.synthetic_frame_pair(fw, fh, R, seed=500 + i)
+        if i == 0 and rank == 0:
+            frames0 = f
+        if row1 > row0:
+            sl = me_frame.Slab(f, ctu, R, row0, row1)
+            slabs.append(dict(slab=sl, cur=torch.from_numpy(sl.cur).to(device), ref=torch.from_numpy(sl.ref).to(device),
+                              out=torch.empty((sl.n_ctus, 3), dtype=torch.int32, device=device)))
+        del f
+    torch.cuda.synchronize()
+
+    def step(i):
+        if not slabs:
+            return
+        d = slabs[i % n_pairs]
+        sl = d["slab"]
+        B.me_full_search_frame_rows(d["cur"], sl.cur_byte0, sl.stride_cur, d["ref"], sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, row0, row1, out=d["out"])
+
+    def bracket():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    bracket()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()
+    torch.cuda.synchronize()
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local)
+    bracket()
+    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)          # this rank's launches back to back: the kernel's average duration
+    # the answers of the first frame pair, from every rank (outside the timed region)
+    step(0)
+    torch.cuda.synchronize()
+    part = (row0, row1, slabs[0]["out"].cpu().numpy() if slabs else np.zeros((0, 3), dtype=np.int32))
+    table = gather_me_results(part, fw, fh, ctu, device=device if world > 1 and dist.get_backend() == "nccl" else "cpu")
+
+    if rank == 0:
+        n_ctus = rows * cols
+        heights = [min(ctu, fh - r * ctu) for r in range(rows)]
+        byte_diffs = sum(cols * ctu * h for h in heights) * (2 * R + 1) ** 2
+        sad_evals = n_ctus * (2 * R + 1) ** 2
+        alg_bytes = sum(cols * (ctu * h + (ctu + 2 * R) * (h + 2 * R) + 12) for h in heights)     # SURVEY 8(d): source + window + result per CTU
+        my_heights = heights[row0:row1]
+        my_diffs = sum(cols * ctu * h for h in my_heights) * (2 * R + 1) ** 2
+        peak, peak_src = qsad_peak()
+        # CPU baseline: the reference's own hevcasm_sad composed per candidate (refdrv), a bounded sample of this frame's CTUs,
+        # one process per core -- and the same CTUs checked against the GPU's table
+        cpu = None
+        if args.cpu_seconds > 0:
+            cpu = me_cpu_baseline(frames0, table, ctu, R, args.cpu_seconds, args.cpu_procs)
+        value = n_ctus * args.steps / elapsed / 1e6
+        line = {
+            "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
+            "value": round(value, 4), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[4]: full-search motion estimation, SAD over +-64, one 3840x2160 frame per step = 2040 CTUs "
+                                   "(33 rows of 64x64, one of 64x48); a block = one CTU = 16 641 SAD evaluations",
+                       "parallelism": "CTU rows split x%d (rank 0: rows %d..%d), each rank holds its rows + the +-64-row halo of the reference; no data-path collective" % (world, row0, row1),
+                       "frames_per_s": round(args.steps / elapsed, 1), "gsad_evals_per_s": round(sad_evals * args.steps / elapsed / 1e9, 2), **library_record()},
+            "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": round(my_diffs / (kernel_ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                         "unit": "T byte differences/s", "frac": round(my_diffs / (kernel_ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
+                         "avg_launch_ms": round(kernel_ms, 4), "peak_source": peak_src,
+                         "hbm": {"algorithmic_bytes_per_frame": alg_bytes, "gbs": round(alg_bytes * args.steps / elapsed / 1e9, 1),
+                                 "frac_of_hbm_peak": round(alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
+                         "note": "full search is bound by the issue rate of the byte-SAD instruction, not by HBM (1.7 k byte differences per byte fetched); "
+                                 "achieved = rank 0's byte differences per launch / its average launch duration (HIP events around the timed launches)"},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def me_cpu_baseline(frame, gpu_table, ctu, R, budget_s, max_procs):
+    from concurrent.futures import ThreadPoolExecutor
+    from hevcasm_amd import me_frame
+    from oracle import pyref
+    if not pyref.available():
+        return None
+    procs_n, cores_info = host_cores(max_procs)
+    fw, fh = frame["w"], frame["h"]
+    rows, cols = -(-fh // ctu), -(-fw // ctu)
+    # a spread of CTUs over the frame (incl. the first, the seam rows and the 64x48 bottom row), a few per process
+    per_proc = 2
+    picks = np.unique(np.concatenate([np.linspace(0, rows * cols - 1, procs_n * per_proc).astype(np.int64), [rows * cols - 1, (rows - 1) * cols]]))
+    # refdrv takes whole planes through a pipe: hand every process a cut-out that holds its CTUs' windows, not the 4K frame
+    def worker(k):
+        mine = picks[k::procs_n]
+        t, out = 0.0, []
+        with pyref.RefProc() as p:
+            for idx in mine:
+                r, c = divmod(int(idx), cols)
+                h = min(ctu, fh - r * ctu)
+                y0, x0 = r * ctu, c * ctu
+                cur = frame["cur"].reshape(fh, -1)[y0:y0 + h, x0:x0 + ctu].copy()
+                ref = frame["ref"].reshape(fh + 2 * frame["pad"], -1)[y0 + frame["pad"] - R: y0 + frame["pad"] + h + R, x0 + frame["pad"] - R: x0 + frame["pad"] + ctu + R].copy()
+                t0 = time.perf_counter()
+                res = p.me_full_search(cur.reshape(-1), ctu, ref.reshape(-1), ctu + 2 * R, np.array([0], dtype=np.uint32),
+                                       np.array([R * (ctu + 2 * R) + R], dtype=np.uint32), ctu, h, R)
+                t += time.perf_counter() - t0
+                out.append((int(idx), res[0]))
+        return t, out
+
+    with ThreadPoolExecutor(procs_n) as ex:
+        res = list(ex.map(worker, range(procs_n)))
+    n = sum(len(o) for _, o in res)
+    rate = sum(len(o) / t for t, o in res if t > 0)          # CTUs per second, all processes
+    bad = [idx for _, o in res for idx, r in o if not np.array_equal(r, gpu_table[idx])]
+    return dict(value=round(rate / 1e6, 6), unit="Mblocks/s", cores=procs_n, kind="reference", ctus_per_s=round(rate, 2),
+                gsad_evals_per_s=round(rate * (2 * R + 1) ** 2 / 1e9, 4),
+                sample="reference hevcasm_sad (C path, gcc -O3, via oracle/_ref/refdrv) composed per candidate over +-%d: %d CTUs spread over the frame, "
+                       "%d processes" % (R, n, procs_n),
+                checked_against_gpu=dict(ctus=n, mismatches=len(bad)), **cores_info)
 
 
 if __name__ == "__main__":

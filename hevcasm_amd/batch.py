@@ -143,6 +143,17 @@ def me_full_search(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, sea
     return out
 
 
+def me_full_search_frame_rows(cur, cur_byte0, stride_cur, ref, ref_byte0, stride_ref, frame_w, frame_h, ctu, search_range, row0, row1, out=None):
+    """Full search over CTU rows [row0, row1) of a frame.  ``cur`` / ``ref`` are device tensors holding (a slab of) the
+    planes; ``cur_byte0`` / ``ref_byte0`` are the byte positions in them of the pixel in column 0 of CTU row ``row0``."""
+    cols = -(-frame_w // ctu)
+    out = torch.empty(((row1 - row0) * cols, 3), dtype=torch.int32, device=cur.device) if out is None else out
+    check(lib().hevcasm_hip_me_full_search_frame_rows(cur.data_ptr() + cur_byte0, stride_cur, ref.data_ptr() + ref_byte0, stride_ref,
+                                                      frame_w, frame_h, ctu, search_range, row0, row1, out.data_ptr(), _stream()),
+          "me_full_search_frame_rows")
+    return out
+
+
 def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0, out=None):
     """Fused quarter-pel refinement: out[i] = (qx, qy, cost) of the best of the 49 displacements."""
     n = src_off.numel()

@@ -38,6 +38,7 @@ HIP_API = {
     "hevcasm_hip_quantize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _sz, _vp, _vp]),
     "hevcasm_hip_quantize_reconstruct_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_me_full_search_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),
+    "hevcasm_hip_me_full_search_frame_rows": (_i, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hevcasm_hip_subpel_refine_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),
     "hevcasm_hip_pred_intra_batch": (_i, [_vp, _vp, _pd, _i, _i, _sz, _vp]),
     "hevcasm_hip_ssd_linear_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
@@ -47,6 +48,7 @@ HIP_API = {
 _test_fn = (None, [C.POINTER(_i), _i])
 HOST_API = {
     "hevcasm_instruction_set_support": (_i, []),
+    "hevcasm_instruction_set_hip": (_i, []),
     "hevcasm_print_instruction_set_support": (None, [_vp, _i]),
     "hevcasm_main": (_i, [_i, _vp]),
     "hevcasm_test": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),

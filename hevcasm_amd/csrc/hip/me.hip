@@ -17,14 +17,35 @@
 
 namespace hevc {
 
+// Where the blocks of a launch lie.  LIST: block i = base + off[i], all W x H (the batch entry point).  FRAME: the launch
+// is rows of a CTU grid -- block i is CTU (i / cols, i % cols) of a slab whose first pixel both planes point at, CTUs
+// cut off by the frame's right / bottom edge are narrower / shorter (a 2160-row frame ends in a row of 64x48 CTUs) --
+// one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
+struct MeFrame { int cols, ctu, frame_w, slab_h; };
+
+template <bool FRAME>
 __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, int n_groups)
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, int n_groups, MeFrame fr)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
 	const uint32_t blk = blockIdx.x;
+	const uint8_t *sp, *rp0;
+	if (FRAME)
+	{
+		const int row = (int)blk / fr.cols, col = (int)blk - row * fr.cols;
+		W = min(fr.ctu, fr.frame_w - col * fr.ctu);
+		H = min(fr.ctu, fr.slab_h - row * fr.ctu);
+		sp = src + (ptrdiff_t)row * fr.ctu * stride_src + col * fr.ctu;
+		rp0 = ref + (ptrdiff_t)row * fr.ctu * stride_ref + col * fr.ctu;
+	}
+	else
+	{
+		sp = src + src_off[blk];
+		rp0 = ref + ref_off[blk];
+	}
 	// Window first, source tile behind it.  Rows are exactly as wide as the window (rounded to 16): the last
 	// dx group reads up to 16 * n_groups + W + 4 bytes of a row, i.e. into the next row -- and from the last
 	// row into the source tile -- but only for candidates past the window, which are never scored.  For 64x64
@@ -36,14 +57,13 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const int wd = W / 4;
 	const int win_w = W + 2 * R, win_h = H + 2 * R;
 
-	const uint8_t *sp = src + src_off[blk];
 	for (int i = threadIdx.x; i < wd * H; i += kThreads)
 	{
 		const int y = i / wd, x = i - y * wd;
 		s_src[i] = reinterpret_cast<const U1 *>(sp + (ptrdiff_t)y * stride_src + 4 * x)->v;
 	}
 	// window rows, zero-padded to win_stride
-	const uint8_t *rp = ref + ref_off[blk] - (ptrdiff_t)R * stride_ref - R;
+	const uint8_t *rp = rp0 - (ptrdiff_t)R * stride_ref - R;
 	const int row_dwords = win_stride / 4;
 	for (int i = threadIdx.x; i < row_dwords * win_h; i += kThreads)
 	{
@@ -148,6 +168,17 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 
 using namespace hevc;
 
+// LDS bytes of one workgroup: (H + 2R) window rows of win_stride bytes, then the source tile, which also absorbs what
+// the last dx group reads past the last window row (see the kernel's layout note)
+static size_t me_lds_bytes(int W, int H, int range, int *win_stride, int *n_groups)
+{
+	*n_groups = (2 * range + 1 + 15) / 16;                           // dx groups of 16
+	*win_stride = (W + 2 * range + 15) & ~15;
+	const int overread = 16 * *n_groups + W + 4 - *win_stride;       // bytes the last window row is read past its end
+	const int tail = W * H > overread ? W * H : overread;
+	return (size_t)*win_stride * (H + 2 * range) + (size_t)((tail + 15) & ~15);
+}
+
 extern "C" int hevcasm_hip_me_full_search_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *result,
@@ -160,14 +191,32 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (n_blocks == 0) return 0;
 	if (n_blocks > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	// dx groups of 16; a group reads up to W + 20 window bytes starting at 16 * g (see the kernel's layout note)
-	const int n_groups = (2 * range + 1 + 15) / 16;
-	const int win_stride = (W + 2 * range + 15) & ~15;
-	const int overread = 16 * n_groups + W + 4 - win_stride;         // bytes the last window row is read past its end
-	const int tail = W * H > overread ? W * H : overread;            // the source tile absorbs them
-	const size_t shmem = (size_t)win_stride * (H + 2 * range) + (size_t)((tail + 15) & ~15);
+	int win_stride, n_groups;
+	const size_t shmem = me_lds_bytes(W, H, range, &win_stride, &n_groups);
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	hipLaunchKernelGGL(me_full_search_kernel, dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups);
+	hipLaunchKernelGGL(me_full_search_kernel<false>, dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
+			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
 	return launch_status("me_full_search_kernel");
+}
+
+extern "C" int hevcasm_hip_me_full_search_frame_rows(
+	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+	int frame_w, int frame_h, int ctu, int range, int row0, int row1, int *result, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (ctu < 4 || ctu > 64 || (ctu & 3)) return set_error(HEVCASM_HIP_EINVAL, "CTU size must be a multiple of 4 in 4..64");
+	if (frame_w < 4 || frame_h < 4 || (frame_w & 3) || (frame_h & 3)) return set_error(HEVCASM_HIP_EINVAL, "frame dimensions must be multiples of 4");
+	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
+	const int rows = (frame_h + ctu - 1) / ctu, cols = (frame_w + ctu - 1) / ctu;
+	if (row0 < 0 || row1 > rows || row0 > row1) return set_error(HEVCASM_HIP_EINVAL, "CTU rows outside the frame");
+	if (row0 == row1) return 0;
+	if (!cur || !ref || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	int win_stride, n_groups;
+	const size_t shmem = me_lds_bytes(ctu, ctu, range, &win_stride, &n_groups);
+	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
+	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
+	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu };
+	hipLaunchKernelGGL(me_full_search_kernel<true>, dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
+			cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
+	return launch_status("me_full_search_kernel<frame>");
 }

@@ -2,7 +2,13 @@
  * hevcasm.c -- library entry points: instruction-set discovery and the self-test main.
  *
  * Counterpart of the reference's src/lib/hevcasm.c.  hevcasm_instruction_set_support()
- * (:99-138 there) additionally reports HEVCASM_HIP when the HIP side finds a gfx950 device.
+ * (:99-138 there) reports the host's instruction sets, as the reference does.  HEVCASM_HIP is OPT-IN:
+ * the reference's convention is that the highest instruction set in the mask overwrites the table
+ * entries (sad.c:63-98), and a per-block table entry behind the HIP bit is a kernel launch per block --
+ * right for the self-test's HIP column, wrong for an unchanged codec's inner loop.  So the bit is only
+ * reported when the application asks for it (HEVCASM_ENABLE_HIP=1 in the environment), and
+ * hevcasm_main() adds it itself for the self-test.  The throughput path (hevcasm_hip_*_batch) never
+ * depends on the bit.
  * hevcasm_main() (:152-186 there) runs the reference's twelve self-tests in the reference's order
  * (the ten hot-path families, intra DC and Hadamard SATD), then the linear-SSD test, which the
  * reference has (diff.c:113) but does not call from its main.
@@ -53,12 +59,22 @@ static int x86_mask(void)
 static int x86_mask(void) { return 0; }
 #endif
 
+static int env_set(const char *name)
+{
+	const char *v = getenv(name);
+	return v && *v && strcmp(v, "0");
+}
+
 hevcasm_instruction_set hevcasm_instruction_set_support(void)
 {
 	int mask = HEVCASM_C_REF | HEVCASM_C_OPT | x86_mask();
-	const char *off = getenv("HEVCASM_DISABLE_HIP");
-	if (!(off && *off && strcmp(off, "0")) && hevcasm_hip_available()) mask |= HEVCASM_HIP;
+	if (env_set("HEVCASM_ENABLE_HIP") && !env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available()) mask |= HEVCASM_HIP;
 	return (hevcasm_instruction_set)mask;
+}
+
+hevcasm_instruction_set hevcasm_instruction_set_hip(void)
+{
+	return (hevcasm_instruction_set)((!env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available()) ? HEVCASM_HIP : 0);
 }
 
 void hevcasm_print_instruction_set_support(FILE *f, hevcasm_instruction_set mask)
@@ -73,7 +89,8 @@ void hevcasm_print_instruction_set_support(FILE *f, hevcasm_instruction_set mask
 int hevcasm_main(int argc, const char *argv[])
 {
 	(void)argc; (void)argv;
-	const hevcasm_instruction_set mask = hevcasm_instruction_set_support();
+	/* the self-test wants the HIP column whenever a device is there (HEVCASM_DISABLE_HIP=1 leaves it out) */
+	const hevcasm_instruction_set mask = (hevcasm_instruction_set)(hevcasm_instruction_set_support() | hevcasm_instruction_set_hip());
 
 	printf("HEVCasm self test\n\n");
 	hevcasm_print_instruction_set_support(stdout, mask);

@@ -77,10 +77,19 @@ typedef enum
 #undef X
 } hevcasm_instruction_set;
 
-/* Bitmask of usable instruction sets: C_REF | C_OPT always, the x86 bits from cpuid
- * (reference hevcasm.c:99-138), and HEVCASM_HIP when a gfx950 device is visible to the HIP
- * runtime and HEVCASM_DISABLE_HIP is not set in the environment. */
+/* Bitmask of usable instruction sets: C_REF | C_OPT always and the x86 bits from cpuid
+ * (reference hevcasm.c:99-138) -- what the reference returns, so an unchanged codec that populates its
+ * tables from this mask gets host code, as before.  HEVCASM_HIP is opt-in: it is included only when
+ * HEVCASM_ENABLE_HIP=1 is set in the environment (and a gfx950 device is visible, and
+ * HEVCASM_DISABLE_HIP is not set), because the highest bit in a mask overwrites the table entries
+ * (reference sad.c:63-98) and a per-block entry behind HEVCASM_HIP costs a kernel launch per block. */
 hevcasm_instruction_set HEVCASM_API hevcasm_instruction_set_support(void);
+
+/* HEVCASM_HIP if a gfx950 device is visible to the HIP runtime (and HEVCASM_DISABLE_HIP is not set),
+ * else 0: for callers that want the per-block HIP table entries on purpose -- the self-test does,
+ * hevcasm_main() ORs this into its mask -- `hevcasm_instruction_set_support() | hevcasm_instruction_set_hip()`.
+ * (Not in the reference.) */
+hevcasm_instruction_set HEVCASM_API hevcasm_instruction_set_hip(void);
 
 /* One "[x] NAME (description)" line per instruction set (reference hevcasm.c:141-149).
  * Unlike the reference, output really goes to `f`. */

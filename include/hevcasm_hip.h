@@ -203,6 +203,19 @@ int hevcasm_hip_me_full_search_batch(
 	const uint32_t *src_off, const uint32_t *ref_off, int *result,
 	uint32_t rect, int range, size_t n_blocks, void *stream);
 
+/* The same search over rows [row0, row1) of a frame's CTU grid, with no descriptor arrays: the unit BASELINE.json
+ * config #5 shards across GPUs (contiguous CTU rows per GPU, each with its +-range halo of the
+ * reference frame).  The frame is frame_w x frame_h pixels (multiples of 4), cut into ctu x ctu CTUs in raster
+ * order; CTUs on the right / bottom edge are as wide / tall as the frame leaves them (2160 rows: 33 rows of 64x64
+ * and one of 64x48, the reference's partitions sad.c:231-232).  `cur` and `ref` point at the pixel in column 0 of
+ * CTU row row0 -- so a rank passes pointers into whatever slab it holds -- and the reference must be readable
+ * `range` pixels beyond the slab on every side (the halo; the caller pads frame edges, HEVC-style).
+ * result[3k..3k+2] = { dx, dy, cost } for the k-th CTU of those rows in raster order; per CTU exactly
+ * hevcasm_hip_me_full_search_batch's answer (hevcasm_sad, sad.c:47-60, per candidate; raster-first minimum). */
+int hevcasm_hip_me_full_search_frame_rows(
+	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+	int frame_w, int frame_h, int ctu, int range, int row0, int row1, int *result, void *stream);
+
 /* ---- fused quarter-pel refinement ------------------------------------- */
 
 /* For each block: the 49 luma quarter-pel displacements (qx, qy) in [-3, 3]^2 around the

@@ -194,29 +194,79 @@ def me_cases(seed=900):
     c = _me_case(16, 16, 4, 3, seed + 5)
     c["ref"][:] = 7
     out.append(("me_ties", "me", c))
+    # BASELINE.json config #5's own geometry: +-64 around 64x64 CTUs and the 64x48 CTUs of a 2160-row frame's
+    # bottom row (reference sad.c:231-232 sizes, hevcasm_sad sad.c:47-60 per candidate, raster-first minimum).
+    # Even blocks carry a planted copy (cost 0 at a known place), odd blocks are pure noise (non-zero minima).
+    out.append(("me_64x64_r64", "me", _me_case(64, 64, 64, 4, seed + 64)))
+    out.append(("me_64x48_r64", "me", _me_case(64, 48, 64, 4, seed + 48)))
+    # video-like content: smooth gradients, many near-equal costs, minima well inside the window
+    out.append(("me_64x64_r64_video", "me", _me_case(64, 64, 64, 2, seed + 65, kind="video", plant=False)))
+    # flat reference at +-64: a 16 641-way tie must resolve to (-64, -64)
+    c = _me_case(64, 64, 64, 2, seed + 66, plant=False)
+    c["ref"][:] = 200
+    out.append(("me_64x64_r64_ties", "me", c))
+    c = _me_case(64, 48, 64, 2, seed + 67, plant=False)
+    c["ref"][:] = 3
+    out.append(("me_64x48_r64_ties", "me", c))
+    # the window's corners and edges: the last dx group of the kernel holds ONE scored candidate (dx = +64) and
+    # reads on into the next window row; dy = +64 is the window's last row.  One planted copy per block.
+    at = [(64, 64), (-64, -64), (64, -64), (-64, 64), (64, 0), (0, 64), (63, 63), (48, -64), (49, 64)]
+    out.append(("me_64x64_r64_corners", "me", _me_case(64, 64, 64, len(at), seed + 68, plant=at)))
+    out.append(("me_64x48_r64_corners", "me", _me_case(64, 48, 64, len(at), seed + 69, plant=at)))
+    # two equal minima: the same block planted twice; the raster-first one (smaller dy, then smaller dx) must win
+    c = _me_case(64, 64, 64, 3, seed + 70, plant=[(17, 5), (-3, 20), (64, -64)])
+    _plant(c, 0, -30, 5)     # same row, further left  -> (-30, 5) wins over (17, 5)
+    _plant(c, 1, 40, -21)    # an earlier row          -> (40, -21) wins over (-3, 20)
+    _plant(c, 2, -64, 64)    # a later row             -> (64, -64) stays
+    out.append(("me_64x64_r64_double", "me", c))
+    # other ranges with the same layout rules: a range that is not a multiple of 16, the largest the API takes at 16x16
+    out.append(("me_32x32_r37", "me", _me_case(32, 32, 37, 3, seed + 71)))
+    out.append(("me_16x16_r100", "me", _me_case(16, 16, 100, 2, seed + 72)))
     return out
 
 
-def _me_case(w, h, r, n, seed):
-    fw, fh = wl.SMALL_W, wl.SMALL_H
-    frames = wl.Plane.frames_for(n, w, h, fw, fh)
-    sp = wl.Plane(fw, fh, frames)
-    rp = wl.Plane(fw, fh, frames, border_x=16, border_y=16)
-    assert r <= 16
+def _plant(c, i, dx, dy):
+    """Copy source block i into its reference window at displacement (dx, dy)."""
+    w, h = c["w"], c["h"]
+    blk = _dst_rows(c["src"], c["stride_src"], c["src_off"][i:i + 1], w, h)[0]
+    base = int(c["ref_off"][i]) + dy * c["stride_ref"] + dx
+    for y in range(h):
+        c["ref"][base + y * c["stride_ref"]: base + y * c["stride_ref"] + w] = blk[y]
+
+
+def _me_case(w, h, r, n, seed, kind="noise", plant=True):
+    """n blocks on tiles at least a window apart, so that neighbouring blocks' plantings never meet.
+    plant: True = a random displacement for every other block; a list of (dx, dy) = block i at plant[i]."""
+    if r <= 16:
+        fw, fh = wl.SMALL_W, wl.SMALL_H
+        frames = wl.Plane.frames_for(n, w, h, fw, fh)
+        sp = wl.Plane(fw, fh, frames)
+        rp = wl.Plane(fw, fh, frames, border_x=16, border_y=16)
+        src_off = sp.tile_offsets(n, w, h)
+        ref_off = rp.tile_offsets(n, w, h)
+    else:
+        # one block per (w + 2r) x (h + 2r) cell, three cells to a row: windows of different blocks are disjoint
+        fw, fh = (w + 2 * r) * min(n, 3), (h + 2 * r) * -(-n // 3)
+        sp = wl.Plane(fw, fh, 1)
+        rp = wl.Plane(fw, fh, 1, border_x=r, border_y=r)
+        i = np.arange(n, dtype=np.int64)
+        cy, cx = (i // 3) * (h + 2 * r) + r, (i % 3) * (w + 2 * r) + r
+        src_off = cy * sp.stride + cx
+        ref_off = (cy + r) * rp.stride + cx + r
     rng = np.random.default_rng(seed)
-    src = wl.fill_u8(sp.size, seed)
-    ref = wl.fill_u8(rp.size, seed + 1)
-    src_off = sp.tile_offsets(n, w, h)
-    ref_off = rp.tile_offsets(n, w, h)
-    # plant the source block somewhere in the window of half the blocks so the minimum is unique and interior
-    for i in range(0, n, 2):
-        dx, dy = rng.integers(-r, r + 1, 2)
-        blk = _dst_rows(src, sp.stride, src_off[i:i + 1], w, h)[0]
-        base = int(ref_off[i]) + dy * rp.stride + dx
-        for y in range(h):
-            ref[base + y * rp.stride: base + y * rp.stride + w] = blk[y]
-    return dict(src=src, stride_src=sp.stride, ref=ref, stride_ref=rp.stride, src_off=src_off.astype(np.uint32),
-                ref_off=ref_off.astype(np.uint32), w=w, h=h, range=r, n=n)
+    src = wl.fill_u8(sp.size, seed, kind)
+    ref = wl.fill_u8(rp.size, seed + 1, kind)
+    c = dict(src=src, stride_src=sp.stride, ref=ref, stride_ref=rp.stride, src_off=src_off.astype(np.uint32),
+             ref_off=ref_off.astype(np.uint32), w=w, h=h, range=r, n=n)
+    if plant is True:
+        # plant the source block somewhere in the window of half the blocks so the minimum is unique and interior
+        for i in range(0, n, 2):
+            dx, dy = rng.integers(-r, r + 1, 2)
+            _plant(c, i, int(dx), int(dy))
+    elif plant:
+        for i, (dx, dy) in enumerate(plant):
+            _plant(c, i, dx, dy)
+    return c
 
 
 def subpel_cases(seed=1000):

@@ -64,7 +64,7 @@ def small_cases():
         out.append(("fwd_%s_res9" % tag, "forward", wl.forward_case(tr, lg, 6, 54 + lg, "residual9", frame=(2 * s, 2 * s))))
         out.append(("fwd_%s_full" % tag, "forward", wl.forward_case(tr, lg, 6, 55 + lg, "full", frame=(2 * s, 2 * s))))
     out += [x for x in cases.quant_cases() if x[0] in ("deq_16_ref", "deq_1024_full", "q_16_ref", "q_256_hevc", "q_1024_min", "q_64_sparse", "rec_4", "rec_32_full", "deq_tail")]
-    out += [x for x in cases.me_cases() if x[0] in ("me_16x16_r8", "me_ties")]
+    out += [x for x in cases.me_cases() if x[0] in ("me_16x16_r8", "me_ties", "me_32x32_r37", "me_64x48_r64_ties", "me_64x64_r64_double")]
     out += [x for x in cases.subpel_cases() if x[0] in ("subpel_8x8", "subpel_smooth_16x16", "subpel_ties", "subpel_satd_16x16", "subpel_satd_12x16")]
     out += [x for x in cases.intra_cases() if x[0].endswith("_s160")]
     out += [x for x in cases.ssd_linear_cases() if x[0] in ("ssdlin_17", "ssdlin_512", "ssdlin_1023", "ssdlin_4099")]

@@ -127,15 +127,30 @@ int main(void) {
 
 
 def test_no_gpu_means_refusal_not_fallback():
-    """Without a usable gfx950 device every batch entry point returns ENODEV and the mask has no
-    HIP bit.  (On the GPU box this test checks the opposite side: the bit is present.)"""
+    """Without a usable gfx950 device every batch entry point returns ENODEV and no mask has the HIP
+    bit.  The default mask NEVER has it -- an unchanged codec populating its tables from
+    hevcasm_instruction_set_support() must get host code, not a kernel launch per block -- it is
+    opt-in (HEVCASM_ENABLE_HIP=1, or hevcasm_instruction_set_hip()); on the GPU box this test
+    checks that side too."""
+    import subprocess
+    import sys
     L = capi.lib()
+    assert "HEVCASM_ENABLE_HIP" not in os.environ
     mask = L.hevcasm_instruction_set_support()
     assert mask & capi.C_REF and mask & capi.C_OPT
-    if L.hevcasm_hip_available():
-        assert mask & capi.HIP
-        return
     assert not mask & capi.HIP
+    probe = "import sys; sys.path.insert(0, %r); from hevcasm_amd import capi; print(capi.lib().hevcasm_instruction_set_support() & capi.HIP, capi.lib().hevcasm_instruction_set_hip())" % ROOT
+    def masks(**env):
+        out = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, check=True, env=dict(os.environ, **env)).stdout.split()
+        return int(out[0]), int(out[1])
+    if L.hevcasm_hip_available():
+        assert L.hevcasm_instruction_set_hip() == capi.HIP
+        assert masks(HEVCASM_ENABLE_HIP="1") == (capi.HIP, capi.HIP)
+        assert masks(HEVCASM_ENABLE_HIP="1", HEVCASM_DISABLE_HIP="1") == (0, 0)
+        assert masks(HEVCASM_ENABLE_HIP="0") == (0, capi.HIP)
+        return
+    assert L.hevcasm_instruction_set_hip() == 0
+    assert masks(HEVCASM_ENABLE_HIP="1") == (0, 0)
     assert L.hevcasm_hip_sad_batch(None, 0, None, 0, None, None, None, capi.rect(16, 16), 1, None) == capi.ENODEV
     assert L.hevcasm_hip_quantize_inverse(None, None, 1, 1, 16, None) == capi.ENODEV
     p = C.c_void_p()

@@ -56,6 +56,43 @@ def test_sad_full_size_properties():
     assert int(B.ssd(src, c["stride_src"], src, c["stride_src"], so, so, 16, 16).abs().max()) == 0
 
 
+@pytest.mark.parametrize("w,h", [(64, 64), (48, 64), (32, 32), (64, 16), (16, 64), (8, 8)])
+def test_sad4_full_size_on_the_bench_geometry(w, h):
+    """The kernels bench.py's step is dominated by, at the shape bench.py times them: 1 Mi blocks per size on 1920x1152
+    frames (reference stride 1952), built by bench.py's own SizeBatch -- 64x64 and 48x64 as two launches of 524 288
+    blocks each (the 4 GiB offset window), the window kernel for the 64-/48-wide ones.  Per launch: the 4-way result
+    equals four single-reference launches; SAD of the source against itself is 0; the blocks of the LAST frame (largest
+    offsets) equal the oracle on a host copy of that frame alone."""
+    import torch
+    import bench
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    sb = bench.SizeBatch(w, h, 1 << 20, 4711 + w + h, torch.device("cuda", 0))
+    assert len(sb.chunks) == (2 if w * h >= 48 * 64 else 1)
+    per_frame = (wl.FRAME_W // w) * (wl.FRAME_H // h)
+    for c in sb.chunks:
+        n = c["n"]
+        sb.launch(4, c)
+        four = c["out4"]
+        ro = c["ref_off4"].view(n, 4)
+        for k in range(4):
+            one = B.sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], ro[:, k].contiguous(), w, h)
+            assert torch.equal(one, four[:, k]), (w, h, k)
+        assert int(B.sad(c["src"], c["stride_src"], c["src"], c["stride_src"], c["src_off"], c["src_off"], w, h).abs().max()) == 0
+        # last whole frame of the chunk against the oracle: copy just that frame of each plane to the host and rebase the offsets
+        f = (n - 1) // per_frame
+        a, b = f * per_frame, min(n, (f + 1) * per_frame)
+        src_frame, ref_frame = wl.FRAME_W * wl.FRAME_H, (wl.FRAME_W + 32) * (wl.FRAME_H + 16)
+        src_h = c["src"][f * src_frame: (f + 1) * src_frame].cpu().numpy()
+        ref_h = c["ref"][f * ref_frame: (f + 1) * ref_frame].cpu().numpy()
+        so = (c["src_off"][a:b].cpu().numpy().view(np.uint32).astype(np.int64) - f * src_frame).astype(np.uint32)
+        ro_h = (c["ref_off4"][4 * a: 4 * b].cpu().numpy().view(np.uint32).astype(np.int64) - f * ref_frame).astype(np.uint32)
+        want = pyoracle.sad_multiref_batch(src_h, c["stride_src"], ref_h, c["stride_ref"], so, ro_h, w, h)
+        assert np.array_equal(four[a:b].cpu().numpy(), want), (w, h)
+    del sb
+    torch.cuda.empty_cache()
+
+
 def test_transform_roundtrip_full_size():
     """Forward DCT then inverse transform + add onto a zero prediction returns the (clipped)
     residual to within the HEVC integer transform pair's rounding (a few LSB): a property no single kernel can fake."""
@@ -87,9 +124,17 @@ def test_quantize_roundtrip_and_cbf():
     # cbf == 0 exactly for all-zero blocks
     nz = (q.view(-1, 256) != 0).any(dim=1)
     assert torch.equal(nz, cbf != 0)
-    # dequantising with the matching scale lands within one quantiser step of the input
-    dq = B.quantize_inverse(q, 80, 0 + 1)  # scale 80 >> 1 = 40 = HEVC levelScale for qP%6 == 0 (step 2^(... ) )
-    assert dq.shape == src.shape
+    # the quantiser itself, whole batch, against its definition (reference quantize.c:160-186) in numpy
+    x = src.cpu().numpy().astype(np.int64)
+    lv = np.sign(x) * ((np.abs(x) * 26214 + ((171 << 7) << (21 - 16))) >> 21)
+    assert np.array_equal(q.cpu().numpy().astype(np.int64), np.clip(lv, -32768, 32767))
+    # dequantising with the matching scale (26214 / 2^21 = 1 / 80.0: step 80 = scale 160 >> 1) lands within one quantiser
+    # step of the input -- (q * 160 + 1) >> 1 = 80 q, no clipping since |q| <= 410 -- and on the input's side of zero
+    dq = B.quantize_inverse(q, 160, 1)
+    err = (dq.to(torch.int32) - src.to(torch.int32))
+    assert int(err.abs().max()) < 80, int(err.abs().max())
+    assert bool((dq.to(torch.int32).abs() <= src.to(torch.int32).abs() + 27).all())      # rounding offset 0.334 of a step: at most 27 above |x|
+    assert torch.equal(dq.to(torch.int32), q.to(torch.int32) * 80)
 
 
 def test_pred_full_size_properties():
@@ -126,10 +171,13 @@ def test_pred_full_size_properties():
 
 
 def test_full_search_finds_planted_block():
-    """Config #5 geometry (64x64 CTUs, +-64): a CTU copied into its own search window at a known
-    displacement is found with cost 0; CTUs with a flat window tie to the first candidate."""
+    """Config #5 geometry (64x64 CTUs, +-64) on a frame whose search windows overlap as they do in a
+    real frame: a CTU copied into its own window at a known displacement is found with cost 0 at the
+    raster-first zero-cost position, which is the planted one unless an earlier candidate is also a
+    perfect match (checked by recomputing that candidate's SAD); every CTU equals the oracle."""
     import torch
     from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
     fw, fh, r, w, h = 1024, 512, 64, 64, 64
     rng = np.random.default_rng(5)
     src = wl.fill_u8(fw * fh, 1)
@@ -138,7 +186,7 @@ def test_full_search_finds_planted_block():
     by, bx = np.meshgrid(np.arange(fh // h), np.arange(fw // w), indexing="ij")
     so = (by * h * fw + bx * w).reshape(-1)
     ro = ((by * h + r) * stride_r + bx * w + r).reshape(-1)
-    # plant every other CTU; windows of neighbouring CTUs overlap, so only the cost-0 ones are asserted exactly
+    # plant every other CTU; windows of neighbouring CTUs overlap, so a later planting may overwrite an earlier one
     planted = {}
     for i in range(0, so.size, 2):
         dx, dy = (int(v) for v in rng.integers(-r, r + 1, 2))
@@ -153,12 +201,65 @@ def test_full_search_finds_planted_block():
     hits = 0
     for i, (dx, dy) in planted.items():
         blk = cases._dst_rows(src, fw, so[i:i + 1], w, h)[0]
-        still = all(np.array_equal(ref[int(ro[i]) + (dy + y) * stride_r + dx: int(ro[i]) + (dy + y) * stride_r + dx + w], blk[y]) for y in range(h))
+        still = np.array_equal(cases._dst_rows(ref, stride_r, np.array([int(ro[i]) + dy * stride_r + dx]), w, h)[0], blk)
         if still:   # not overwritten by a later neighbour's planting
-            assert out[i, 2] == 0 and (out[i, 0], out[i, 1]) <= (dx, dy) or out[i, 2] == 0, (i, out[i], dx, dy)
-            assert out[i, 2] == 0
+            assert out[i, 2] == 0, (i, out[i], dx, dy)
+            gx, gy = int(out[i, 0]), int(out[i, 1])
+            assert (gy, gx) <= (dy, dx), (i, out[i], dx, dy)            # raster order of (dy, dx): never after the planted one
+            if (gy, gx) != (dy, dx):                                        # an earlier perfect match must really be one
+                assert np.array_equal(cases._dst_rows(ref, stride_r, np.array([int(ro[i]) + gy * stride_r + gx]), w, h)[0], blk)
             hits += 1
     assert hits >= len(planted) // 2
+    want = pyoracle.me_full_search(src, fw, ref, stride_r, so.astype(np.uint32), ro.astype(np.uint32), w, h, r)
+    cases.assert_same("me 1024x512 +-64", (out,), (want,))
+
+
+def test_full_search_4k_frame_equals_oracle():
+    """BASELINE.json config #5 at its full size: one 3840x2160 luma frame, 60 x 34 CTUs (33 rows of
+    64x64 and a bottom row of 64x48, reference sad.c:231-232), +-64 around every CTU, the reference
+    frame padded by 64 replicated pixels.  Three ways to the same table, all compared over the WHOLE
+    frame: the oracle (hevcasm_sad, sad.c:47-60, per candidate, raster-first minimum: 33.9 M SAD
+    evaluations on video-like content, non-zero minima everywhere); the block-list entry point (two
+    launches, one per CTU shape); the frame-rows entry point, unsharded (one launch) and as the 8 ranks
+    of config #5 would run it (each on its own slab = its CTU rows + the +-64-row halo, uploaded
+    separately; the 34 rows split 5,5,4,4,4,4,4,4 so the 64x48 row is the last rank's)."""
+    import torch
+    from hevcasm_amd import batch as B, me_frame
+    from oracle import pyoracle
+    f = me_frame.synthetic_frame_pair(3840, 2160, 64, seed=77)
+    jobs = me_frame.ctu_jobs(2160, 3840, 64, f["stride_cur"], f["stride_ref"], 64, 0, 34)
+    assert sorted((j["w"], j["h"], len(j["index"])) for j in jobs) == [(64, 48, 60), (64, 64, 1980)]
+    cur_d, ref_d = B.u8(f["cur"]), B.u8(f["ref"])
+    want = np.zeros((2040, 3), dtype=np.int32)
+    listed = np.zeros((2040, 3), dtype=np.int32)
+    for j in jobs:
+        want[j["index"]] = pyoracle.me_full_search(f["cur"], f["stride_cur"], f["ref"], f["stride_ref"], j["cur_off"], j["ref_off"], 64, j["h"], 64)
+        listed[j["index"]] = B.me_full_search(cur_d, f["stride_cur"], ref_d, f["stride_ref"], B.off32(j["cur_off"]), B.off32(j["ref_off"]), 64, j["h"], 64).cpu().numpy()
+    assert (want[:, 2] > 0).mean() > 0.9          # the comparison is about non-trivial minima ...
+    assert len(set(map(tuple, want[:, :2]))) > 1000   # ... at many different displacements
+    cases.assert_same("me 4K frame, block lists", (listed,), (want,))
+    whole = B.me_full_search_frame_rows(cur_d, 0, f["stride_cur"], ref_d, 64 * f["stride_ref"] + 64, f["stride_ref"], 3840, 2160, 64, 64, 0, 34).cpu().numpy()
+    cases.assert_same("me 4K frame, one launch", (whole,), (want,))
+    fn = me_frame.hip_rows_fn()
+    parts = [me_frame.search_rank(f, 64, 64, rank, 8, fn) for rank in range(8)]
+    assert [p[1] - p[0] for p in parts] == [5, 5, 4, 4, 4, 4, 4, 4]
+    cases.assert_same("me 4K frame, 8 slabs", (me_frame.assemble(parts, 3840, 2160, 64),), (want,))
+
+
+def test_full_search_frame_rows_ragged_edges():
+    """Frames whose width and height are not multiples of the CTU (right column, bottom row and the corner CTU are
+    narrower / shorter), ranges that are not multiples of 16, more ranks than CTU rows: every split equals the oracle."""
+    from hevcasm_amd import batch as B, me_frame
+    from oracle import pyoracle
+    for (fw, fh, ctu, r, world) in ((200, 176, 64, 24, 3), (96, 80, 32, 37, 2), (64, 48, 64, 64, 4), (128, 128, 16, 9, 5), (72, 40, 64, 16, 1)):
+        f = me_frame.synthetic_frame_pair(fw, fh, r, seed=fw + r, ctu=ctu, max_motion=min(r, 20))
+        rows, cols = -(-fh // ctu), -(-fw // ctu)
+        want = np.zeros((rows * cols, 3), dtype=np.int32)
+        for j in me_frame.ctu_jobs(fh, fw, ctu, f["stride_cur"], f["stride_ref"], r, 0, rows):
+            want[j["index"]] = pyoracle.me_full_search(f["cur"], f["stride_cur"], f["ref"], f["stride_ref"], j["cur_off"], j["ref_off"], j["w"], j["h"], r)
+        fn = me_frame.hip_rows_fn()
+        parts = [me_frame.search_rank(f, ctu, r, rank, world, fn) for rank in range(world)]
+        cases.assert_same("me frame %dx%d ctu %d +-%d x%d" % (fw, fh, ctu, r, world), (me_frame.assemble(parts, fw, fh, ctu),), (want,))
 
 
 def test_subpel_refine_equals_unfused_composition():

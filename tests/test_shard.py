@@ -59,3 +59,93 @@ def test_two_rank_gloo_shards_reassemble():
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
     assert "SHARD_OK" in outs[0][0]
+
+
+# ----------------------------------------------------------------------- config #5: CTU rows + halo
+
+def _oracle_rows_fn(slab):
+    """A rank's search on the CPU: the oracle over the slab's CTUs.  The slab is copied into exactly-sized arrays first,
+    so anything the rank would need beyond its rows + halo is simply not there."""
+    import numpy as np
+    from hevcasm_amd import me_frame
+    from oracle import pyoracle
+    cur, ref = slab.cur.copy(), slab.ref.copy()
+    out = np.zeros((slab.n_ctus, 3), dtype=np.int32)
+    for j in me_frame.ctu_jobs(slab.frame_h, slab.frame_w, slab.ctu, slab.stride_cur, slab.stride_ref, slab.pad, slab.row0, slab.row1,
+                               cur_row_base=slab.y0, ref_row_base=slab.ref_row_base):
+        out[j["index"]] = pyoracle.me_full_search(cur, slab.stride_cur, ref, slab.stride_ref, j["cur_off"], j["ref_off"], j["w"], j["h"], slab.range)
+    return out
+
+
+def _whole_frame_oracle(f, ctu, r):
+    from hevcasm_amd import me_frame
+    from oracle import pyoracle
+    rows, cols = -(-f["h"] // ctu), -(-f["w"] // ctu)
+    want = np.zeros((rows * cols, 3), dtype=np.int32)
+    for j in me_frame.ctu_jobs(f["h"], f["w"], ctu, f["stride_cur"], f["stride_ref"], f["pad"], 0, rows):
+        want[j["index"]] = pyoracle.me_full_search(f["cur"], f["stride_cur"], f["ref"], f["stride_ref"], j["cur_off"], j["ref_off"], j["w"], j["h"], r)
+    return want
+
+
+def test_me_slab_rows_cover_exactly_the_search_windows():
+    from hevcasm_amd.shard import ctu_row_range, me_slab_rows
+    # 2160 rows, 64x64 CTUs, +-64, 8 ranks: 34 CTU rows as 5,5,4,...; the last rank's slab ends with the 48-row CTUs
+    spans = [ctu_row_range(34, r, 8) for r in range(8)]
+    assert [b - a for a, b in spans] == [5, 5, 4, 4, 4, 4, 4, 4]
+    assert me_slab_rows(2160, 64, 64, *spans[0]) == (0, 320, -64, 384)
+    assert me_slab_rows(2160, 64, 64, *spans[7]) == (1920, 2160, 1856, 2224)
+    # neighbouring slabs share exactly 2 * range reference rows and no current-frame row
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        ya = me_slab_rows(2160, 64, 64, a0, a1)
+        yb = me_slab_rows(2160, 64, 64, b0, b1)
+        assert ya[1] == yb[0] and ya[3] - yb[2] == 128
+    with np.testing.assert_raises(ValueError):
+        me_slab_rows(2160, 64, 64, 30, 35)
+    assert ctu_row_range(2, 3, 4) == (2, 2)          # more ranks than rows: empty range
+
+
+def test_me_frame_splits_equal_the_unsharded_search():
+    """Every split of a frame into CTU-row slabs (each searched on a private copy of its rows + halo) reassembles into
+    the unsharded result: seams between ranks, the 64x48 bottom row, ragged right column, an idle rank."""
+    from hevcasm_amd import me_frame
+    for (fw, fh, ctu, r, worlds) in ((200, 240, 64, 64, (1, 2, 3, 4, 6)), (96, 80, 32, 20, (2, 3))):
+        f = me_frame.synthetic_frame_pair(fw, fh, r, seed=fw, ctu=ctu, max_motion=min(r, 30))
+        want = _whole_frame_oracle(f, ctu, r)
+        assert len(set(map(tuple, want[:, :2]))) > len(want) // 2
+        for world in worlds:
+            parts = [me_frame.search_rank(f, ctu, r, rank, world, _oracle_rows_fn) for rank in range(world)]
+            assert np.array_equal(me_frame.assemble(parts, fw, fh, ctu), want), (fw, fh, world)
+
+
+_ME_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from hevcasm_amd import me_frame
+import bench, test_shard
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank, world = dist.get_rank(), dist.get_world_size()
+# 320 x 240: CTU rows of 64, 64, 64 and 48 pixels -> rank 0 owns rows 0-1, rank 1 rows 2-3 (the seam at row 128 and the 64x48 bottom row)
+f = me_frame.synthetic_frame_pair(320, 240, 64, seed=5)
+# bench.py's own config #5 path: search this rank's slab, then collect the answers (bench.gather_me_results)
+part = me_frame.search_rank(f, 64, 64, rank, world, test_shard._oracle_rows_fn)   # the oracle stands in for the GPU on this CPU-only box
+table = bench.gather_me_results(part, 320, 240, 64)
+if rank == 0:
+    want = test_shard._whole_frame_oracle(f, 64, 64)
+    assert table.shape == (20, 3) and np.array_equal(table, want), (table, want)
+    print("ME_SHARD_OK", part[0], part[1])
+else:
+    assert table is None and (part[0], part[1]) == (2, 4)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_me_frame_rows_and_halo():
+    port = 31500 + os.getpid() % 2000
+    code = _ME_WORKER % dict(root=ROOT, port=port)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    assert "ME_SHARD_OK 0 2" in outs[0][0]

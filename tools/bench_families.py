@@ -70,6 +70,79 @@ def bench_pred(frames=64, only=None):
                 torch.cuda.empty_cache()
 
 
+def bench_pred_latency(reps=30):
+    """Config #3 at its literal size -- ONE 1920x1080 4:2:0 frame: luma tiled by 16x16 PUs (8-tap), Cb and Cr by 8x8 (4-tap), all
+    phases -- as a codec that predicts frame by frame sees it (hard parts): (a) one plane per launch, launches
+    issued back to back, HIP events around each; (b) the frame's three launches (luma + Cb + Cr) captured once into a HIP graph
+    and replayed, events around `reps` replays.  Inputs rotate over 3 frames; a frame (3 MB + 3 MB) sits in the Infinity Cache
+    after its first use, which is also what a decoder's reference frames do."""
+    planes = (("luma", 8, 1920, 1080, 16, 16), ("cb", 4, 960, 540, 8, 8), ("cr", 4, 960, 540, 8, 8))
+    for bi in (False, True):
+        refs = 2 if bi else 1
+        sets = []
+        for k in range(3):
+            one = []
+            for j, (name, taps, fw, fh, pw, ph) in enumerate(planes):
+                n = (fw // pw) * (fh // ph)
+                c = wl.pred_case(taps, pw, ph, n, 700 + 10 * k + j, bi=bi, frame=(fw, fh), device="cuda")
+                d = dict(c=c, n=n, taps=taps, pw=pw, ph=ph, dst=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), dst_off=B.off32(c["dst_off"]))
+                for r in range(refs):
+                    d["ref%d" % r] = c["ref%d" % r]; d["ref%d_off" % r] = B.off32(c["ref%d_off" % r]); d["frac%d" % r] = B.u8(c["frac%d" % r])
+                one.append(d)
+            sets.append(one)
+
+        def launch(d):
+            c = d["c"]
+            if bi:
+                B.pred_bi(d["dst"], c["stride_dst"], d["ref0"], d["ref1"], c["stride_ref"], d["dst_off"], d["ref0_off"], d["ref1_off"], d["frac0"], d["frac1"], d["taps"], d["pw"], d["ph"])
+            else:
+                B.pred_uni(d["dst"], c["stride_dst"], d["ref0"], c["stride_ref"], d["dst_off"], d["ref0_off"], d["frac0"], d["taps"], d["pw"], d["ph"])
+
+        def bytes_of(d):
+            return refs * (d["pw"] + d["taps"] - 1) * (d["ph"] + d["taps"] - 1) + d["pw"] * d["ph"] + 4 * (1 + refs) + refs
+
+        for one in sets:                       # warm-up: code objects, first touch
+            for d in one:
+                launch(d)
+        torch.cuda.synchronize()
+        # (a) one plane per launch
+        for j in (0, 1):
+            ts = []
+            for i in range(reps):
+                d = sets[i % 3][j]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); launch(d); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            d = sets[0][j]
+            report("pred_%s_%dtap" % ("bi" if bi else "uni", d["taps"]), d["n"], bytes_of(d), float(np.median(ts)), size="%dx%d" % (d["pw"], d["ph"]), frames=1,
+                   note="one %s plane of one 1080p frame per launch, HIP events around the launch" % planes[j][0])
+        # (b) luma + Cb + Cr as one graph
+        graphs = []
+        side = torch.cuda.Stream()
+        for one in sets:
+            g = torch.cuda.CUDAGraph()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(g, stream=side):
+                for d in one:
+                    launch(d)
+            graphs.append(g)
+        torch.cuda.synchronize()
+        for g in graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            graphs[i % 3].replay()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        n_all = sum(d["n"] for d in sets[0])
+        report("pred_%s frame graph" % ("bi" if bi else "uni"), n_all, sum(bytes_of(d) * d["n"] for d in sets[0]) // n_all, ms, size="16x16 luma + 2 x 8x8 chroma", frames=1, launches=3,
+               note="one 1080p 4:2:0 frame = 3 launches captured in one HIP graph, %d replays back to back; %.0f frames/s" % (reps, 1e3 / ms))
+        del sets, graphs
+        torch.cuda.empty_cache()
+
+
 def bench_transform(coeffs_per_launch=1 << 26, only=None):
     for tr, lg in wl.TRANSFORMS:
         if only and (tr, lg) not in only:
@@ -153,6 +226,26 @@ def bench_me():
     ms2 = timed(frame, reps=3)
     print(json.dumps(dict(kernel="me_full_search frame total, bottom row on a second stream", ms=round(ms2, 3), ctus=total_blocks,
                           frames_per_s=round(1e3 / ms2, 1), gsad_evals_per_s=round(total_sads / ms2 / 1e6, 2))), flush=True)
+
+
+def bench_me_frame(reps=5):
+    """Config #5 through the frame-rows entry point: the whole 3840x2160 frame (33 rows of 64x64 CTUs + one of 64x48) in ONE launch."""
+    from hevcasm_amd import me_frame
+    fw, fh, ctu, r = 3840, 2160, 64, 64
+    frames = [me_frame.synthetic_frame_pair(fw, fh, r, seed=900 + i) for i in range(2)]
+    devs = [(B.u8(f["cur"]), B.u8(f["ref"])) for f in frames]
+    f0 = frames[0]
+    rows, cols = -(-fh // ctu), -(-fw // ctu)
+    out = torch.empty((rows * cols, 3), dtype=torch.int32, device="cuda")
+    ms = timed(lambda i: B.me_full_search_frame_rows(devs[i % 2][0], 0, f0["stride_cur"], devs[i % 2][1], r * f0["stride_ref"] + r, f0["stride_ref"], fw, fh, ctu, r, 0, rows, out=out), reps=reps)
+    heights = [min(ctu, fh - k * ctu) for k in range(rows)]
+    side = (2 * r + 1) ** 2
+    res = dict(ms=ms, ctus=rows * cols, sad_evals=rows * cols * side, byte_diffs=sum(cols * ctu * h for h in heights) * side,
+               bytes=sum(cols * (ctu * h + (ctu + 2 * r) * (h + 2 * r) + 12) for h in heights))
+    if SINK is None:
+        print(json.dumps(dict(kernel="me_full_search_frame_rows, whole 4K frame in one launch", ms=round(ms, 4), ctus=res["ctus"], frames_per_s=round(1e3 / ms, 1),
+                              gsad_evals_per_s=round(res["sad_evals"] / ms / 1e6, 2), tera_byte_diffs_per_s=round(res["byte_diffs"] / ms / 1e9, 2))), flush=True)
+    return res
 
 
 def bench_satd():
@@ -246,4 +339,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, ssdlin=bench_ssd_linear)[w]()
