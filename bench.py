@@ -543,7 +543,7 @@ def bench_me5(args, rank, world, device):
         # one process per core -- and the same CTUs checked against the GPU's table
         cpu = None
         if args.cpu_seconds > 0:
-            cpu = me_cpu_baseline(frames0, table, ctu, R, args.cpu_seconds, args.cpu_procs)
+            cpu = me_cpu_baseline(frames0, table, ctu, R, min(args.cpu_seconds, 12.0), args.cpu_procs)
         value = n_ctus * args.steps / elapsed / 1e6
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
@@ -569,33 +569,36 @@ def bench_me5(args, rank, world, device):
 
 
 def me_cpu_baseline(frame, gpu_table, ctu, R, budget_s, max_procs):
+    """The reference's own hevcasm_sad (C path) composed per candidate, one refdrv process per core: process k searches CTUs
+    k, k + P, k + 2P ... of the frame for its share of `budget_s`, each CTU handed over as a cut-out holding its window;
+    every CTU searched is also compared with the GPU's answer."""
     from concurrent.futures import ThreadPoolExecutor
-    from hevcasm_amd import me_frame
     from oracle import pyref
     if not pyref.available():
         return None
     procs_n, cores_info = host_cores(max_procs)
-    fw, fh = frame["w"], frame["h"]
+    fw, fh, pad = frame["w"], frame["h"], frame["pad"]
     rows, cols = -(-fh // ctu), -(-fw // ctu)
-    # a spread of CTUs over the frame (incl. the first, the seam rows and the 64x48 bottom row), a few per process
-    per_proc = 2
-    picks = np.unique(np.concatenate([np.linspace(0, rows * cols - 1, procs_n * per_proc).astype(np.int64), [rows * cols - 1, (rows - 1) * cols]]))
-    # refdrv takes whole planes through a pipe: hand every process a cut-out that holds its CTUs' windows, not the 4K frame
+    cur2, ref2 = frame["cur"].reshape(fh, -1), frame["ref"].reshape(fh + 2 * pad, -1)
+    last_row = (rows - 1) * cols
+
     def worker(k):
-        mine = picks[k::procs_n]
+        order = [last_row + k % cols] + list(range(k, rows * cols, procs_n))       # one CTU of the short bottom row first, then a stride over the frame
         t, out = 0.0, []
         with pyref.RefProc() as p:
-            for idx in mine:
+            for idx in order:
                 r, c = divmod(int(idx), cols)
                 h = min(ctu, fh - r * ctu)
                 y0, x0 = r * ctu, c * ctu
-                cur = frame["cur"].reshape(fh, -1)[y0:y0 + h, x0:x0 + ctu].copy()
-                ref = frame["ref"].reshape(fh + 2 * frame["pad"], -1)[y0 + frame["pad"] - R: y0 + frame["pad"] + h + R, x0 + frame["pad"] - R: x0 + frame["pad"] + ctu + R].copy()
+                cur = cur2[y0:y0 + h, x0:x0 + ctu].copy()
+                ref = ref2[y0 + pad - R: y0 + pad + h + R, x0 + pad - R: x0 + pad + ctu + R].copy()
                 t0 = time.perf_counter()
                 res = p.me_full_search(cur.reshape(-1), ctu, ref.reshape(-1), ctu + 2 * R, np.array([0], dtype=np.uint32),
                                        np.array([R * (ctu + 2 * R) + R], dtype=np.uint32), ctu, h, R)
                 t += time.perf_counter() - t0
                 out.append((int(idx), res[0]))
+                if t > budget_s:
+                    break
         return t, out
 
     with ThreadPoolExecutor(procs_n) as ex:
@@ -605,8 +608,8 @@ def me_cpu_baseline(frame, gpu_table, ctu, R, budget_s, max_procs):
     bad = [idx for _, o in res for idx, r in o if not np.array_equal(r, gpu_table[idx])]
     return dict(value=round(rate / 1e6, 6), unit="Mblocks/s", cores=procs_n, kind="reference", ctus_per_s=round(rate, 2),
                 gsad_evals_per_s=round(rate * (2 * R + 1) ** 2 / 1e9, 4),
-                sample="reference hevcasm_sad (C path, gcc -O3, via oracle/_ref/refdrv) composed per candidate over +-%d: %d CTUs spread over the frame, "
-                       "%d processes" % (R, n, procs_n),
+                sample="reference hevcasm_sad (C path, gcc -O3, via oracle/_ref/refdrv) composed per candidate over +-%d: %d CTUs of the frame (a stride over "
+                       "all rows incl. the 64x48 bottom row), %d processes, up to %.0f s each" % (R, n, procs_n, budget_s),
                 checked_against_gpu=dict(ctus=n, mismatches=len(bad)), **cores_info)
 
 

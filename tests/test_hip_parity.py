@@ -59,8 +59,8 @@ def test_sad_full_size_properties():
 @pytest.mark.parametrize("w,h", [(64, 64), (48, 64), (32, 32), (64, 16), (16, 64), (8, 8)])
 def test_sad4_full_size_on_the_bench_geometry(w, h):
     """The kernels bench.py's step is dominated by, at the shape bench.py times them: 1 Mi blocks per size on 1920x1152
-    frames (reference stride 1952), built by bench.py's own SizeBatch -- 64x64 and 48x64 as two launches of 524 288
-    blocks each (the 4 GiB offset window), the window kernel for the 64-/48-wide ones.  Per launch: the 4-way result
+    frames (reference stride 1952), built by bench.py's own SizeBatch -- 64x64 as two launches of 524 288 blocks each
+    (the 4 GiB offset window), the window kernel for the 64-/48-wide ones.  Per launch: the 4-way result
     equals four single-reference launches; SAD of the source against itself is 0; the blocks of the LAST frame (largest
     offsets) equal the oracle on a host copy of that frame alone."""
     import torch
@@ -68,7 +68,7 @@ def test_sad4_full_size_on_the_bench_geometry(w, h):
     from hevcasm_amd import batch as B, workload as wl
     from oracle import pyoracle
     sb = bench.SizeBatch(w, h, 1 << 20, 4711 + w + h, torch.device("cuda", 0))
-    assert len(sb.chunks) == (2 if w * h >= 48 * 64 else 1)
+    assert len(sb.chunks) == (2 if (w, h) == (64, 64) else 1)
     per_frame = (wl.FRAME_W // w) * (wl.FRAME_H // h)
     for c in sb.chunks:
         n = c["n"]
