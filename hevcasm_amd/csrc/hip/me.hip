@@ -23,7 +23,8 @@ namespace hevc {
 // one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
 struct MeFrame { int cols, ctu, frame_w, slab_h; };
 
-template <bool FRAME>
+// W64: every block of the launch is 64 wide (the common case: CTUs) -- the row loops then have constant trip counts and unroll.
+template <bool FRAME, bool W64>
 __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	if (FRAME)
 	{
 		const int row = (int)blk / fr.cols, col = (int)blk - row * fr.cols;
-		W = min(fr.ctu, fr.frame_w - col * fr.ctu);
+		W = W64 ? 64 : min(fr.ctu, fr.frame_w - col * fr.ctu);
 		H = min(fr.ctu, fr.slab_h - row * fr.ctu);
 		sp = src + (ptrdiff_t)row * fr.ctu * stride_src + col * fr.ctu;
 		rp0 = ref + (ptrdiff_t)row * fr.ctu * stride_ref + col * fr.ctu;
@@ -54,7 +55,8 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	uint8_t *s_win = lds;                                                  // (H + 2R) rows of win_stride bytes
 	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds + (size_t)win_stride * (H + 2 * R));   // H rows of W / 4 dwords
 	unsigned long long *best_of_wave = reinterpret_cast<unsigned long long *>(lds);          // reused after the search
-	const int wd = W / 4;
+	if (W64) W = 64;
+	const int wd = W64 ? 16 : W / 4;
 	const int win_w = W + 2 * R, win_h = H + 2 * R;
 
 	for (int i = threadIdx.x; i < wd * H; i += kThreads)
@@ -79,9 +81,23 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 
 	const int side = 2 * R + 1;
 	unsigned long long best = ~0ull;
-	for (int item = threadIdx.x; item < side * n_groups; item += kThreads)
+	// Work items.  A FULL item = (dy, 16 consecutive dx): 16 v_qsad per 16 source bytes, the window bytes shared by the item's
+	// four quads of candidates.  A QUARTER item = (dy, 4 consecutive dx): one v_qsad per source dword.  side = 2R + 1 is odd,
+	// so a row of candidates is nfg full groups and a remainder (+-64: 8 groups and ONE candidate, dx = +64); dealing
+	// ceil(side / 16) full items per row -- as this kernel did until round 3 -- spends a ninth of the work on candidates
+	// outside the window, and side * 9 = 1161 items over 256 threads is 5 rounds of which the last is 13 % full.  Instead:
+	// the side * nfg full items are dealt in whole rounds of 256; what is left over (1032 - 4 * 256 = 8 items) is cut into
+	// quarters and joins the remainder columns (129 quarter items) in ONE short round: 4.25 rounds instead of 5, and no lane
+	// ever scores more than 3 candidates outside the window.
+	const int nfg = side >> 4;                                 // full groups per candidate row
+	const int rem_q = ((side & 15) + 3) >> 2;                  // quarter groups that hold a row's remaining candidates
+	const int full_items = side * nfg;
+	const int whole = full_items & ~(kThreads - 1);            // dealt as full items
+	const int quarters = 4 * (full_items - whole) + side * rem_q;
+	(void)n_groups;
+	for (int item = threadIdx.x; item < whole; item += kThreads)
 	{
-		const int cy = item / n_groups, g = item - cy * n_groups;   // candidates (cy, 16 g .. 16 g + 15)
+		const int cy = item / nfg, g = item - cy * nfg;   // candidates (cy, 16 g .. 16 g + 15)
 		uint32_t acc[16];
 #pragma unroll
 		for (int k = 0; k < 16; ++k) acc[k] = 0;
@@ -136,10 +152,52 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 #pragma unroll
 		for (int k = 0; k < 16; ++k)
 		{
-			const int cx = 16 * g + k;
-			if (cx < side)
+			const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + 16 * g + k);      // every candidate of a full group is inside the window
+			best = key < best ? key : best;
+		}
+	}
+	for (int qi = threadIdx.x; qi < quarters; qi += kThreads)
+	{
+		int cy, cx0;       // candidates (cy, cx0 .. cx0 + 3)
+		if (qi < 4 * (full_items - whole))
+		{
+			const int item = whole + (qi >> 2);
+			cy = item / nfg;
+			cx0 = 16 * (item - cy * nfg) + 4 * (qi & 3);
+		}
+		else
+		{
+			const int k = qi - 4 * (full_items - whole);
+			cy = k / rem_q;
+			cx0 = 16 * nfg + 4 * (k - cy * rem_q);
+		}
+		uint32_t acc[4] = { 0, 0, 0, 0 };
+		for (int y0 = 0; y0 < H; y0 += 4)
+		{
+			unsigned long long pk = 0;
+			for (int y = y0; y < y0 + 4; ++y)
 			{
-				const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + cx);
+				const uint32_t *wrow = reinterpret_cast<const uint32_t *>(s_win + (y + cy) * win_stride + cx0);
+				const uint32_t *srow = s_src + y * wd;
+				uint32_t lo = wrow[0];
+				for (int j = 0; j < wd; ++j)
+				{
+					const uint32_t hi = wrow[j + 1];
+					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, srow[j], pk);
+					lo = hi;
+				}
+			}
+			acc[0] += (uint32_t)(pk & 0xffff);
+			acc[1] += (uint32_t)((pk >> 16) & 0xffff);
+			acc[2] += (uint32_t)((pk >> 32) & 0xffff);
+			acc[3] += (uint32_t)(pk >> 48);
+		}
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			if (cx0 + k < side)
+			{
+				const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + cx0 + k);
 				best = key < best ? key : best;
 			}
 		}
@@ -194,8 +252,12 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	int win_stride, n_groups;
 	const size_t shmem = me_lds_bytes(W, H, range, &win_stride, &n_groups);
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	hipLaunchKernelGGL(me_full_search_kernel<false>, dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-			src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
+	if (W == 64)
+		hipLaunchKernelGGL((me_full_search_kernel<false, true>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
+				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
+	else
+		hipLaunchKernelGGL((me_full_search_kernel<false, false>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
+				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
 	return launch_status("me_full_search_kernel");
 }
 
@@ -216,7 +278,11 @@ extern "C" int hevcasm_hip_me_full_search_frame_rows(
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
 	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
 	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu };
-	hipLaunchKernelGGL(me_full_search_kernel<true>, dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
-			cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
+	if (ctu == 64 && frame_w % 64 == 0)
+		hipLaunchKernelGGL((me_full_search_kernel<true, true>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
+				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
+	else
+		hipLaunchKernelGGL((me_full_search_kernel<true, false>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
+				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
 	return launch_status("me_full_search_kernel<frame>");
 }
