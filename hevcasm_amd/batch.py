@@ -87,6 +87,22 @@ def pred_bi(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off
     return dst
 
 
+def pred_uni_2planes(dst_a, dst_b, stride_dst, ref_a, ref_b, stride_ref, dst_off, ref_off, frac, taps, w, h):
+    """Cb and Cr (one PU list, two planes) in one launch."""
+    check(lib().hevcasm_hip_pred_uni_8to8_batch_2planes(dst_a.data_ptr(), dst_b.data_ptr(), stride_dst, ref_a.data_ptr(), ref_b.data_ptr(), stride_ref,
+                                                        dst_off.data_ptr(), ref_off.data_ptr(), frac.data_ptr(), taps, w, h, dst_off.numel(), _stream()),
+          "pred_uni_8to8_batch_2planes")
+    return dst_a, dst_b
+
+
+def pred_bi_2planes(dst_a, dst_b, stride_dst, ref0_a, ref0_b, ref1_a, ref1_b, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, taps, w, h):
+    check(lib().hevcasm_hip_pred_bi_8to8_batch_2planes(dst_a.data_ptr(), dst_b.data_ptr(), stride_dst, ref0_a.data_ptr(), ref0_b.data_ptr(),
+                                                       ref1_a.data_ptr(), ref1_b.data_ptr(), stride_ref, dst_off.data_ptr(), ref0_off.data_ptr(),
+                                                       ref1_off.data_ptr(), frac0.data_ptr(), frac1.data_ptr(), taps, w, h, dst_off.numel(), _stream()),
+          "pred_bi_8to8_batch_2planes")
+    return dst_a, dst_b
+
+
 def inverse_transform_add(dst, stride_dst, pred, stride_pred, dst_off, pred_off, coeffs, tr_type, log2n):
     n = dst_off.numel()
     check(lib().hevcasm_hip_inverse_transform_add_batch(dst.data_ptr(), stride_dst, pred.data_ptr(), stride_pred, dst_off.data_ptr(),

@@ -294,8 +294,17 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
-	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments)
+	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments,
+	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
 {
+	// gridDim.y = 2: the same PU list on a second set of planes (Cb and Cr share motion vectors and geometry); the second
+	// set is given as byte distances from the first (blockIdx.y is wave-uniform: scalar adds)
+	if (blockIdx.y)
+	{
+		dst += plane2_dst;
+		ref0 += plane2_ref0;
+		ref1 += plane2_ref1;
+	}
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
 	constexpr int CPL = 4 * NDW;            // window / output columns per lane
@@ -528,10 +537,14 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	}
 }
 
+// a second set of planes for the same PU list (null dst = none), as byte distances from the first set
+struct Planes2 { int count; ptrdiff_t dst, ref0, ref1; };
+static ptrdiff_t plane_distance(const void *b, const void *a) { return (ptrdiff_t)(reinterpret_cast<uintptr_t>(b) - reinterpret_cast<uintptr_t>(a)); }   // (separate allocations: integer arithmetic on the flat addresses)
+
 template <int TAPS, int NDW, bool BI>
 static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
 		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
-		int W, int H, size_t n, hipStream_t st)
+		int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
 {
 	const int lw = (W + TAPS - 1 + 4 * NDW - 1) / (4 * NDW);   // lanes per PU: one per 4*NDW window columns
 	const int ppw = kWave / lw;
@@ -540,39 +553,39 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	// of tall PUs are split into row segments of >= 2 T rows (the T-1 extra window rows per segment are loads only).
 	// 64 frames of 1080p per launch, same box, ms: uni 8-tap 64x64 0.0955 -> 0.0847, bi 64x64 0.162 -> 0.1445, bi 32x32
 	// 0.188 -> 0.170, bi 16x64 0.209 -> 0.192; nothing slower (profiles/r01_pred_segments_ab.txt).
-	size_t waves = ceil_div(n, (size_t)ppw);
+	size_t waves = ceil_div(n, (size_t)ppw) * (size_t)p2.count;     // (the launch's waves: what the segment heuristic looks at)
 	int log2_segments = 0;
 	while (log2_segments < 2 && waves < 16384 && H % (2 << log2_segments) == 0 && (H >> (log2_segments + 1)) >= 2 * TAPS)
 	{
 		++log2_segments;
 		waves *= 2;
 	}
-	const uint32_t grid = ceil_div(waves, (size_t)(kThreads / kWave));
+	const uint32_t grid = ceil_div(waves / (size_t)p2.count, (size_t)(kThreads / kWave));
 	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
 	static const bool no_fast = getenv("HEVCASM_PRED_NOFAST") != nullptr;   // A/B switch for the measurements in profiles/
 	if (NDW == 1 && W < 4)   // a zero-xFrac window is narrower than the 4-byte lane load: those lanes load byte by byte
-		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1, false>), dim3(grid), dim3(kThreads), 0, st,
-				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1, false>), dim3(grid, p2.count), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
 	else if (W % 4 == 0 && (H >> log2_segments) % TAPS == 0 && !no_fast)
-		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, true>), dim3(grid), dim3(kThreads), 0, st,
-				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, true>), dim3(grid, p2.count), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
 	else
-		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, false>), dim3(grid), dim3(kThreads), 0, st,
-				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments);
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, false>), dim3(grid, p2.count), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
 	return launch_status("pred_stream_kernel");
 }
 
 template <int TAPS, bool BI>
 static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
 		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
-		int W, int H, size_t n, hipStream_t st)
+		int W, int H, size_t n, hipStream_t st, const Planes2 &p2 = Planes2{ 1, 0, 0, 0 })
 {
 	// 8 bytes per lane per row halves the load instructions (the texture-address unit handles 4 lanes
 	// per cycle whatever their width); PUs narrower than 8 keep 4 bytes so that no lane is half idle.
 	// The window must hold at least one full lane load: W + T - 1 >= 8 for the wide variant.
 	// (4 bytes per lane for bi-prediction, 95 VGPRs, was measured too: 10 % slower at 16x16, equal at 64x64.)
-	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
-	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st);
+	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
+	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 }
 
 static int check_pred_args(int taps, int W, int H, size_t n)
@@ -624,4 +637,40 @@ extern "C" int hevcasm_hip_pred_bi_8to8_batch(
 	return taps == 8
 		? launch_pred<8, true>(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, nPbW, nPbH, n_blocks, st)
 		: launch_pred<4, true>(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, nPbW, nPbH, n_blocks, st);
+}
+
+// Two planes with one PU list (Cb and Cr: same motion vectors, same geometry): one launch, gridDim.y = 2.
+extern "C" int hevcasm_hip_pred_uni_8to8_batch_2planes(
+	uint8_t *dst_a, uint8_t *dst_b, ptrdiff_t stride_dst, const uint8_t *ref_a, const uint8_t *ref_b, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (int e = check_pred_args(taps, nPbW, nPbH, n_blocks)) return e;
+	if (n_blocks == 0) return 0;
+	if (!dst_a || !dst_b || !ref_a || !ref_b || !dst_off || !ref_off || !frac) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t st = as_stream(stream);
+	const Planes2 p2 = { 2, plane_distance(dst_b, dst_a), plane_distance(ref_b, ref_a), plane_distance(ref_b, ref_a) };
+	return taps == 8
+		? launch_pred<8, false>(dst_a, stride_dst, ref_a, ref_a, stride_ref, dst_off, ref_off, ref_off, frac, frac, nPbW, nPbH, n_blocks, st, p2)
+		: launch_pred<4, false>(dst_a, stride_dst, ref_a, ref_a, stride_ref, dst_off, ref_off, ref_off, frac, frac, nPbW, nPbH, n_blocks, st, p2);
+}
+
+extern "C" int hevcasm_hip_pred_bi_8to8_batch_2planes(
+	uint8_t *dst_a, uint8_t *dst_b, ptrdiff_t stride_dst,
+	const uint8_t *ref0_a, const uint8_t *ref0_b, const uint8_t *ref1_a, const uint8_t *ref1_b, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
+	const uint8_t *frac0, const uint8_t *frac1,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (int e = check_pred_args(taps, nPbW, nPbH, n_blocks)) return e;
+	if (n_blocks == 0) return 0;
+	if (!dst_a || !dst_b || !ref0_a || !ref0_b || !ref1_a || !ref1_b || !dst_off || !ref0_off || !ref1_off || !frac0 || !frac1)
+		return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t st = as_stream(stream);
+	const Planes2 p2 = { 2, plane_distance(dst_b, dst_a), plane_distance(ref0_b, ref0_a), plane_distance(ref1_b, ref1_a) };
+	return taps == 8
+		? launch_pred<8, true>(dst_a, stride_dst, ref0_a, ref1_a, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, nPbW, nPbH, n_blocks, st, p2)
+		: launch_pred<4, true>(dst_a, stride_dst, ref0_a, ref1_a, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, nPbW, nPbH, n_blocks, st, p2);
 }

@@ -193,6 +193,21 @@ int hevcasm_hip_quantize_reconstruct_batch(
 	const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res,
 	int nCbS, size_t n_blocks, void *stream);
 
+/* The same two calls for TWO planes that share one PU list -- Cb and Cr of a 4:2:0 frame: same geometry, same motion
+ * vectors, same fractions -- in one launch: plane a and plane b of the destination and of each reference have the same
+ * stride and take the same offsets.  Results are exactly those of two single-plane calls; a frame's chroma launches are
+ * short (a 1080p plane of 8x8 PUs is ~10 us), so halving their number is worth having. */
+int hevcasm_hip_pred_uni_8to8_batch_2planes(
+	uint8_t *dst_a, uint8_t *dst_b, ptrdiff_t stride_dst, const uint8_t *ref_a, const uint8_t *ref_b, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
+int hevcasm_hip_pred_bi_8to8_batch_2planes(
+	uint8_t *dst_a, uint8_t *dst_b, ptrdiff_t stride_dst,
+	const uint8_t *ref0_a, const uint8_t *ref0_b, const uint8_t *ref1_a, const uint8_t *ref1_b, ptrdiff_t stride_ref,
+	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off,
+	const uint8_t *frac0, const uint8_t *frac1,
+	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
+
 /* ---- full-search motion estimation (composition of hevcasm_sad) -- */
 
 /* For each block: SAD at every displacement (dx, dy) in [-range, range]^2 around

@@ -170,6 +170,47 @@ def test_pred_full_size_properties():
         assert np.array_equal(cases._dst_rows(got, c["stride_dst"], c["dst_off"][a:], w, h), cases._dst_rows(want, c["stride_dst"], c["dst_off"][a:], w, h))
 
 
+def test_pred_two_planes_equal_two_single_plane_calls():
+    """Cb and Cr in one launch (hevcasm_hip_pred_*_batch_2planes: one PU list, two planes of the destination and of each
+    reference) give exactly the bytes of two single-plane calls, which the cases above compare with the oracle; plane a
+    also goes against the oracle directly.  Every chroma PU size (incl. the 2- and 6-wide ones), luma for good measure,
+    a launch small enough to be cut into row segments, and planes at odd distances from each other."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    todo = [(4, w // 2, h // 2, 40) for (w, h) in wl.PU_SIZES] + [(8, 16, 16, 50), (8, 64, 64, 8), (8, 4, 8, 33)]
+    for taps, w, h, n in todo:
+        for bi in (False, True):
+            if bi and (w, h) in ((4, 2), (2, 4)):
+                continue
+            ca = wl.pred_case(taps, w, h, n, 1300 + w + 7 * h, bi=bi)
+            cb = wl.pred_case(taps, w, h, n, 2300 + w + 7 * h, bi=bi)      # same geometry (offsets depend on the seed only through the motion vectors: use ca's)
+            pad = 3                                                        # plane b starts 3 bytes into its buffer: plane distances are not multiples of anything
+            def dev(x, shift=0):
+                t = torch.zeros(x.size + 8, dtype=torch.uint8, device="cuda")
+                t[shift:shift + x.size] = torch.from_numpy(x).cuda()
+                return t[shift:shift + x.size]
+            ra0, rb0 = dev(ca["ref0"]), dev(cb["ref0"], pad)
+            doff, r0off, f0 = B.off32(ca["dst_off"]), B.off32(ca["ref0_off"]), B.u8(ca["frac0"])
+            da, db = torch.zeros(ca["dst_bytes"], dtype=torch.uint8, device="cuda"), torch.zeros(ca["dst_bytes"] + 8, dtype=torch.uint8, device="cuda")[5:5 + ca["dst_bytes"]]
+            wa, wb = torch.zeros_like(da), torch.zeros(ca["dst_bytes"], dtype=torch.uint8, device="cuda")
+            if bi:
+                ra1, rb1 = dev(ca["ref1"]), dev(cb["ref1"], 1)
+                r1off, f1 = B.off32(ca["ref1_off"]), B.u8(ca["frac1"])
+                B.pred_bi_2planes(da, db, ca["stride_dst"], ra0, rb0, ra1, rb1, ca["stride_ref"], doff, r0off, r1off, f0, f1, taps, w, h)
+                B.pred_bi(wa, ca["stride_dst"], ra0, ra1, ca["stride_ref"], doff, r0off, r1off, f0, f1, taps, w, h)
+                B.pred_bi(wb, ca["stride_dst"], rb0, rb1, ca["stride_ref"], doff, r0off, r1off, f0, f1, taps, w, h)
+                want = pyoracle.pred_bi_batch(taps, ca["dst_bytes"], ca["stride_dst"], ca["ref0"], ca["ref1"], ca["stride_ref"], ca["dst_off"], ca["ref0_off"], ca["ref1_off"], ca["frac0"], ca["frac1"], w, h)
+            else:
+                B.pred_uni_2planes(da, db, ca["stride_dst"], ra0, rb0, ca["stride_ref"], doff, r0off, f0, taps, w, h)
+                B.pred_uni(wa, ca["stride_dst"], ra0, ca["stride_ref"], doff, r0off, f0, taps, w, h)
+                B.pred_uni(wb, ca["stride_dst"], rb0, ca["stride_ref"], doff, r0off, f0, taps, w, h)
+                want = pyoracle.pred_uni_batch(taps, ca["dst_bytes"], ca["stride_dst"], ca["ref0"], ca["stride_ref"], ca["dst_off"], ca["ref0_off"], ca["frac0"], w, h)
+            torch.cuda.synchronize()
+            assert torch.equal(da, wa) and torch.equal(db, wb), (taps, w, h, bi)
+            assert np.array_equal(cases._dst_rows(da.cpu().numpy(), ca["stride_dst"], ca["dst_off"], w, h), cases._dst_rows(want, ca["stride_dst"], ca["dst_off"], w, h)), (taps, w, h, bi)
+
+
 def test_full_search_finds_planted_block():
     """Config #5 geometry (64x64 CTUs, +-64) on a frame whose search windows overlap as they do in a
     real frame: a CTU copied into its own window at a known displacement is found with cost 0 at the

@@ -35,7 +35,7 @@ def report(name, n, bytes_per_block, ms, **kw):
         print(json.dumps(row), flush=True)
 
 
-def bench_pred(frames=64, only=None):
+def bench_pred(frames=64, only=None, two_planes=True):
     """Config #3: 1920x1080 luma tiled by each PU size (chroma planes 960x540, 4-tap), all phases,
     `frames` frames per launch so that the launch is far above the launch floor."""
     for taps, fw, fh in ((8, 1920, 1080), (4, 960, 540)):
@@ -65,7 +65,22 @@ def bench_pred(frames=64, only=None):
                         B.pred_uni(d["dst"], c0["stride_dst"], d["ref0"], c0["stride_ref"], d["dst_off"], d["ref0_off"], d["frac0"], taps, pw, ph)
                 ms = timed(run, reps=4)
                 refs = 2 if bi else 1
-                report("pred_%s_%dtap" % ("bi" if bi else "uni", taps), n, refs * (pw + taps - 1) * (ph + taps - 1) + pw * ph + 4 * (1 + refs) + refs, ms, size="%dx%d" % (pw, ph), frames=frames)
+                bytes_per_pu = refs * (pw + taps - 1) * (ph + taps - 1) + pw * ph + 4 * (1 + refs) + refs
+                report("pred_%s_%dtap" % ("bi" if bi else "uni", taps), n, bytes_per_pu, ms, size="%dx%d" % (pw, ph), frames=frames)
+                if taps == 4 and two_planes:
+                    # Cb and Cr of the same frames in ONE launch (same PU list and motion vectors, hevcasm_hip_pred_*_batch_2planes): 2 n PUs;
+                    # the descriptors are read once per plane, so the bytes per PU are the same
+                    second = [dict(dst=torch.zeros_like(d["dst"]), **{k: wl.fill_u8(d[k].numel(), 900 + i, device="cuda") for k in d if k in ("ref0", "ref1")}) for i, d in enumerate(devs)]
+
+                    def run2(i):
+                        d, e = devs[i % len(devs)], second[i % len(devs)]
+                        if bi:
+                            B.pred_bi_2planes(d["dst"], e["dst"], c0["stride_dst"], d["ref0"], e["ref0"], d["ref1"], e["ref1"], c0["stride_ref"], d["dst_off"], d["ref0_off"], d["ref1_off"], d["frac0"], d["frac1"], taps, pw, ph)
+                        else:
+                            B.pred_uni_2planes(d["dst"], e["dst"], c0["stride_dst"], d["ref0"], e["ref0"], c0["stride_ref"], d["dst_off"], d["ref0_off"], d["frac0"], taps, pw, ph)
+                    ms2 = timed(run2, reps=4)
+                    report("pred_%s_%dtap Cb+Cr" % ("bi" if bi else "uni", taps), 2 * n, bytes_per_pu, ms2, size="%dx%d" % (pw, ph), frames=frames)
+                    del second
                 del cs, devs
                 torch.cuda.empty_cache()
 
