@@ -304,9 +304,10 @@ __device__ __forceinline__ void block_cost_sums(
 	// 8-byte chunks (16-, 24-, 40-, 56-wide): overlapping aligned loads, see OverlapRefChunk.  Same-box A/B, ms per 1 Mi
 	// blocks (profiles/r01_sad_overlap_ab.txt): 4-way 16x64 0.75 -> 0.59, 16x32 0.38 -> 0.29, 16x16 0.192 -> 0.170,
 	// 24x32 0.59 -> 0.46; one reference 16x64 0.43 -> 0.41, shorter blocks unchanged.
-	// Measured and not adopted: 48-wide as 4 x 16 bytes at 12-byte pitch (1.38 -> 1.48: worse than dwordx3 + tail),
-	// 24-wide as 2 x 12-byte chunks with 16-byte loads (0.47, no better than 3 x 8), 4-way 32-wide as 4 x 8-byte chunks
-	// (fewer L1 accesses but twice the lane loads: 32x32 0.58 -> 0.62, 32x24 0.43 -> 0.55).
+	// Round 1 measured three more re-cuts as no better on the kernels of the time (48-wide as 4 x 16 bytes at 12-byte pitch, 24-wide as
+	// 2 x 12-byte chunks with 16-byte loads, 4-way 32-wide as 4 x 8-byte chunks); round 2 re-measured them on the kernels as they then
+	// stood and all three pay -- they are what Plan<24> / Plan<32> / Plan<48> below use (profiles/r02_sad_rowmajor_ab.txt: 24-wide as
+	// 2 x 12 bytes -6 ... -16 %, 4-way 32-wide as 4 x 8 bytes with 4 rows in flight -5 ... -9 %, one-reference 48-wide with aligned 16-byte loads -4 %).
 	// 4-byte chunks (12-, 20-, 28-wide ...): the same with 8-byte aligned loads -- a misaligned dword load costs the L1 four
 	// times an aligned one: 12x16 four references 0.27 -> 0.20 ms, one reference 0.125 -> 0.116
 	// (With the loads still alternating between source and reference rows, the short single-trip blocks lost 4-10 % to the
@@ -317,7 +318,7 @@ __device__ __forceinline__ void block_cost_sums(
 	// 0.078 -> 0.059 ms, 8x16 0.145 -> 0.101, 8x32 0.279 -> 0.193, one reference -2 ... -5 %.  (Deciding about close rows with a
 	// branch inside the kernel instead of a template flag made the 4-way kernels three times slower.)
 	constexpr bool OVERLAP1 = (C == 8 || C == 12) && LPR == 1 && !LOOP && !TIGHT;
-	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2 && W != 24;      // (one reference, 48-wide, aligned: +1 % -- round 2, gpurun_out/ab2_sad1_al48.txt)
+	constexpr bool ALIGNED = WAYS == 4 && C >= 12 && LPR >= 2 && W != 24;      // (one reference, 48-wide, through this path: +1 % -- round 2, profiles/r02_sad_rowmajor_ab.txt)
 	const bool last = chunk == LPR - 1;
 
 	// Source rows are read exactly once.  Where the blocks of a wave cover whole 128-byte lines of a frame row between
@@ -753,7 +754,8 @@ static bool window_stride_ok(ptrdiff_t sr, int W) { return sr >= W + 64 && sr <=
 
 template <int W> static int launch_window(const Args &a)
 {
-	const uint32_t inv = getenv("HEVCASM_SAD4_NOWINDOW") ? 0u : (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;    // (0: every block takes the generic code -- measurements only)
+	static const bool no_window = getenv("HEVCASM_SAD4_NOWINDOW") != nullptr;     // measurement switch, read once per process
+	const uint32_t inv = no_window ? 0u : (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;    // (0: every block takes the generic code)
 	const uint32_t grid = ceil_div(a.n, kThreads / kWave);
 #define WINDOW(HM) hipLaunchKernelGGL((sad4_window_kernel<W, HM>), dim3(grid), dim3(kThreads), 0, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
 	if (a.H == 16) WINDOW(16); else if (a.H == 32) WINDOW(32); else if (a.H == 48) WINDOW(48); else WINDOW(64);
@@ -766,13 +768,14 @@ template <int W, int C, int R, int U, int WAYS, int OP, bool TIGHT> static int l
 	constexpr int blocks_per_wg = Tiling<W, C, R>::BPW * (kThreads / kWave);
 	const uint32_t grid = ceil_div(a.n, blocks_per_wg);
 	// 64- and 48-wide blocks of 16 / 32 / 48 / 64 rows go through sad4_window_kernel, which decides per block: candidates close together ->
-	// union window through LDS (same-box A/B against the generic kernel below, config #2's +-7 pixels: 64x64 -2 %, 64x48 -3 %, 64x32 -4 %,
-	// 64x16 -12 %, 48x64 -6 %); far apart -> generic code, one block per wave (-12 ... +10 %).  32-wide blocks stay here: their window
-	// path measured +2 ... +21 % on close candidates (the window is 1.6x the block's width) although the far path gained 15 %
-	// (gpurun_out/ab2_sad4_w32*.txt, ab2_sad4_window6.txt, ab2_sad4_far40c.txt).
+	// union window through LDS (same-box A/B of the shipped form against the round-1 generic kernel, config #2's +-7 pixels: 64x64 -6 %,
+	// 64x48 -3 %, 64x32 -2 %, 64x16 -8 %, 48x64 -10 %: DESIGN.md section 0); far apart -> generic code, one block per wave (-10 ... +14 %).
+	// 32-wide blocks stay here: their window path measured +2 ... +21 % on close candidates (the window is 1.6x the block's width) although
+	// the far path gained 15 % (profiles/r02_sad4_window_ab.txt).
+	static const bool generic_only = getenv("HEVCASM_SAD4_GENERIC") != nullptr;    // measurement switch, read once per process
 	if constexpr (WAYS == 4 && OP == OP_SAD && (W == 64 || W == 48) && !TIGHT && U <= 6)
 	{
-		if (a.H % 16 == 0 && a.H <= 64 && window_stride_ok(a.sr, W) && !getenv("HEVCASM_SAD4_GENERIC"))
+		if (a.H % 16 == 0 && a.H <= 64 && window_stride_ok(a.sr, W) && !generic_only)
 		{
 			return launch_window<W>(a);
 		}
@@ -813,7 +816,7 @@ template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 	}
 	if constexpr (W == 12)
 	{
-		if (a.sr < 12 && a.sr > -12) return launch_rows<W, 4, 4, WAYS, OP, false>(a);     // overlapping rows: the 4-byte-chunk kernels, which load at the byte address
+		if (a.sr < 12 && a.sr > -12) return launch_rows<W, 4, 4, WAYS, OP, false>(a);     // overlapping rows: three lanes of 4 bytes per row (dword-aligned 8-byte loads that overlap between the lanes of a row, never between rows)
 		// four references, heights that are not one trip of 1 / 2 / 3 / 4 / 6 / 8 rows per lane: the aligned loads of the one-lane-per-row mapping need a
 		// single trip (they must know which row is the block's highest), and at the byte address it is 3 - 6 % slower than three lanes of 4 bytes
 		const int rpl = a.H / 4;

@@ -29,6 +29,9 @@
  *    fallback: without a usable gfx950 device every entry point fails with
  *    HEVCASM_HIP_ENODEV.  hevcasm_hip_last_error() returns text for the calling thread's last
  *    failure.
+ *  - Side effect on the HIP runtime's error state: every entry point starts by reading (and thereby CLEARING)
+ *    the calling thread's pending non-sticky HIP error (hipGetLastError), so that the status it returns is this
+ *    call's own; an application that polls hipGetLastError() for its own launches must do so before calling in.
  *  - Thread safety: entry points may be called concurrently from several host threads (use one
  *    stream per thread to overlap).
  */
@@ -69,9 +72,10 @@ int hevcasm_hip_stream_synchronize(void *stream);
 /* Batched hevcasm_sad (sad.h; reference sad.h:50, C body sad.c:47-60).
  * sad[i] = SAD(src + src_off[i], ref + ref_off[i]); width, height multiples of 4 in 4..64.
  * Memory touched: the block rows themselves, and for the reference plane at most the 4-byte-aligned words that hold
- * a byte of a block row (the kernels load reference rows word-aligned and realign in registers) -- for 8-wide blocks also
- * up to 4 bytes that lie between two rows of the same block; never anything below the lowest or above the highest
- * word that holds a byte of the block.  Nothing is written but sad[]. */
+ * a byte of a block row (the kernels load reference rows word-aligned and realign in registers) -- for 8- and 12-wide
+ * blocks (one lane per row) also up to 4 bytes past a row's end, or before the top row's start, that lie between two
+ * rows of the same block (rows at least a block width apart, |stride| >= w; closer rows take byte-exact kernels); never
+ * anything below the lowest or above the highest word that holds a byte of the block.  Nothing is written but sad[]. */
 int hevcasm_hip_sad_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *sad,
@@ -89,7 +93,11 @@ int hevcasm_hip_sad_multiref_batch(
 	uint32_t rect, size_t n_blocks, void *stream);
 
 /* Batched hevcasm_ssd (reference ssd.h:53, C body ssd.c:43-55); w, h multiples of 4 in 4..64
- * (the reference's table holds the square sizes 4..64, its C body takes any w x h). */
+ * (the reference's table holds the square sizes 4..64, its C body takes any w x h).
+ * Memory touched: as hevcasm_hip_sad_batch (the same kernel): for BOTH planes whole 4-byte-aligned words between the lowest
+ * and the highest word that hold a byte of the block -- with one lane per row (8- and 12-wide blocks) that includes up to
+ * 4 bytes past a row's end, or before the top row's start, in the gap between two rows of the block; this needs rows at
+ * least a block width apart (|stride| >= w, which the entry point checks: closer rows take byte-exact kernels). */
 int hevcasm_hip_ssd_batch(
 	const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB,
 	const uint32_t *offA, const uint32_t *offB, int *ssd,

@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_report_header(config):
+    """The library has a few measurement switches read from the environment (HEVCASM_HIP_LIB: another build of the library;
+    HEVCASM_SAD4_NOWINDOW / _GENERIC, HEVCASM_PRED_NOFAST: other kernel paths).  A stale one in the shell would silently change
+    what is tested: say so at the top of every run."""
+    stale = sorted(k for k in os.environ if k.startswith("HEVCASM_"))
+    from hevcasm_amd import capi
+    lines = ["hevcasm library under test: %s" % capi.LIB_PATH]
+    if stale:
+        lines.append("WARNING: %s set in the environment -- this run does NOT test the default configuration" % ", ".join("%s=%s" % (k, os.environ[k]) for k in stale))
+    return lines
+
+
 @pytest.fixture(scope="session")
 def refproc():
     """The reference's own C path (oracle/_ref/refdrv).  Present wherever `make -C oracle` ran with

@@ -10,7 +10,12 @@ for g in "GRBM_GUI_ACTIVE SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_
          "TCP_UTCL1_STALL_MULTI_MISS_sum TCP_UTCL1_SERIALIZATION_STALL_sum TCP_UTCL1_LFIFO_FULL_sum TCP_UTCL1_STALL_UTCL2_REQ_OUT_OF_CREDITS_sum" \
          "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_LATENCY_sum TCP_TCC_READ_REQ_LATENCY_sum"; do
   d=$O/$(echo $g | cut -d" " -f2)
-  # (a group the counter blocks cannot hold makes rocprofv3 abort and then hang: TA_TA_BUSY_sum + 3 TA_*_STALLED_* did)
+  # A group the counter blocks cannot hold makes rocprofv3 abort at the first dispatch and then hang ("error code 38: Request exceeds the capabilities of
+  # the hardware to collect": TA_TA_BUSY_sum + 3 TA_*_STALLED_* did, profiles/r02_pred_ab.txt).  The TA / TD / TCA blocks have two counter registers each
+  # (rocprofv3 --list-avail: block sizes): refuse such a group here instead of finding out from a timeout on a GPU-holding process.
+  for blk in TA_ TD_ TCA_; do
+    if [ $(echo $g | tr " " "\n" | grep -c "^$blk") -gt 2 ]; then echo "SKIPPED (more than 2 ${blk}* counters in one pass): $g"; continue 2; fi
+  done
   timeout -k 5 120 rocprofv3 --pmc $g --output-format csv -d $d -- python3 "$@" > $d.log 2>&1 || echo "FAILED $g"
   echo "done $g" >> $O/progress.txt
 done
