@@ -440,11 +440,13 @@ def measure_families():
     collect("#3, one 1080p frame", lambda r: "inter_pred_latency")
     fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32
     collect("#4, 2^26 coefficients per launch", lambda r: "idct" if "inverse" in r["kernel"] else "fdct")
+    fam.bench_transform(1 << 28, only=((0, 4), (0, 5)))       # the same kernels nearer their steady state: a 60 us launch pays 10-13 us of ramp-up and tail
+    collect("#4, 2^28 coefficients per launch", lambda r: "idct_large_launch" if "inverse" in r["kernel"] else "fdct_large_launch")
     fam.SINK = None
     me = fam.bench_me_frame()
     peak, src = qsad_peak()
     rows.append(dict(family="full_search", kernel="me_full_search 64x64 (+ 64x48 row) +-64", config="#5, one 3840x2160 frame = 2040 CTUs, one launch",
-                     ms=me["ms"], mblocks_per_s=round(me["ctus"] / me["ms"] / 1e3, 3), frames_per_s=round(1e3 / me["ms"], 1),
+                     ms=round(me["ms"], 4), mblocks_per_s=round(me["ctus"] / me["ms"] / 1e3, 3), frames_per_s=round(1e3 / me["ms"], 1),
                      gbs=round(me["bytes"] / me["ms"] / 1e6, 1), frac=round(me["bytes"] / me["ms"] / 1e6 / HBM_PEAK_GBS, 4),
                      bound="valu", gsad_evals_per_s=round(me["sad_evals"] / me["ms"] / 1e6, 2),
                      achieved=round(me["byte_diffs"] / me["ms"] / 1e9, 2), peak=round(peak, 1), unit="T byte differences/s",

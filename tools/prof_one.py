@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One family / one configuration, a few launches on cold buffers -- the target of rocprofv3 --pmc.
-usage: prof_one.py pred_uni TAPS W H | inverse LOG2 | forward LOG2 | me"""
+usage: prof_one.py pred_uni TAPS W H | pred_bi TAPS W H | inverse LOG2 | forward LOG2 | sad W H WAYS | me"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -37,5 +37,11 @@ elif kind == "sad":
             B.sad_multiref(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4, w, h)
         else:
             B.sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4.view(n, 4)[:, 0].contiguous(), w, h)
+elif kind == "me":
+    # config #5: the whole 3840x2160 frame through the frame-rows entry point, one launch per frame pair
+    from hevcasm_amd import me_frame
+    for i in range(3):
+        f = me_frame.synthetic_frame_pair(3840, 2160, 64, seed=900 + i)
+        B.me_full_search_frame_rows(B.u8(f["cur"]), 0, f["stride_cur"], B.u8(f["ref"]), 64 * f["stride_ref"] + 64, f["stride_ref"], 3840, 2160, 64, 64, 0, 34)
 torch.cuda.synchronize()
 print("done")
