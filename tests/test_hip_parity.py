@@ -292,7 +292,8 @@ def test_full_search_frame_rows_ragged_edges():
     narrower / shorter), ranges that are not multiples of 16, more ranks than CTU rows: every split equals the oracle."""
     from hevcasm_amd import batch as B, me_frame
     from oracle import pyoracle
-    for (fw, fh, ctu, r, world) in ((200, 176, 64, 24, 3), (96, 80, 32, 37, 2), (64, 48, 64, 64, 4), (128, 128, 16, 9, 5), (72, 40, 64, 16, 1)):
+    for (fw, fh, ctu, r, world) in ((200, 176, 64, 24, 3), (96, 80, 32, 37, 2), (64, 48, 64, 64, 4), (128, 128, 16, 9, 5), (72, 40, 64, 16, 1),
+                                    (16, 16, 4, 0, 2), (4, 4, 64, 3, 1), (260, 12, 64, 70, 2), (36, 300, 20, 100, 7)):
         f = me_frame.synthetic_frame_pair(fw, fh, r, seed=fw + r, ctu=ctu, max_motion=min(r, 20))
         rows, cols = -(-fh // ctu), -(-fw // ctu)
         want = np.zeros((rows * cols, 3), dtype=np.int32)
@@ -560,8 +561,20 @@ def test_error_codes_not_fallbacks():
     assert L.hevcasm_hip_quantize_batch(p, p, 51, 20, -14, 16, 1, o.data_ptr(), None) == capi.EINVAL     # not computed differently from the C body
     assert L.hevcasm_hip_pred_uni_8to8_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), p, 6, 8, 8, 1, None) == capi.EINVAL
     assert b"hevcasm_hip error" in L.hevcasm_hip_last_error()
+    # the round-3 entry points: frame-rows search (CTU size, frame dimensions, rows outside the frame, a window that does not fit LDS), two planes
+    fr = L.hevcasm_hip_me_full_search_frame_rows
+    assert fr(p, 64, p, 64, 64, 64, 10, 8, 0, 1, o.data_ptr(), None) == capi.EINVAL
+    assert fr(p, 64, p, 64, 62, 64, 16, 8, 0, 1, o.data_ptr(), None) == capi.EINVAL
+    assert fr(p, 64, p, 64, 64, 64, 16, 8, 0, 5, o.data_ptr(), None) == capi.EINVAL      # 4 CTU rows only
+    assert fr(p, 64, p, 64, 64, 64, 16, 8, 3, 2, o.data_ptr(), None) == capi.EINVAL
+    assert fr(p, 64, p, 64, 64, 64, 64, 127, 0, 1, o.data_ptr(), None) == capi.EINVAL    # (64 + 254)^2 bytes of window: not in 64 KiB
+    assert fr(p, 64, p, 64, 64, 64, 16, 8, 2, 2, o.data_ptr(), None) == 0                # an idle rank's empty range
+    assert fr(None, 64, p, 64, 64, 64, 16, 8, 0, 1, o.data_ptr(), None) == capi.EINVAL
+    assert L.hevcasm_hip_pred_uni_8to8_batch_2planes(p, None, 64, p, p, 64, o.data_ptr(), o.data_ptr(), p, 4, 8, 8, 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_pred_uni_8to8_batch_2planes(p, p, 64, p, p, 64, o.data_ptr(), o.data_ptr(), p, 4, 40, 8, 1, None) == capi.EINVAL
     # empty batches are legal no-ops
     assert L.hevcasm_hip_sad_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), capi.rect(16, 16), 0, None) == 0
+    assert L.hevcasm_hip_pred_bi_8to8_batch_2planes(p, p, 64, p, p, p, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), p, p, 8, 16, 16, 0, None) == 0
 
 
 def test_in_place_reconstruction():
