@@ -287,6 +287,11 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 
 template <bool B> struct Flag { static constexpr bool value = B; };
 
+// a second set of planes for the same PU list (null dst = none), as byte distances from the first set
+struct Planes2 { int count; ptrdiff_t dst, ref0, ref1; };
+static ptrdiff_t plane_distance(const void *b, const void *a) { return (ptrdiff_t)(reinterpret_cast<uintptr_t>(b) - reinterpret_cast<uintptr_t>(a)); }   // (separate allocations: integer arithmetic on the flat addresses)
+
+
 // FAST: W % 4 == 0 and (rows per wave) % TAPS == 0 -- the row loop then has no branch around any load or store (see the loop).
 template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW, bool FAST>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
@@ -537,9 +542,6 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	}
 }
 
-// a second set of planes for the same PU list (null dst = none), as byte distances from the first set
-struct Planes2 { int count; ptrdiff_t dst, ref0, ref1; };
-static ptrdiff_t plane_distance(const void *b, const void *a) { return (ptrdiff_t)(reinterpret_cast<uintptr_t>(b) - reinterpret_cast<uintptr_t>(a)); }   // (separate allocations: integer arithmetic on the flat addresses)
 
 template <int TAPS, int NDW, bool BI>
 static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
@@ -575,6 +577,288 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	return launch_status("pred_stream_kernel");
 }
 
+// wave-wide reductions of a 32-bit value (every lane ends up with the result)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, kWave));
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, kWave));
+	return v;
+}
+
+// ---- 4-tap (chroma) prediction, one lane per 8-column strip ------------------------------------------------------------------
+//
+// A chroma PU row is narrow: an 8-wide PU's window is 11 bytes.  pred_stream_kernel gives it two lanes of 8 bytes (the second moved
+// left to end with the window), byte-misaligned, and exchanges vertical results between the lanes by DPP; half of its lanes' horizontal
+// work produces no pixel.  Here a lane owns a STRIP of up to 8 output columns and loads the whole 11-byte window of the strip itself --
+// ONE dword-aligned 16-byte load per row (a quad of lanes = four strips: one vector-L1 access per strip row instead of two or three),
+// realigned in registers with v_alignbit -- runs the vertical pass on 12 columns and the horizontal pass on its own results: no
+// cross-lane traffic at all, every lane stores pixels, twice the PUs per wave.  The vertical pass is repeated on the 3 columns two
+// strips share, which 4 taps can afford (24 v_pk_mad_u16 per row against 16) and 8 taps cannot (round 2 measured that form of the luma
+// kernel 6-31 % slower).  Any W (strips of 8, the last one narrower) and any H.
+// Footprint: whole 4-byte-aligned words, never below the lowest nor above the highest word that holds a byte of the windows of the PUs
+// of ONE wave (at most 64 consecutive PUs of the batch): a load that would pass that word is moved left and the bytes are picked from
+// further up the 16 (the wave's span is at least 16 bytes: the launcher sends H < 2 or |stride| < 16 to pred_stream_kernel).
+// v_cndmask_b32 on two register values
+__device__ __forceinline__ uint32_t pick(bool c, uint32_t a, uint32_t b)
+{
+	uint32_t r;
+	asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(__builtin_amdgcn_ballot_w64(c)));
+	return r;
+}
+
+// one reference's state of a strip lane (pred_strip4_kernel): window slots, the rows in flight, the row stream
+template <int AHEAD> struct StripStream4
+{
+	static constexpr int TAPS = 4;
+	uint32_t e[TAPS][3], o[TAPS][3];     // window slots: even / odd columns of the strip's 12 window columns as int16 pairs
+	uint32_t pending[AHEAD][4];          // rows in flight: the 16 aligned bytes
+	uint32_t where[AHEAD];               // ... and where in them the strip's first byte is (0 .. 15)
+	const uint8_t *plane;
+	uint32_t off, lo, hi;                // byte offset of the strip's window in the next row to load; row clamp of a yFrac == 0 stream
+	uint32_t last_load;                  // the highest offset a 16-byte load may start at
+	Coefs<4> c;
+
+	// load the next window row into ring slot `slot` (registers untouched until take(): the wave must not wait here)
+	__device__ __forceinline__ void issue(int slot, uint32_t step)
+	{
+		const uint32_t a = min(off & ~3u, last_load);
+		where[slot] = off - a;
+		const u32x4 v = *reinterpret_cast<const u32x4 *>(plane + (size_t)a);      // dword-aligned
+		pending[slot][0] = v.x; pending[slot][1] = v.y; pending[slot][2] = v.z; pending[slot][3] = v.w;
+		off = med3_u32(off + step, lo, hi);
+	}
+	// ring slot `slot` -> window slot `into`: pick the strip's 12 bytes out of the 16, unpack to int16 pairs
+	__device__ __forceinline__ void take(int slot, int into)
+	{
+		// the strip's bytes start `at` (0 .. 15) bytes into the 16: 0 .. 3 unless the load was moved left, further up the narrower the strip.
+		// (Selects on VALUES held in registers: written as selects between array elements the compiler turns them into one load with a
+		// per-lane index -- the ring in scratch memory, 3-5 x slower.)
+		const uint32_t at = where[slot], sh = 8u * (at & 3u);
+		const uint32_t d0 = pending[slot][0], d1 = pending[slot][1], d2 = pending[slot][2], d3 = pending[slot][3];
+		const uint32_t x0 = pick(at >= 12u, d3, pick(at >= 8u, d2, pick(at >= 4u, d1, d0)));
+		const uint32_t x1 = pick(at >= 8u, d3, pick(at >= 4u, d2, d1));
+		const uint32_t x2 = pick(at >= 4u, d3, d2);
+		const uint32_t w[3] = { __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), __builtin_amdgcn_alignbit(d3, x2, sh) };
+#pragma unroll
+		for (int m = 0; m < 3; ++m)
+		{
+			e[into][m] = __builtin_amdgcn_perm(0, w[m], 0x0c020c00);
+			o[into][m] = __builtin_amdgcn_perm(0, w[m], 0x0c030c01);
+		}
+	}
+};
+
+template <bool BI, bool FAST, int AHEAD>
+__global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
+	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
+	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
+	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
+	int W, int H, int S /* strips per PU */, int PPW /* PUs per wave */, uint32_t n_blocks,
+	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
+{
+	if (blockIdx.y)
+	{
+		dst += plane2_dst;
+		ref0 += plane2_ref0;
+		ref1 += plane2_ref1;
+	}
+	constexpr int NREF = BI ? 2 : 1;
+	constexpr int TAPS = 4, UNROLL = AHEAD > TAPS ? AHEAD : TAPS;
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	const int lane = threadIdx.x & 63;
+	int sub = lane / S;
+	int strip = lane - sub * S;
+	const bool spare = sub >= PPW;
+	if (spare) { sub = PPW - 1; strip = 0; }
+	uint32_t pu = wave * PPW + sub;
+	const bool in_batch = pu < n_blocks;
+	if (!in_batch) pu = n_blocks - 1;
+	const int cols = min(8, W - 8 * strip);
+	const bool stores = in_batch && !spare;
+	const uint32_t step_ref = (uint32_t)stride_ref, step_dst = (uint32_t)stride_dst;
+
+	typedef StripStream4<AHEAD> Stream;
+	Stream rs[NREF];
+
+	uint32_t lo_span = 0xffffffffu, hi_span = 0;
+#pragma unroll
+	for (int r = 0; r < NREF; ++r)
+	{
+		const int frac = (r ? frac1 : frac0)[pu];
+		const bool fx = (frac & 15) != 0, fy = (frac >> 4) != 0;
+		const int need = cols + (fx ? TAPS - 1 : 0);
+		const uint32_t first = (r ? ref1_off : ref0_off)[pu] - (fy ? step_ref : 0u) + (uint32_t)(8 * strip - (fx ? 1 : 0));
+		const uint32_t last = first + (uint32_t)(H - 1 + (fy ? TAPS - 1 : 0)) * step_ref;
+		rs[r].plane = r ? ref1 : ref0;
+		rs[r].off = first;
+		rs[r].lo = fy ? 0u : min(first, first + (uint32_t)(H - 1) * step_ref);
+		rs[r].hi = fy ? 0xffffffffu : max(first, first + (uint32_t)(H - 1) * step_ref);
+		rs[r].c.load(frac);
+		// the span of this reference's windows over the wave (per reference: two planes)
+		const uint32_t lo_l = min(first, last) & ~3u, hi_l = (max(first, last) + (uint32_t)need + 3u) & ~3u;
+		const uint32_t lo_w = wave_min_u32(cols > 0 ? lo_l : 0xffffffffu), hi_w = wave_max_u32(cols > 0 ? hi_l : 0u);
+		rs[r].last_load = hi_w - 16u;
+		lo_span = lo_w; hi_span = hi_w;
+	}
+	(void)lo_span; (void)hi_span;
+	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * strip);
+
+	// prologue: window rows 0 .. 2 into slots 0 .. 2, rows 3 .. 6 in flight
+#pragma unroll
+	for (int r = 0; r < NREF; ++r)
+	{
+#pragma unroll
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].issue(q, step_ref);
+#pragma unroll
+		for (int q = 0; q < TAPS - 1; ++q) rs[r].take(q, q);
+		if (FAST || H >= AHEAD)
+		{
+#pragma unroll
+			for (int a = 0; a < AHEAD; ++a) rs[r].issue(a, step_ref);
+		}
+		else
+		{
+#pragma unroll
+			for (int a = 0; a < AHEAD; ++a) { if (a < H) rs[r].issue(a, step_ref); }
+		}
+	}
+
+	const int rows = H + TAPS - 1;
+	auto output_row = [&](auto loads_tag, auto fast_tag, const int i, const int y)
+	{
+		constexpr bool LOADS = decltype(loads_tag)::value, BRANCH_FREE = decltype(fast_tag)::value;
+		int s[NREF][8];
+#pragma unroll
+		for (int r = 0; r < NREF; ++r)
+		{
+			Stream &st = rs[r];
+			st.take(i % AHEAD, (i + TAPS - 1) % TAPS);                                              // window row y + 3
+			if (LOADS && (BRANCH_FREE || y + TAPS - 1 + AHEAD < rows)) st.issue(i % AHEAD, step_ref);     // window row y + 3 + AHEAD
+			uint32_t ve[3], vo[3];
+#pragma unroll
+			for (int m = 0; m < 3; ++m)
+			{
+				if (!BI)
+				{
+					ve[m] = pk_mad_fused(st.e[i % TAPS][m], st.c.v[0], 0x00200020u);      // the seed: 32 * 64 = the rounding constant after the horizontal pass
+					vo[m] = pk_mad_fused(st.o[i % TAPS][m], st.c.v[0], 0x00200020u);
+				}
+				else
+				{
+					ve[m] = pk_mad(st.e[i % TAPS][m], st.c.v[0], 0);
+					vo[m] = pk_mad(st.o[i % TAPS][m], st.c.v[0], 0);
+				}
+#pragma unroll
+				for (int k = 1; k < TAPS; ++k)
+				{
+					ve[m] = pk_mad(st.e[(i + k) % TAPS][m], st.c.v[k], ve[m]);
+					vo[m] = pk_mad(st.o[(i + k) % TAPS][m], st.c.v[k], vo[m]);
+				}
+			}
+			uint32_t a[2], b[2];
+#pragma unroll
+			for (int m = 0; m < 2; ++m)
+			{
+				a[m] = __builtin_amdgcn_alignbit(ve[m + 1], ve[m], 16);
+				b[m] = __builtin_amdgcn_alignbit(vo[m + 1], vo[m], 16);
+			}
+#pragma unroll
+			for (int m = 0; m < 2; ++m)
+			{
+				s[r][4 * m + 0] = dot2(vo[m], st.c.h[1], first_dot<!BI>(ve[m], st.c.h[0]));
+				s[r][4 * m + 1] = dot2(a[m], st.c.h[1], first_dot<!BI>(vo[m], st.c.h[0]));
+				s[r][4 * m + 2] = dot2(b[m], st.c.h[1], first_dot<!BI>(a[m], st.c.h[0]));
+				s[r][4 * m + 3] = dot2(ve[m + 1], st.c.h[1], first_dot<!BI>(b[m], st.c.h[0]));
+			}
+		}
+		uint32_t px[2];
+#pragma unroll
+		for (int m = 0; m < 2; ++m)
+		{
+			int t[4];
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				t[q] = BI ? (s[0][4 * m + q] >> 6) + (s[NREF - 1][4 * m + q] >> 6) + 64 : s[0][4 * m + q];
+			constexpr int SHIFT = BI ? 7 : 12;
+			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
+			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
+			px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+		}
+		uint8_t *out = dst + (size_t)out_off;
+		if (stores)
+		{
+			if (cols == 8)
+			{
+				u32x2 v; v.x = px[0]; v.y = px[1];
+				__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
+			}
+			else if (cols == 4) reinterpret_cast<U1 *>(out)->v = px[0];
+			else
+				for (int q = 0; q < cols; ++q) out[q] = (uint8_t)(px[q >> 2] >> (8 * (q & 3)));
+		}
+		out_off += step_dst;
+	};
+
+	if (FAST)
+	{
+		// H = n * UNROLL rows: every row of the first n - 1 groups refills its ring slot, no row of the last group does (no branch between
+		// the loads); with AHEAD = 8 and H = 8 the whole window is in flight before the first row is computed
+		const int groups = H / UNROLL;
+		int y = 0;
+		for (int g = 0; g < groups - 1; ++g)
+		{
+#pragma unroll
+			for (int i = 0; i < UNROLL; ++i) output_row(Flag<true>(), Flag<true>(), i, y + i);
+			y += UNROLL;
+		}
+		if (AHEAD == UNROLL)
+		{
+#pragma unroll
+			for (int i = 0; i < UNROLL; ++i) output_row(Flag<false>(), Flag<true>(), i, y + i);
+		}
+	}
+	else
+	{
+		for (int y0 = 0; y0 < H; y0 += UNROLL)
+		{
+#pragma unroll
+			for (int i = 0; i < UNROLL; ++i)
+			{
+				const int y = y0 + i;
+				if (y < H) output_row(Flag<true>(), Flag<false>(), i, y);
+			}
+		}
+	}
+}
+
+template <bool BI>
+static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
+		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
+		int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
+{
+	const int strips = (W + 7) / 8, ppw = kWave / strips;
+	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
+	// Rows in flight: 4 (the ring turns once per unrolled group of TAPS rows) or 8 -- with 8, an 8-row PU has its whole 11-row window in
+	// flight before the first row is computed.  Same box (profiles/r03_pred_strip_ab.txt): 8x8 uni -18 %, 8x16 -8 % / -11 % (uni / bi), 16x16 -5 %,
+	// 6x8 uni -10 %; heights that are not multiples of 8 take the general row loop with it and lose 20-30 %, 2-wide and bi 6-wide lose 8-16 %.
+	const bool ahead8 = H % 8 == 0 && W >= 6 && !(BI && W < 8);
+#define STRIP(FASTV, AH) hipLaunchKernelGGL((pred_strip4_kernel<BI, FASTV, AH>), dim3(grid, p2.count), dim3(kThreads), 0, st, \
+		dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
+	if (ahead8) { if (H % 8 == 0) STRIP(true, 8); else STRIP(false, 8); }
+	else if (H % 4 == 0) STRIP(true, 4);
+	else STRIP(false, 4);
+#undef STRIP
+	return launch_status("pred_strip4_kernel");
+}
+
 template <int TAPS, bool BI>
 static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
 		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
@@ -584,6 +868,13 @@ static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const ui
 	// per cycle whatever their width); PUs narrower than 8 keep 4 bytes so that no lane is half idle.
 	// The window must hold at least one full lane load: W + T - 1 >= 8 for the wide variant.
 	// (4 bytes per lane for bi-prediction, 95 VGPRs, was measured too: 10 % slower at 16x16, equal at 64x64.)
+	// 4 taps: one lane per 8-column strip (needs a wave's windows to span 16 bytes: at least two rows a 16-byte stride apart)
+	static const bool no_strip = getenv("HEVCASM_PRED_NOSTRIP") != nullptr;      // measurement switch, read once per process
+	// Where it pays (same box, 256 frames of 960x540 per launch, profiles/r03_pred_strip_ab.txt): 8-wide -13 ... -21 %, 2- and 6-wide -18 ... -26 %,
+	// 16-wide -7 ... -10 %, 4-wide -11 % (uni) / +4 % (bi), 12-wide +16 ... +24 % (two strips = the stream kernel's two lanes, more arithmetic),
+	// 24- / 32-wide +-0 ... +20 % (the stream kernel's lanes share the vertical pass there).
+	const bool strip_pays = (W <= 8 && !(BI && W == 4)) || W == 16;
+	if (TAPS == 4 && strip_pays && H >= 2 && (sr >= 16 || sr <= -16) && !no_strip) return launch_pred_strip4<BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 }

@@ -35,10 +35,12 @@ def report(name, n, bytes_per_block, ms, **kw):
         print(json.dumps(row), flush=True)
 
 
-def bench_pred(frames=64, only=None, two_planes=True):
+def bench_pred(frames=64, only=None, two_planes=True, taps_only=None):
     """Config #3: 1920x1080 luma tiled by each PU size (chroma planes 960x540, 4-tap), all phases,
     `frames` frames per launch so that the launch is far above the launch floor."""
     for taps, fw, fh in ((8, 1920, 1080), (4, 960, 540)):
+        if taps_only and taps != taps_only:
+            continue
         for (w, h) in wl.PU_SIZES:
             if only and (w, h) not in only:
                 continue
@@ -353,6 +355,9 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
+        if w == "pred4tap":                               # chroma only, every PU size
+            bench_pred(taps_only=4)
+            continue
         if w == "pred16":
             bench_pred(only=((16, 16),))
             continue
