@@ -102,3 +102,54 @@ def test_search_operators_and_small_families_random_parameters():
         stride, n = int(rng.integers(2 << log2, 300)), int(rng.integers(1, 90))
         c = dict(neighbours=wl.fill_u8(stride * n + 128, 8500 + i), neighbour_stride=stride, mode=1, packed=(8 << 8) | (log2 << 1) | edge, n=n)
         cases.assert_same("fuzz intra %d edge=%d stride=%d" % (1 << log2, edge, stride), cases.run_hip("intra", c), cases.run_oracle("intra", c))
+
+
+def test_frame_search_and_two_plane_prediction_random_geometry():
+    """Round-3 entry points: the frame-rows full search on random frames (dimensions any multiple of 4, CTU 8 ... 64, ranges up to
+    the LDS limit, any number of ranks) against the oracle over the block lists of the same CTUs; block-list full search at ranges
+    beyond 16; Cb + Cr prediction in one launch against two single-plane launches."""
+    import torch
+    from hevcasm_amd import batch as B, me_frame
+    from oracle import pyoracle
+    rng = np.random.default_rng(20261008 + SEED)
+    for i in range(10):
+        ctu = int(rng.choice([8, 16, 32, 64]))
+        r = int(rng.integers(0, 41))
+        fw, fh = 4 * int(rng.integers(1, 60)), 4 * int(rng.integers(1, 40))
+        world = int(rng.integers(1, 5))
+        f = me_frame.synthetic_frame_pair(fw, fh, r, seed=8600 + i + SEED, ctu=ctu, max_motion=min(r, 24))
+        rows, cols = -(-fh // ctu), -(-fw // ctu)
+        want = np.zeros((rows * cols, 3), dtype=np.int32)
+        for j in me_frame.ctu_jobs(fh, fw, ctu, f["stride_cur"], f["stride_ref"], r, 0, rows):
+            want[j["index"]] = pyoracle.me_full_search(f["cur"], f["stride_cur"], f["ref"], f["stride_ref"], j["cur_off"], j["ref_off"], j["w"], j["h"], r)
+        fn = me_frame.hip_rows_fn()
+        parts = [me_frame.search_rank(f, ctu, r, rank, world, fn) for rank in range(world)]
+        cases.assert_same("fuzz me frame %dx%d ctu %d +-%d x%d" % (fw, fh, ctu, r, world), (me_frame.assemble(parts, fw, fh, ctu),), (want,))
+    for i in range(6):
+        w, h = 4 * int(rng.integers(1, 17)), 4 * int(rng.integers(1, 17))
+        c = cases._me_case(w, h, int(rng.integers(17, 65)), int(rng.integers(1, 4)) * NMUL, 8700 + i, plant=bool(rng.integers(0, 2)))
+        cases.assert_same("fuzz me %dx%d +-%d" % (w, h, c["range"]), cases.run_hip("me", c), cases.run_oracle("me", c))
+    for i in range(20):
+        taps = int(rng.choice([8, 4]))
+        lim = 64 if taps == 8 else 32
+        w, h = int(rng.integers(1, lim + 1)), int(rng.integers(1, lim + 1))
+        n = int(rng.integers(1, 40)) * NMUL
+        bi = bool(rng.integers(0, 2))
+        frame = (w * int(rng.integers(1, 4)), h * int(rng.integers(1, 4)))
+        ca = wl.pred_case(taps, w, h, n, 8800 + i, bi=bi, frame=frame)
+        cb = wl.pred_case(taps, w, h, n, 8900 + i, bi=bi, frame=frame)
+        refs = ["ref0", "ref1"] if bi else ["ref0"]
+        da, db = (torch.zeros(ca["dst_bytes"], dtype=torch.uint8, device="cuda") for _ in range(2))
+        wa, wb = (torch.zeros(ca["dst_bytes"], dtype=torch.uint8, device="cuda") for _ in range(2))
+        ra, rb = [B.u8(ca[k]) for k in refs], [B.u8(cb[k]) for k in refs]
+        doff, offs, fr = B.off32(ca["dst_off"]), [B.off32(ca[k + "_off"]) for k in refs], [B.u8(ca["frac%d" % q]) for q in range(len(refs))]
+        if bi:
+            B.pred_bi_2planes(da, db, ca["stride_dst"], ra[0], rb[0], ra[1], rb[1], ca["stride_ref"], doff, offs[0], offs[1], fr[0], fr[1], taps, w, h)
+            B.pred_bi(wa, ca["stride_dst"], ra[0], ra[1], ca["stride_ref"], doff, offs[0], offs[1], fr[0], fr[1], taps, w, h)
+            B.pred_bi(wb, ca["stride_dst"], rb[0], rb[1], ca["stride_ref"], doff, offs[0], offs[1], fr[0], fr[1], taps, w, h)
+        else:
+            B.pred_uni_2planes(da, db, ca["stride_dst"], ra[0], rb[0], ca["stride_ref"], doff, offs[0], fr[0], taps, w, h)
+            B.pred_uni(wa, ca["stride_dst"], ra[0], ca["stride_ref"], doff, offs[0], fr[0], taps, w, h)
+            B.pred_uni(wb, ca["stride_dst"], rb[0], ca["stride_ref"], doff, offs[0], fr[0], taps, w, h)
+        torch.cuda.synchronize()
+        assert torch.equal(da, wa) and torch.equal(db, wb), ("fuzz 2 planes", taps, w, h, bi, n)
