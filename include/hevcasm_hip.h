@@ -134,9 +134,13 @@ int hevcasm_hip_pred_intra_batch(
 /* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).
  * taps = 8 (luma, fractions 0..3, nPbW/nPbH <= 64) or 4 (chroma, fractions 0..7, <= 32).
  * frac[i] = xFrac | (yFrac << 4).  ref + ref_off[i] is the integer-pel top-left sample.
- * Memory read per block is exactly the reference's: the filter margins (taps/2 - 1 samples before, taps/2 after) only in a
+ * Memory read per block is the reference's footprint: the filter margins (taps/2 - 1 samples before, taps/2 after) only in a
  * direction whose fraction is non-zero -- nPbW x nPbH bytes for an integer motion vector, (nPbW + taps - 1) x nPbH for
  * a horizontal-only, nPbW x (nPbH + taps - 1) for a vertical-only and the full window for a two-dimensional fraction.
+ * 8 taps: exactly those bytes.  4 taps, PUs up to 8 wide or 16 wide: the kernel loads whole 4-byte-aligned words, 16 bytes at a
+ * time, never below the lowest nor above the highest word that holds a byte of the footprints of the (at most 64)
+ * consecutive PUs of the batch that one wavefront handles -- i.e. it may read bytes between those footprints, and up to 3
+ * bytes beside the first / last of them inside their words, all of which a frame plane contains.
  * Writes exactly nPbW x nPbH bytes per block. */
 int hevcasm_hip_pred_uni_8to8_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,

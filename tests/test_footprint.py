@@ -1,5 +1,6 @@
-"""What the prediction entry points READ: exactly the reference's footprint (reference pred_inter.c:141-228) -- the filter
-margins only in a direction whose fraction is non-zero.  The per-block table entries are probed with blocks flush
+"""What the prediction entry points READ: the reference's footprint (reference pred_inter.c:141-228) -- the filter
+margins only in a direction whose fraction is non-zero; byte-exact but for the 4-tap strip kernel of narrow PUs, which loads
+whole aligned words between the lowest and the highest word of one wavefront's windows (include/hevcasm_hip.h).  The per-block table entries are probed with blocks flush
 against inaccessible pages (tests/footprint_probe.py, in a subprocess: an over-read is a segmentation fault); the batch
 kernels with blocks flush at both ends of exactly-sized device allocations."""
 import os
