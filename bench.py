@@ -402,9 +402,8 @@ def library_record():
     return dict(library=os.path.relpath(capi.LIB_PATH, ROOT), env_switches={k: v for k, v in os.environ.items() if k.startswith("HEVCASM_")})
 
 
-# byte differences per second the chip can issue through v_qsad_pk_u16_u8 (16 per lane and instruction):
-# tools/ubench/qsad_rate.hip on MI355X, profiles/r03_qsad_rate.txt
-QSAD_PEAK_TBYTEDIFFS = None     # filled from profiles/r03_qsad_rate.json when present
+# byte differences per second the chip can issue through v_qsad_pk_u16_u8 (16 per lane and instruction): measured by
+# tools/ubench/qsad_rate.hip on MI355X (profiles/r03_qsad_rate.txt / .json); the nominal figure is the fallback when that record is absent
 NOMINAL_QSAD_TBYTEDIFFS = 256 * 4 * 64 * 16 / 16.0 * 2.4e9 / 1e12     # quarter rate: 16 differences per lane per 16 cycles at 2.4 GHz = 157 T/s
 
 

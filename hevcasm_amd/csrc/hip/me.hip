@@ -28,7 +28,7 @@ template <bool FRAME, bool W64>
 __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, int n_groups, MeFrame fr)
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, MeFrame fr)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
@@ -94,7 +94,6 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const int full_items = side * nfg;
 	const int whole = full_items & ~(kThreads - 1);            // dealt as full items
 	const int quarters = 4 * (full_items - whole) + side * rem_q;
-	(void)n_groups;
 	for (int item = threadIdx.x; item < whole; item += kThreads)
 	{
 		const int cy = item / nfg, g = item - cy * nfg;   // candidates (cy, 16 g .. 16 g + 15)
@@ -254,10 +253,10 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
 	if (W == 64)
 		hipLaunchKernelGGL((me_full_search_kernel<false, true>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
+				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, MeFrame{});
 	else
 		hipLaunchKernelGGL((me_full_search_kernel<false, false>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, n_groups, MeFrame{});
+				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, MeFrame{});
 	return launch_status("me_full_search_kernel");
 }
 
@@ -280,9 +279,9 @@ extern "C" int hevcasm_hip_me_full_search_frame_rows(
 	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu };
 	if (ctu == 64 && frame_w % 64 == 0)
 		hipLaunchKernelGGL((me_full_search_kernel<true, true>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
-				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
+				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, fr);
 	else
 		hipLaunchKernelGGL((me_full_search_kernel<true, false>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
-				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, n_groups, fr);
+				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, fr);
 	return launch_status("me_full_search_kernel<frame>");
 }

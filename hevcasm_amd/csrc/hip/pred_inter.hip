@@ -688,7 +688,6 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 	typedef StripStream4<AHEAD> Stream;
 	Stream rs[NREF];
 
-	uint32_t lo_span = 0xffffffffu, hi_span = 0;
 #pragma unroll
 	for (int r = 0; r < NREF; ++r)
 	{
@@ -705,10 +704,9 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 		// the span of this reference's windows over the wave (per reference: two planes)
 		const uint32_t lo_l = min(first, last) & ~3u, hi_l = (max(first, last) + (uint32_t)need + 3u) & ~3u;
 		const uint32_t lo_w = wave_min_u32(cols > 0 ? lo_l : 0xffffffffu), hi_w = wave_max_u32(cols > 0 ? hi_l : 0u);
-		rs[r].last_load = hi_w - 16u;
-		lo_span = lo_w; hi_span = hi_w;
+		rs[r].last_load = hi_w - 16u;          // >= lo_w: the launcher guarantees a span of at least 16 bytes
+		(void)lo_w;
 	}
-	(void)lo_span; (void)hi_span;
 	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * strip);
 
 	// prologue: window rows 0 .. 2 into slots 0 .. 2, rows 3 .. 6 in flight
