@@ -14,6 +14,7 @@
 // VALU/LDS-bound (about 1.7 k byte differences per byte fetched), not HBM-bound.
 
 #include "common.hpp"
+#include <cstdlib>
 
 namespace hevc {
 
@@ -23,16 +24,25 @@ namespace hevc {
 // one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
 struct MeFrame { int cols, ctu, frame_w, slab_h; };
 
+__device__ __forceinline__ unsigned long long *me_key_slot(int *result, uint32_t k) { return reinterpret_cast<unsigned long long *>(result + 3 * (size_t)k + (k & 1u)); }
+
 // W64: every block of the launch is 64 wide (the common case: CTUs) -- the row loops then have constant trip counts and unroll.
+// parts (1 .. 8): workgroups per block.  A block's candidates cost 1.15 M SIMD-cycles of v_qsad, i.e. a whole CU for 119 us, however
+// many threads work on it; a launch of fewer blocks than the chip has CUs x 4 (one rank's rows of a frame split over 8 GPUs: 240-300 CTUs)
+// leaves CUs idle or gives some of them two blocks in a row.  Such launches cut every block's candidate ROWS into `parts` ranges, one
+// workgroup each (its window is the H + rows - 1 window rows the range needs); the ranges' minima meet in an atomicMin on the 64-bit key
+// (cost << 16 | index: ties still go to the raster-first candidate) held in the block's own 12-byte result slot, and me_decode_kernel
+// rewrites the keys as (dx, dy, cost) afterwards.
 template <bool FRAME, bool W64>
 __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, MeFrame fr)
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, MeFrame fr, int parts)
 {
 	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
 
-	const uint32_t blk = blockIdx.x;
+	const uint32_t blk = blockIdx.x / (uint32_t)parts;
+	const int part = (int)(blockIdx.x - blk * (uint32_t)parts);
 	const uint8_t *sp, *rp0;
 	if (FRAME)
 	{
@@ -52,12 +62,15 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	// row into the source tile -- but only for candidates past the window, which are never scored.  For 64x64
 	// blocks and +-64 that makes 36 864 + 4 096 = 40 960 bytes: FOUR workgroups per CU (160 KiB), and a 4K
 	// frame's 2040 CTUs are then two full rounds of 1024 instead of three of 768.
-	uint8_t *s_win = lds;                                                  // (H + 2R) rows of win_stride bytes
-	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds + (size_t)win_stride * (H + 2 * R));   // H rows of W / 4 dwords
-	unsigned long long *best_of_wave = reinterpret_cast<unsigned long long *>(lds);          // reused after the search
+	const int side = 2 * R + 1;
+	const int per = (side + parts - 1) / parts;
+	const int cy0 = part * per, cnt = min(per, side - cy0);              // this workgroup's candidate rows cy0 .. cy0 + cnt - 1 (the launcher keeps cnt >= 1)
+	uint8_t *s_win = lds;                                                  // (H + cnt - 1) rows of win_stride bytes: window rows cy0 ..
 	if (W64) W = 64;
 	const int wd = W64 ? 16 : W / 4;
-	const int win_w = W + 2 * R, win_h = H + 2 * R;
+	const int win_w = W + 2 * R, win_h = H + cnt - 1;
+	uint32_t *s_src = reinterpret_cast<uint32_t *>(lds + (size_t)win_stride * win_h);         // H rows of W / 4 dwords
+	unsigned long long *best_of_wave = reinterpret_cast<unsigned long long *>(lds);          // reused after the search
 
 	for (int i = threadIdx.x; i < wd * H; i += kThreads)
 	{
@@ -65,7 +78,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		s_src[i] = reinterpret_cast<const U1 *>(sp + (ptrdiff_t)y * stride_src + 4 * x)->v;
 	}
 	// window rows, zero-padded to win_stride
-	const uint8_t *rp = rp0 - (ptrdiff_t)R * stride_ref - R;
+	const uint8_t *rp = rp0 + (ptrdiff_t)(cy0 - R) * stride_ref - R;
 	const int row_dwords = win_stride / 4;
 	for (int i = threadIdx.x; i < row_dwords * win_h; i += kThreads)
 	{
@@ -79,7 +92,6 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	}
 	__syncthreads();
 
-	const int side = 2 * R + 1;
 	unsigned long long best = ~0ull;
 	// Work items.  A FULL item = (dy, 16 consecutive dx): 16 v_qsad per 16 source bytes, the window bytes shared by the item's
 	// four quads of candidates.  A QUARTER item = (dy, 4 consecutive dx): one v_qsad per source dword.  side = 2R + 1 is odd,
@@ -91,9 +103,9 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	// ever scores more than 3 candidates outside the window.
 	const int nfg = side >> 4;                                 // full groups per candidate row
 	const int rem_q = ((side & 15) + 3) >> 2;                  // quarter groups that hold a row's remaining candidates
-	const int full_items = side * nfg;
-	const int whole = full_items & ~(kThreads - 1);            // dealt as full items
-	const int quarters = 4 * (full_items - whole) + side * rem_q;
+	const int full_items = cnt * nfg;
+	const int whole = full_items & ~(kThreads - 1);             // dealt as full items
+	const int quarters = 4 * (full_items - whole) + cnt * rem_q;
 	for (int item = threadIdx.x; item < whole; item += kThreads)
 	{
 		const int cy = item / nfg, g = item - cy * nfg;   // candidates (cy, 16 g .. 16 g + 15)
@@ -151,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 #pragma unroll
 		for (int k = 0; k < 16; ++k)
 		{
-			const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + 16 * g + k);      // every candidate of a full group is inside the window
+			const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)((cy0 + cy) * side + 16 * g + k);      // every candidate of a full group is inside the window
 			best = key < best ? key : best;
 		}
 	}
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		{
 			if (cx0 + k < side)
 			{
-				const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)(cy * side + cx0 + k);
+				const unsigned long long key = ((unsigned long long)acc[k] << 16) | (unsigned)((cy0 + cy) * side + cx0 + k);
 				best = key < best ? key : best;
 			}
 		}
@@ -214,26 +226,77 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	if (threadIdx.x == 0)
 	{
 		for (int w = 1; w < kThreads / kWave; ++w) best = best_of_wave[w] < best ? best_of_wave[w] : best;
-		const int c = (int)(best & 0xffff);
-		result[3 * blk + 0] = c % side - R;
-		result[3 * blk + 1] = c / side - R;
-		result[3 * blk + 2] = (int)(best >> 16);
+		if (parts == 1)
+		{
+			const int c = (int)(best & 0xffff);
+			result[3 * blk + 0] = c % side - R;
+			result[3 * blk + 1] = c / side - R;
+			result[3 * blk + 2] = (int)(best >> 16);
+		}
+		else
+			atomicMin(me_key_slot(result, blk), best);
 	}
+}
+
+// several workgroups per block: the 8-byte-aligned 8 bytes inside block k's 12-byte result slot (the first 8 when k is even, the last 8 when odd)
+// hold the running minimum key, preset to all ones; this turns them into the result
+__global__ __launch_bounds__(kThreads) void me_decode_kernel(int *result, uint32_t n_blocks, int R)
+{
+	const uint32_t k = blockIdx.x * kThreads + threadIdx.x;
+	if (k >= n_blocks) return;
+	const unsigned long long key = *me_key_slot(result, k);
+	const int side = 2 * R + 1, c = (int)(key & 0xffff);
+	result[3 * k + 0] = c % side - R;
+	result[3 * k + 1] = c / side - R;
+	result[3 * k + 2] = (int)(key >> 16);
 }
 
 }  // namespace hevc
 
 using namespace hevc;
 
-// LDS bytes of one workgroup: (H + 2R) window rows of win_stride bytes, then the source tile, which also absorbs what
-// the last dx group reads past the last window row (see the kernel's layout note)
-static size_t me_lds_bytes(int W, int H, int range, int *win_stride, int *n_groups)
+// workgroups per block: 1 when the launch fills the chip's workgroup slots (4 per CU at 64x64 / +-64) by itself
+static int me_parts(size_t n_blocks, int range)
 {
-	*n_groups = (2 * range + 1 + 15) / 16;                           // dx groups of 16
+	static const int forced = getenv("HEVCASM_ME_PARTS") ? atoi(getenv("HEVCASM_ME_PARTS")) : 0;    // measurement switch, read once per process
+	int parts = (forced >= 1 && forced <= 8) ? forced : n_blocks <= 384 ? 4 : n_blocks <= 768 ? 2 : 1;
+	while (parts > 1 && 2 * range + 1 < 8 * parts) --parts;              // every part gets candidate rows
+	return parts;
+}
+
+// LDS bytes of one workgroup: `win_rows` window rows of win_stride bytes (H + 2 range of them when one workgroup takes all of a block's
+// candidate rows), then the source tile, which also absorbs what the last dx group reads past the last window row (see the kernel's layout note)
+static size_t me_lds_bytes(int W, int H, int range, int win_rows, int *win_stride)
+{
+	const int n_groups = (2 * range + 1 + 15) / 16;                  // dx groups of 16 (the quarter items stay inside the same bound)
 	*win_stride = (W + 2 * range + 15) & ~15;
-	const int overread = 16 * *n_groups + W + 4 - *win_stride;       // bytes the last window row is read past its end
+	const int overread = 16 * n_groups + W + 4 - *win_stride;        // bytes the last window row is read past its end
 	const int tail = W * H > overread ? W * H : overread;
-	return (size_t)*win_stride * (H + 2 * range) + (size_t)((tail + 15) & ~15);
+	return (size_t)*win_stride * win_rows + (size_t)((tail + 15) & ~15);
+}
+
+// launches the search (and, with several workgroups per block, the preset of the key slots before it and their decoding after it)
+template <bool FRAME>
+static int me_launch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, const uint32_t *src_off, const uint32_t *ref_off,
+		int *result, int W, int H, int range, bool w64, size_t n_blocks, const MeFrame &fr, hipStream_t st)
+{
+	int win_stride;
+	// the domain does not depend on the batch: a window must fit LDS whole, whether or not this launch cuts it into parts
+	if (me_lds_bytes(W, H, range, H + 2 * range, &win_stride) > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
+	const int parts = me_parts(n_blocks, range);
+	const int per = (2 * range + 1 + parts - 1) / parts;             // candidate rows per workgroup
+	const size_t shmem = me_lds_bytes(W, H, range, H + per - 1, &win_stride);
+	if (parts > 1) HEVC_HIP_TRY(hipMemsetAsync(result, 0xff, 12 * n_blocks, st));
+	const dim3 grid((uint32_t)(n_blocks * parts));
+	if (w64) hipLaunchKernelGGL((me_full_search_kernel<FRAME, true>), grid, dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, fr, parts);
+	else hipLaunchKernelGGL((me_full_search_kernel<FRAME, false>), grid, dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, fr, parts);
+	if (int e = launch_status("me_full_search_kernel")) return e;
+	if (parts > 1)
+	{
+		hipLaunchKernelGGL(me_decode_kernel, dim3(ceil_div(n_blocks, (size_t)kThreads)), dim3(kThreads), 0, st, result, (uint32_t)n_blocks, range);
+		return launch_status("me_decode_kernel");
+	}
+	return 0;
 }
 
 extern "C" int hevcasm_hip_me_full_search_batch(
@@ -246,18 +309,9 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (W < 4 || W > 64 || H < 4 || H > 64 || (W & 3) || (H & 3)) return set_error(HEVCASM_HIP_EINVAL, "block size must be a multiple of 4 in 4..64");
 	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
 	if (n_blocks == 0) return 0;
-	if (n_blocks > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
+	if (n_blocks > 0x1fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	int win_stride, n_groups;
-	const size_t shmem = me_lds_bytes(W, H, range, &win_stride, &n_groups);
-	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	if (W == 64)
-		hipLaunchKernelGGL((me_full_search_kernel<false, true>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, MeFrame{});
-	else
-		hipLaunchKernelGGL((me_full_search_kernel<false, false>), dim3((uint32_t)n_blocks), dim3(kThreads), shmem, as_stream(stream),
-				src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, MeFrame{});
-	return launch_status("me_full_search_kernel");
+	return me_launch<false>(src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, W == 64, n_blocks, MeFrame{}, as_stream(stream));
 }
 
 extern "C" int hevcasm_hip_me_full_search_frame_rows(
@@ -272,16 +326,8 @@ extern "C" int hevcasm_hip_me_full_search_frame_rows(
 	if (row0 < 0 || row1 > rows || row0 > row1) return set_error(HEVCASM_HIP_EINVAL, "CTU rows outside the frame");
 	if (row0 == row1) return 0;
 	if (!cur || !ref || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	int win_stride, n_groups;
-	const size_t shmem = me_lds_bytes(ctu, ctu, range, &win_stride, &n_groups);
-	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
 	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
 	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu };
-	if (ctu == 64 && frame_w % 64 == 0)
-		hipLaunchKernelGGL((me_full_search_kernel<true, true>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
-				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, fr);
-	else
-		hipLaunchKernelGGL((me_full_search_kernel<true, false>), dim3((uint32_t)((row1 - row0) * cols)), dim3(kThreads), shmem, as_stream(stream),
-				cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, win_stride, fr);
-	return launch_status("me_full_search_kernel<frame>");
+	return me_launch<true>(cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, ctu == 64 && frame_w % 64 == 0,
+			(size_t)(row1 - row0) * cols, fr, as_stream(stream));
 }
