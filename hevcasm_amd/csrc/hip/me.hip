@@ -77,18 +77,33 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 		const int y = i / wd, x = i - y * wd;
 		s_src[i] = reinterpret_cast<const U1 *>(sp + (ptrdiff_t)y * stride_src + 4 * x)->v;
 	}
-	// window rows, zero-padded to win_stride
+	// window rows, zero-padded to win_stride: whole 16-byte pieces first (one load and one ds_write_b128 per piece, the (row, piece) pair
+	// stepped without a division), then what is left of each row dword by dword
 	const uint8_t *rp = rp0 + (ptrdiff_t)(cy0 - R) * stride_ref - R;
-	const int row_dwords = win_stride / 4;
-	for (int i = threadIdx.x; i < row_dwords * win_h; i += kThreads)
 	{
-		const int y = i / row_dwords, x = i - y * row_dwords;
-		const uint8_t *p = rp + (ptrdiff_t)y * stride_ref + 4 * x;
-		uint32_t v = 0;
-		if (4 * x + 4 <= win_w) v = reinterpret_cast<const U1 *>(p)->v;
-		else
-			for (int b = 0; 4 * x + b < win_w; ++b) v |= (uint32_t)p[b] << (8 * b);   // never read past the window the caller guarantees
-		*reinterpret_cast<uint32_t *>(s_win + y * win_stride + 4 * x) = v;
+		const int cpr = win_w >> 4;                                          // whole pieces per row
+		if (cpr > 0)
+		{
+			int y = (int)threadIdx.x / cpr, x = (int)threadIdx.x - y * cpr;
+			const int dy = kThreads / cpr, dx = kThreads - dy * cpr;
+			while (y < win_h)
+			{
+				*reinterpret_cast<u32x4 *>(s_win + y * win_stride + 16 * x) = reinterpret_cast<const U4 *>(rp + (ptrdiff_t)y * stride_ref + 16 * x)->v;
+				y += dy; x += dx;
+				if (x >= cpr) { x -= cpr; y += 1; }
+			}
+		}
+		const int first = cpr * 4, row_dwords = win_stride / 4, rest = row_dwords - first;       // dwords [first, row_dwords) of every row
+		for (int i = threadIdx.x; i < rest * win_h; i += kThreads)
+		{
+			const int y = i / rest, x = first + i - y * rest;
+			const uint8_t *p = rp + (ptrdiff_t)y * stride_ref + 4 * x;
+			uint32_t v = 0;
+			if (4 * x + 4 <= win_w) v = reinterpret_cast<const U1 *>(p)->v;
+			else
+				for (int b = 0; 4 * x + b < win_w; ++b) v |= (uint32_t)p[b] << (8 * b);   // never read past the window the caller guarantees
+			*reinterpret_cast<uint32_t *>(s_win + y * win_stride + 4 * x) = v;
+		}
 	}
 	__syncthreads();
 
