@@ -799,6 +799,8 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 				__builtin_nontemporal_store(v, reinterpret_cast<u32x2_u *>(out));
 			}
 			else if (cols == 4) reinterpret_cast<U1 *>(out)->v = px[0];
+			else if (cols == 6) { reinterpret_cast<U1 *>(out)->v = px[0]; reinterpret_cast<H1 *>(out + 4)->v = (uint16_t)px[1]; }
+			else if (cols == 2) reinterpret_cast<H1 *>(out)->v = (uint16_t)px[0];
 			else
 				for (int q = 0; q < cols; ++q) out[q] = (uint8_t)(px[q >> 2] >> (8 * (q & 3)));
 		}
