@@ -27,8 +27,8 @@ roofline.per_family = the other kernels BASELINE.json's metric names, measured i
 
     python bench.py --workload me5 [--gpus N ...]
 BASELINE.json configs[4] instead: full-search motion estimation, +-64, over 3840x2160 frames of 64x64 CTUs (bottom row
-64x48), every frame's CTU ROWS sharded across the ranks, each rank holding its rows + the +-64-row halo of the
-reference frame (hevcasm_amd/me_frame.py, shard.py).  A step = one frame; strong scaling; no data-path collective
+64x48), every frame's CTUs sharded across the ranks -- contiguous CTU rows, handed out balanced to one CTU (--me-split rows: to one
+row) -- each rank holding the rows its CTUs lie in + the +-64-row halo of the reference frame (hevcasm_amd/me_frame.py, shard.py).  A step = one frame; strong scaling; no data-path collective
 (after the timed region the 12-byte answers are collected and rank 0 checks a sample of them against the
 reference's hevcasm_sad composed per candidate).
 """
@@ -225,6 +225,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="host processes of the CPU baseline legs (one GPU's share of the host)")
     ap.add_argument("--no-families", action="store_true", help="skip the per-family measurements (inter prediction, transforms, full search) after the timed region")
+    ap.add_argument("--me-split", default="ctus", choices=("rows", "ctus"), help="me5: ranks own raster runs of CTUs balanced to one CTU (default; each still holds whole CTU rows + halo), or whole CTU rows")
     ap.add_argument("--workload", default="sad", choices=("sad", "me5"), help="sad = BASELINE.json configs[1] (the metric's configuration); me5 = configs[4], full search sharded by CTU rows")
     args = ap.parse_args()
     stale = sorted(k for k in os.environ if k.startswith("HEVCASM_") and k not in ("HEVCASM_BENCH_ONE_DEVICE", "HEVCASM_DIST_BACKEND"))
@@ -454,25 +455,28 @@ def measure_families():
     return rows
 
 
-def gather_me_results(part, frame_w, frame_h, ctu, device="cpu"):
-    """Collect every rank's (row0, row1, results) into the frame's table on rank 0 (None elsewhere).  The answers are 12 bytes
-    per CTU, collected after the search: each rank writes its rows into a table of INT_MIN and its row ownership into a
-    vector of zeros; MAX / SUM all-reduces merge them, and the ownership vector proves every row had exactly one owner."""
+def gather_me_results(part, frame_w, frame_h, ctu, device="cpu", unit="rows"):
+    """Collect every rank's (first, last, results) into the frame's table on rank 0 (None elsewhere); first / last count CTU rows
+    (unit="rows") or CTUs in raster order (unit="ctus").  The answers are 12 bytes per CTU, collected after the search: each rank
+    writes its CTUs into a table of INT_MIN and its ownership into a vector of zeros; MAX / SUM all-reduces merge them, and the
+    ownership vector proves every CTU had exactly one owner."""
     import torch
     import torch.distributed as dist
     from hevcasm_amd import me_frame
-    if not (dist.is_available() and dist.is_initialized()):
-        return me_frame.assemble([part], frame_w, frame_h, ctu)
     rows, cols = -(-frame_h // ctu), -(-frame_w // ctu)
-    row0, row1, res = part
+    a, b, res = part
+    if unit == "rows":
+        a, b = a * cols, b * cols
+    if not (dist.is_available() and dist.is_initialized()):
+        return me_frame.assemble_ctus([(a, b, res)], frame_w, frame_h, ctu)
     table = torch.full((rows * cols, 3), -2 ** 31, dtype=torch.int32)
-    table[row0 * cols: row1 * cols] = torch.from_numpy(np.asarray(res, dtype=np.int32).reshape(-1, 3))
-    owners = torch.zeros(rows, dtype=torch.int32)
-    owners[row0:row1] = 1
+    table[a:b] = torch.from_numpy(np.asarray(res, dtype=np.int32).reshape(-1, 3))
+    owners = torch.zeros(rows * cols, dtype=torch.int32)
+    owners[a:b] = 1
     table, owners = table.to(device), owners.to(device)
     dist.all_reduce(table, op=dist.ReduceOp.MAX)
     dist.all_reduce(owners, op=dist.ReduceOp.SUM)
-    assert bool((owners == 1).all()), "CTU rows without exactly one owner: %s" % owners.tolist()
+    assert bool((owners == 1).all()), "CTUs without exactly one owner"
     return table.cpu().numpy() if dist.get_rank() == 0 else None
 
 
@@ -483,19 +487,25 @@ def bench_me5(args, rank, world, device):
     from hevcasm_amd import batch as B, me_frame, shard
     fw, fh, ctu, R = 3840, 2160, 64, 64
     rows, cols = -(-fh // ctu), -(-fw // ctu)
-    row0, row1 = shard.ctu_row_range(rows, rank, world)
+    # the rank's CTUs: whole rows or, --me-split ctus, a raster run balanced to one CTU (255 each at 8 ranks where rows are 300 or 240)
+    if args.me_split == "rows":
+        row0, row1 = shard.ctu_row_range(rows, rank, world)
+        first, last = row0 * cols, row1 * cols
+    else:
+        first, last = shard.ctu_range(rows * cols, rank, world)
+        row0, row1 = shard.rows_of_ctus(first, last, cols)
     # a few distinct frame pairs, rotated over the steps; every rank builds the same frames from the seed and keeps only its slab
-    # (current rows + reference rows with the halo) -- its H2D copy is the slab, never the frame
+    # (the rows its CTUs lie in + reference rows with the halo) -- its H2D copy is the slab, never the frame
     n_pairs = 3
     slabs, frames0 = [], None
     for i in range(n_pairs):
         f = me_frame.synthetic_frame_pair(fw, fh, R, seed=500 + i)
         if i == 0 and rank == 0:
             frames0 = f
-        if row1 > row0:
+        if last > first:
             sl = me_frame.Slab(f, ctu, R, row0, row1)
             slabs.append(dict(slab=sl, cur=torch.from_numpy(sl.cur).to(device), ref=torch.from_numpy(sl.ref).to(device),
-                              out=torch.empty((sl.n_ctus, 3), dtype=torch.int32, device=device)))
+                              out=torch.empty((last - first, 3), dtype=torch.int32, device=device)))
         del f
     torch.cuda.synchronize()
 
@@ -504,7 +514,7 @@ def bench_me5(args, rank, world, device):
             return
         d = slabs[i % n_pairs]
         sl = d["slab"]
-        B.me_full_search_frame_rows(d["cur"], sl.cur_byte0, sl.stride_cur, d["ref"], sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, row0, row1, out=d["out"])
+        B.me_full_search_frame_ctus(d["cur"], sl.cur_byte0, sl.stride_cur, d["ref"], sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, first, last - first, out=d["out"])
 
     def bracket():
         if world > 1:
@@ -528,8 +538,8 @@ def bench_me5(args, rank, world, device):
     # the answers of the first frame pair, from every rank (outside the timed region)
     step(0)
     torch.cuda.synchronize()
-    part = (row0, row1, slabs[0]["out"].cpu().numpy() if slabs else np.zeros((0, 3), dtype=np.int32))
-    table = gather_me_results(part, fw, fh, ctu, device=device if world > 1 and dist.get_backend() == "nccl" else "cpu")
+    part = (first, last, slabs[0]["out"].cpu().numpy() if slabs else np.zeros((0, 3), dtype=np.int32))
+    table = gather_me_results(part, fw, fh, ctu, device=device if world > 1 and dist.get_backend() == "nccl" else "cpu", unit="ctus")
 
     if rank == 0:
         n_ctus = rows * cols
@@ -537,8 +547,7 @@ def bench_me5(args, rank, world, device):
         byte_diffs = sum(cols * ctu * h for h in heights) * (2 * R + 1) ** 2
         sad_evals = n_ctus * (2 * R + 1) ** 2
         alg_bytes = sum(cols * (ctu * h + (ctu + 2 * R) * (h + 2 * R) + 12) for h in heights)     # source + window + result per CTU
-        my_heights = heights[row0:row1]
-        my_diffs = sum(cols * ctu * h for h in my_heights) * (2 * R + 1) ** 2
+        my_diffs = sum(ctu * heights[g // cols] for g in range(first, last)) * (2 * R + 1) ** 2
         peak, peak_src = qsad_peak()
         # CPU baseline: the reference's own hevcasm_sad composed per candidate (refdrv), a bounded sample of this frame's CTUs,
         # one process per core -- and the same CTUs checked against the GPU's table
@@ -553,7 +562,8 @@ def bench_me5(args, rank, world, device):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[4]: full-search motion estimation, SAD over +-64, one 3840x2160 frame per step = 2040 CTUs "
                                    "(33 rows of 64x64, one of 64x48); a block = one CTU = 16 641 SAD evaluations",
-                       "parallelism": "CTU rows split x%d (rank 0: rows %d..%d), each rank holds its rows + the +-64-row halo of the reference; no data-path collective" % (world, row0, row1),
+                       "parallelism": "%s split x%d (rank 0: CTUs %d..%d = rows %d..%d), each rank holds the rows of its CTUs + the +-64-row halo of the reference; no data-path collective"
+                                      % ("CTU rows" if args.me_split == "rows" else "CTU runs", world, first, last, row0, row1),
                        "frames_per_s": round(args.steps / elapsed, 1), "gsad_evals_per_s": round(sad_evals * args.steps / elapsed / 1e9, 2), **library_record()},
             "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": round(my_diffs / (kernel_ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
                          "unit": "T byte differences/s", "frac": round(my_diffs / (kernel_ms * 1e-3) / 1e12 / peak, 4), "traffic": None,

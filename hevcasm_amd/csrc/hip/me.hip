@@ -22,7 +22,7 @@ namespace hevc {
 // is rows of a CTU grid -- block i is CTU (i / cols, i % cols) of a slab whose first pixel both planes point at, CTUs
 // cut off by the frame's right / bottom edge are narrower / shorter (a 2160-row frame ends in a row of 64x48 CTUs) --
 // one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
-struct MeFrame { int cols, ctu, frame_w, slab_h; };
+struct MeFrame { int cols, ctu, frame_w, slab_h, first; };    // first: the launch's first CTU, counted in raster order from column 0 of the slab's first CTU row
 
 __device__ __forceinline__ unsigned long long *me_key_slot(int *result, uint32_t k) { return reinterpret_cast<unsigned long long *>(result + 3 * (size_t)k + (k & 1u)); }
 
@@ -46,7 +46,8 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *sp, *rp0;
 	if (FRAME)
 	{
-		const int row = (int)blk / fr.cols, col = (int)blk - row * fr.cols;
+		const int g = fr.first + (int)blk;
+		const int row = g / fr.cols, col = g - row * fr.cols;
 		W = W64 ? 64 : min(fr.ctu, fr.frame_w - col * fr.ctu);
 		H = min(fr.ctu, fr.slab_h - row * fr.ctu);
 		sp = src + (ptrdiff_t)row * fr.ctu * stride_src + col * fr.ctu;
@@ -329,6 +330,26 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	return me_launch<false>(src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, W == 64, n_blocks, MeFrame{}, as_stream(stream));
 }
 
+extern "C" int hevcasm_hip_me_full_search_frame_ctus(
+	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (ctu < 4 || ctu > 64 || (ctu & 3)) return set_error(HEVCASM_HIP_EINVAL, "CTU size must be a multiple of 4 in 4..64");
+	if (frame_w < 4 || frame_h < 4 || (frame_w & 3) || (frame_h & 3)) return set_error(HEVCASM_HIP_EINVAL, "frame dimensions must be multiples of 4");
+	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
+	const int rows = (frame_h + ctu - 1) / ctu, cols = (frame_w + ctu - 1) / ctu;
+	if (first_ctu < 0 || n_ctus < 0 || (long long)first_ctu + n_ctus > (long long)rows * cols) return set_error(HEVCASM_HIP_EINVAL, "CTUs outside the frame");
+	if (n_ctus == 0) return 0;
+	if (!cur || !ref || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	// the planes point at column 0 of the CTU row that holds first_ctu; the slab ends with the row that holds the last CTU
+	const int row0 = first_ctu / cols, row1 = (first_ctu + n_ctus - 1) / cols + 1;
+	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
+	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu, first_ctu - row0 * cols };
+	return me_launch<true>(cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, ctu == 64 && frame_w % 64 == 0,
+			(size_t)n_ctus, fr, as_stream(stream));
+}
+
 extern "C" int hevcasm_hip_me_full_search_frame_rows(
 	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
 	int frame_w, int frame_h, int ctu, int range, int row0, int row1, int *result, void *stream)
@@ -336,13 +357,7 @@ extern "C" int hevcasm_hip_me_full_search_frame_rows(
 	if (int e = check_device()) return e;
 	if (ctu < 4 || ctu > 64 || (ctu & 3)) return set_error(HEVCASM_HIP_EINVAL, "CTU size must be a multiple of 4 in 4..64");
 	if (frame_w < 4 || frame_h < 4 || (frame_w & 3) || (frame_h & 3)) return set_error(HEVCASM_HIP_EINVAL, "frame dimensions must be multiples of 4");
-	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
 	const int rows = (frame_h + ctu - 1) / ctu, cols = (frame_w + ctu - 1) / ctu;
 	if (row0 < 0 || row1 > rows || row0 > row1) return set_error(HEVCASM_HIP_EINVAL, "CTU rows outside the frame");
-	if (row0 == row1) return 0;
-	if (!cur || !ref || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
-	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu };
-	return me_launch<true>(cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, ctu == 64 && frame_w % 64 == 0,
-			(size_t)(row1 - row0) * cols, fr, as_stream(stream));
+	return hevcasm_hip_me_full_search_frame_ctus(cur, stride_cur, ref, stride_ref, frame_w, frame_h, ctu, range, row0 * cols, (row1 - row0) * cols, result, stream);
 }

@@ -93,6 +93,59 @@ class Slab:
         return (self.row1 - self.row0) * -(-self.frame_w // self.ctu)
 
 
+class CtuRun:
+    """A raster run of CTUs [first, last) and the slab that holds every row it touches."""
+
+    def __init__(self, frame, ctu, search_range, first, last):
+        cols = -(-frame["w"] // ctu)
+        self.first, self.last, self.cols = first, last, cols
+        row0, row1 = shard.rows_of_ctus(first, last, cols)
+        self.slab = Slab(frame, ctu, search_range, row0, row1)
+
+    @property
+    def n_ctus(self):
+        return self.last - self.first
+
+
+def hip_ctus_fn(device=None):
+    """run_fn backed by hevcasm_hip_me_full_search_frame_ctus (uploads the run's slab, searches the run)."""
+    import torch
+    from . import batch as B
+
+    def fn(run):
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        sl = run.slab
+        cur_d, ref_d = torch.from_numpy(sl.cur).to(dev), torch.from_numpy(sl.ref).to(dev)
+        out = B.me_full_search_frame_ctus(cur_d, sl.cur_byte0, sl.stride_cur, ref_d, sl.ref_byte0, sl.stride_ref,
+                                          sl.frame_w, sl.frame_h, sl.ctu, sl.range, run.first, run.n_ctus)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    return fn
+
+
+def search_rank_ctus(frame, ctu, search_range, rank, world, run_fn):
+    """One rank's share of a frame when the split is by CTUs: -> (first, last, int32[n, 3])"""
+    rows, cols = -(-frame["h"] // ctu), -(-frame["w"] // ctu)
+    first, last = shard.ctu_range(rows * cols, rank, world)
+    if first == last:
+        return first, last, np.zeros((0, 3), dtype=np.int32)
+    return first, last, np.asarray(run_fn(CtuRun(frame, ctu, search_range, first, last)), dtype=np.int32)
+
+
+def assemble_ctus(parts, frame_w, frame_h, ctu):
+    """[(first, last, results)] from every rank -> the frame's table; checks that the runs tile the frame exactly once."""
+    rows, cols = -(-frame_h // ctu), -(-frame_w // ctu)
+    out = np.full((rows * cols, 3), np.iinfo(np.int32).min, dtype=np.int32)
+    seen = np.zeros(rows * cols, dtype=bool)
+    for first, last, res in parts:
+        assert not seen[first:last].any(), "CTUs %d..%d assigned twice" % (first, last)
+        seen[first:last] = True
+        out[first:last] = np.asarray(res).reshape(-1, 3)
+    assert seen.all(), "CTUs without an owner"
+    return out
+
+
 def hip_rows_fn(device=None, stream_sync=True):
     """rows_fn backed by hevcasm_hip_me_full_search_frame_rows: uploads the slab it is given (the rank's H2D copy, halo
     included) and searches it.  Returns (fn, state) -- state keeps the device tensors for repeated timing."""

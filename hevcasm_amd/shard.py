@@ -40,3 +40,17 @@ def me_slab_rows(frame_h, ctu, search_range, row0, row1):
         raise ValueError("CTU rows %d..%d outside a frame of %d rows" % (row0, row1, frame_h))
     y0, y1 = row0 * ctu, min(row1 * ctu, frame_h)
     return y0, y1, y0 - search_range, y1 + search_range
+
+
+def ctu_range(n_ctus, rank, world_size):
+    """Config #5, balanced to one CTU instead of one row: rank r owns CTUs [first, last) of the frame in raster order (34 rows of
+    60 CTUs over 8 ranks: 255 each, where whole rows are 300 or 240).  The rank then holds every CTU row its run touches -- a row
+    that two ranks share is held by both -- plus the halo (me_slab_rows on those rows)."""
+    return shard_range(n_ctus, rank, world_size)
+
+
+def rows_of_ctus(first, last, cols):
+    """CTU rows [row0, row1) that the raster run [first, last) touches (empty run: (row, row))."""
+    if last <= first:
+        return first // cols, first // cols
+    return first // cols, (last - 1) // cols + 1

@@ -243,6 +243,14 @@ int hevcasm_hip_me_full_search_frame_rows(
 	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
 	int frame_w, int frame_h, int ctu, int range, int row0, int row1, int *result, void *stream);
 
+/* The same for a run of n_ctus CTUs in raster order starting at CTU first_ctu of the frame (0 = top left), which need not
+ * begin or end on a row: a split by CTUs balances ranks to one CTU where a split by rows balances them to one row (34 rows
+ * over 8 GPUs are 5 or 4 rows each; 2040 CTUs are 255 each).  `cur` and `ref` point at the pixel in column 0 of the CTU row
+ * that holds first_ctu; the caller holds every row the run touches, and the halo around them. */
+int hevcasm_hip_me_full_search_frame_ctus(
+	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream);
+
 /* ---- fused quarter-pel refinement ------------------------------------- */
 
 /* For each block: the 49 luma quarter-pel displacements (qx, qy) in [-3, 3]^2 around the

@@ -285,6 +285,11 @@ def test_full_search_4k_frame_equals_oracle():
     parts = [me_frame.search_rank(f, 64, 64, rank, 8, fn) for rank in range(8)]
     assert [p[1] - p[0] for p in parts] == [5, 5, 4, 4, 4, 4, 4, 4]
     cases.assert_same("me 4K frame, 8 slabs", (me_frame.assemble(parts, 3840, 2160, 64),), (want,))
+    # and split by CTUs (255 per rank: runs that begin and end inside a row, launches small enough to be cut into parts)
+    fn = me_frame.hip_ctus_fn()
+    parts = [me_frame.search_rank_ctus(f, 64, 64, rank, 8, fn) for rank in range(8)]
+    assert [p[1] - p[0] for p in parts] == [255] * 8
+    cases.assert_same("me 4K frame, 8 runs of 255 CTUs", (me_frame.assemble_ctus(parts, 3840, 2160, 64),), (want,))
 
 
 def test_full_search_frame_rows_ragged_edges():
@@ -302,6 +307,9 @@ def test_full_search_frame_rows_ragged_edges():
         fn = me_frame.hip_rows_fn()
         parts = [me_frame.search_rank(f, ctu, r, rank, world, fn) for rank in range(world)]
         cases.assert_same("me frame %dx%d ctu %d +-%d x%d" % (fw, fh, ctu, r, world), (me_frame.assemble(parts, fw, fh, ctu),), (want,))
+        fn = me_frame.hip_ctus_fn()
+        parts = [me_frame.search_rank_ctus(f, ctu, r, rank, world + 1, fn) for rank in range(world + 1)]
+        cases.assert_same("me frame %dx%d ctu %d +-%d, %d runs" % (fw, fh, ctu, r, world + 1), (me_frame.assemble_ctus(parts, fw, fh, ctu),), (want,))
 
 
 def test_subpel_refine_equals_unfused_composition():

@@ -117,6 +117,34 @@ def test_me_frame_splits_equal_the_unsharded_search():
             assert np.array_equal(me_frame.assemble(parts, fw, fh, ctu), want), (fw, fh, world)
 
 
+def _oracle_run_fn(run):
+    """A rank's run of CTUs on the CPU: the oracle over exactly those CTUs, on private copies of the slab's rows."""
+    from hevcasm_amd import me_frame
+    from oracle import pyoracle
+    sl = run.slab
+    cur, ref = sl.cur.copy(), sl.ref.copy()
+    out = np.zeros((sl.n_ctus, 3), dtype=np.int32)
+    for j in me_frame.ctu_jobs(sl.frame_h, sl.frame_w, sl.ctu, sl.stride_cur, sl.stride_ref, sl.pad, sl.row0, sl.row1, cur_row_base=sl.y0, ref_row_base=sl.ref_row_base):
+        out[j["index"]] = pyoracle.me_full_search(cur, sl.stride_cur, ref, sl.stride_ref, j["cur_off"], j["ref_off"], j["w"], j["h"], sl.range)
+    a = run.first - sl.row0 * run.cols          # the run inside the slab's CTUs
+    return out[a: a + run.n_ctus]
+
+
+def test_me_frame_splits_by_ctu_equal_the_unsharded_search():
+    """The split balanced to one CTU (shard.ctu_range): runs that begin and end in the middle of a row, a row shared by two or
+    three ranks, more ranks than CTUs."""
+    from hevcasm_amd import me_frame
+    from hevcasm_amd.shard import ctu_range, rows_of_ctus
+    assert [ctu_range(2040, r, 8) for r in range(8)][:2] == [(0, 255), (255, 510)]
+    assert rows_of_ctus(255, 510, 60) == (4, 9) and rows_of_ctus(0, 60, 60) == (0, 1) and rows_of_ctus(7, 7, 60) == (0, 0)
+    for (fw, fh, ctu, r, worlds) in ((200, 240, 64, 64, (1, 2, 3, 5, 7, 16, 20)), (96, 80, 32, 20, (2, 4, 11))):
+        f = me_frame.synthetic_frame_pair(fw, fh, r, seed=fw + 1, ctu=ctu, max_motion=min(r, 30))
+        want = _whole_frame_oracle(f, ctu, r)
+        for world in worlds:
+            parts = [me_frame.search_rank_ctus(f, ctu, r, rank, world, _oracle_run_fn) for rank in range(world)]
+            assert np.array_equal(me_frame.assemble_ctus(parts, fw, fh, ctu), want), (fw, fh, world)
+
+
 _ME_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))

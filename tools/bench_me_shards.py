@@ -10,25 +10,30 @@ from hevcasm_amd import batch as B, me_frame, shard
 
 fw, fh, ctu, R, reps = 3840, 2160, 64, 64, 40
 f = me_frame.synthetic_frame_pair(fw, fh, R, seed=500)
-rows = -(-fh // ctu)
-for world in (1, 2, 4, 8):
-    worst = 0.0
-    per_rank = []
-    for rank in range(world):
-        r0, r1 = shard.ctu_row_range(rows, rank, world)
-        sl = me_frame.Slab(f, ctu, R, r0, r1)
-        cur, ref = torch.from_numpy(sl.cur).cuda(), torch.from_numpy(sl.ref).cuda()
-        out = torch.empty((sl.n_ctus, 3), dtype=torch.int32, device="cuda")
-        run = lambda: B.me_full_search_frame_rows(cur, sl.cur_byte0, sl.stride_cur, ref, sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, r0, r1, out=out)
-        for _ in range(3):
-            run()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            run()
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        per_rank.append(round(ms, 4))
-        worst = max(worst, ms)
-    print(json.dumps(dict(kernel="me frame split x%d" % world, size="4K +-64", ms=round(worst, 4), per_rank_ms=per_rank, frames_per_s=round(1e3 / worst, 1),
-                          speedup_over_one_rank=None)), flush=True)
+rows, cols = -(-fh // ctu), -(-fw // ctu)
+for unit in ("rows", "ctus"):
+    for world in (1, 2, 4, 8):
+        worst = 0.0
+        per_rank = []
+        for rank in range(world):
+            if unit == "rows":
+                r0, r1 = shard.ctu_row_range(rows, rank, world)
+                first, last = r0 * cols, r1 * cols
+            else:
+                first, last = shard.ctu_range(rows * cols, rank, world)
+                r0, r1 = shard.rows_of_ctus(first, last, cols)
+            sl = me_frame.Slab(f, ctu, R, r0, r1)
+            cur, ref = torch.from_numpy(sl.cur).cuda(), torch.from_numpy(sl.ref).cuda()
+            out = torch.empty((last - first, 3), dtype=torch.int32, device="cuda")
+            run = lambda: B.me_full_search_frame_ctus(cur, sl.cur_byte0, sl.stride_cur, ref, sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, first, last - first, out=out)
+            for _ in range(3):
+                run()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            per_rank.append(round(ms, 4))
+            worst = max(worst, ms)
+        print(json.dumps(dict(kernel="me frame split by %s x%d" % (unit, world), size="4K +-64", ms=round(worst, 4), per_rank_ms=per_rank, frames_per_s=round(1e3 / worst, 1))), flush=True)
