@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	constexpr int BEFORE = TAPS / 2 - 1;
 	constexpr int CPL = 4 * NDW;            // window / output columns per lane
 	typedef RefStream<TAPS, NDW, AHEAD> Stream;
-	static_assert(TAPS % AHEAD == 0, "the look-ahead ring must divide the unroll");
+	static_assert(TAPS % AHEAD == 0 || AHEAD % TAPS == 0, "the look-ahead ring and the unroll must divide one another");
+	constexpr int UNROLL = AHEAD > TAPS ? AHEAD : TAPS;     // slot indices (i % TAPS, i % AHEAD) are static after unrolling by this
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
@@ -515,24 +516,25 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 		// No branch stands between the loads, so the compiler knows how many are in flight at every use and waits for exactly the
 		// one it needs (s_waitcnt vmcnt(N)); with a branch around a load it waits for ALL of them at the top of every group of T
 		// rows -- the whole memory latency once per T rows (that is what the general loop below still does).
-		static_assert(AHEAD == TAPS, "the load pattern of the branch-free loop");
-		const int groups = H / TAPS;
+		static_assert(AHEAD >= TAPS, "the load pattern of the branch-free loop");
+		// (AHEAD = 2 T: a 16-row luma PU has its whole 23-row window in flight before its first row is computed)
+		const int groups = H / UNROLL;
 		int y = 0;
 		for (int g = 0; g < groups - 1; ++g)
 		{
 #pragma unroll
-			for (int i = 0; i < TAPS; ++i) output_row(Flag<true>(), Flag<true>(), i, y + i);
-			y += TAPS;
+			for (int i = 0; i < UNROLL; ++i) output_row(Flag<true>(), Flag<true>(), i, y + i);
+			y += UNROLL;
 		}
 #pragma unroll
-		for (int i = 0; i < TAPS; ++i) output_row(Flag<false>(), Flag<true>(), i, y + i);
+		for (int i = 0; i < UNROLL; ++i) output_row(Flag<false>(), Flag<true>(), i, y + i);
 	}
 	else
 	{
-		for (int y0 = 0; y0 < H; y0 += TAPS)
+		for (int y0 = 0; y0 < H; y0 += UNROLL)
 		{
 #pragma unroll
-			for (int i = 0; i < TAPS; ++i)
+			for (int i = 0; i < UNROLL; ++i)
 			{
 				const int y = y0 + i;
 				if (y < H)   // wave-uniform
@@ -565,8 +567,16 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	const uint32_t grid = ceil_div(waves / (size_t)p2.count, (size_t)(kThreads / kWave));
 	// TAPS window rows in flight per reference (the ring then turns once per unrolled group)
 	static const bool no_fast = getenv("HEVCASM_PRED_NOFAST") != nullptr;   // A/B switch for the measurements in profiles/
+	static const bool no_deep = getenv("HEVCASM_PRED_NODEEP") != nullptr;   // A/B switch: T rows in flight everywhere
 	if (NDW == 1 && W < 4)   // a zero-xFrac window is narrower than the 4-byte lane load: those lanes load byte by byte
 		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, NDW == 1, false>), dim3(grid, p2.count), dim3(kThreads), 0, st,
+				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
+	// 2 T window rows in flight instead of T where the rows per wave are a multiple of 2 T: a 16-row luma PU then has its whole 23-row window
+	// requested before its first row is computed.  Same box, 64 frames per launch (profiles/r03_pred_deep_ab.txt): luma uni 16-wide -10 ... -13 %,
+	// 8- / 24-wide -9 ... -10 %, 32- / 48-wide -4 ... -7 %, 64-wide -0 ... -2 %; chroma -2 ... -16 % (mean -3 %); luma bi +6 ... +12 % (205 registers, two waves
+	// per SIMD instead of three): not there.
+	else if ((TAPS == 4 || !BI) && !no_deep && W % 4 == 0 && (H >> log2_segments) % (2 * TAPS) == 0 && !no_fast)
+		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, 2 * TAPS, false, true>), dim3(grid, p2.count), dim3(kThreads), 0, st,
 				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
 	else if (W % 4 == 0 && (H >> log2_segments) % TAPS == 0 && !no_fast)
 		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, TAPS, false, true>), dim3(grid, p2.count), dim3(kThreads), 0, st,
