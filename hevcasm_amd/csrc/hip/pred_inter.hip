@@ -575,6 +575,7 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	// requested before its first row is computed.  Same box, 64 frames per launch (profiles/r03_pred_deep_ab.txt): luma uni 16-wide -10 ... -13 %,
 	// 8- / 24-wide -9 ... -10 %, 32- / 48-wide -4 ... -7 %, 64-wide -0 ... -2 %; chroma -2 ... -16 % (mean -3 %); luma bi +6 ... +12 % (205 registers, two waves
 	// per SIMD instead of three): not there.
+	// (Also measured: 4 T = 32 rows in flight for 32- and 64-row luma PUs, 163 registers: +-1 %; luma bi with 4-byte lanes and 2 T rows, 128 registers: +8 %.)
 	else if ((TAPS == 4 || !BI) && !no_deep && W % 4 == 0 && (H >> log2_segments) % (2 * TAPS) == 0 && !no_fast)
 		hipLaunchKernelGGL((pred_stream_kernel<TAPS, NDW, BI, 2 * TAPS, false, true>), dim3(grid, p2.count), dim3(kThreads), 0, st,
 				dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, lw, ppw, (uint32_t)n, log2_segments, p2.dst, p2.ref0, p2.ref1);
