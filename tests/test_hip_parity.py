@@ -650,7 +650,9 @@ def test_bottom_up_planes_every_strided_family():
         return ((rows - 1 - o // stride) * stride + o % stride).astype(np.uint32)
 
     for taps, w, h, bi in ((8, 16, 16, False), (8, 64, 64, True), (8, 8, 4, False), (4, 4, 8, True), (8, 12, 16, False), (4, 2, 4, False),
-                           (8, 5, 3, False), (8, 32, 32, True), (4, 16, 16, False)):
+                           (8, 5, 3, False), (8, 32, 32, True), (4, 16, 16, False),
+                           # the strip kernel (4 taps, W <= 8 or 16; 8 rows in flight where H % 8 == 0) and the 16-rows-in-flight luma loop
+                           (4, 8, 8, True), (4, 6, 8, False), (4, 8, 16, True), (4, 3, 5, False), (4, 16, 4, True), (8, 16, 32, False), (8, 24, 32, False)):
         c = wl.pred_case(taps, w, h, 37, 4242 + w, bi=bi, frame=(max(2 * w, 64), max(3 * h, 64)))
         fam = "pred_bi" if bi else "pred_uni"
         f = dict(c)
