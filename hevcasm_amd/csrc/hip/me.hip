@@ -24,7 +24,13 @@ namespace hevc {
 // one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
 struct MeFrame { int cols, ctu, frame_w, slab_h, first; };    // first: the launch's first CTU, counted in raster order from column 0 of the slab's first CTU row
 
-__device__ __forceinline__ unsigned long long *me_key_slot(int *result, uint32_t k) { return reinterpret_cast<unsigned long long *>(result + 3 * (size_t)k + (k & 1u)); }
+// the 8-byte-aligned 8 bytes inside block k's 12-byte result slot: its first 8 bytes or its last 8, whichever the ADDRESS makes aligned
+// (result itself need only be int-aligned)
+__device__ __forceinline__ unsigned long long *me_key_slot(int *result, uint32_t k)
+{
+	int *slot = result + 3 * (size_t)k;
+	return reinterpret_cast<unsigned long long *>(slot + ((reinterpret_cast<uintptr_t>(slot) >> 2) & 1u));
+}
 
 // W64: every block of the launch is 64 wide (the common case: CTUs) -- the row loops then have constant trip counts and unroll.
 // parts (1 .. 8): workgroups per block.  A block's candidates cost 1.15 M SIMD-cycles of v_qsad, i.e. a whole CU for 119 us, however
@@ -254,8 +260,8 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	}
 }
 
-// several workgroups per block: the 8-byte-aligned 8 bytes inside block k's 12-byte result slot (the first 8 when k is even, the last 8 when odd)
-// hold the running minimum key, preset to all ones; this turns them into the result
+// several workgroups per block: the 8-byte-aligned 8 bytes inside block k's 12-byte result slot (me_key_slot) hold the running minimum key,
+// preset to all ones; this turns them into the result
 __global__ __launch_bounds__(kThreads) void me_decode_kernel(int *result, uint32_t n_blocks, int R)
 {
 	const uint32_t k = blockIdx.x * kThreads + threadIdx.x;

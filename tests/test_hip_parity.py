@@ -292,6 +292,23 @@ def test_full_search_4k_frame_equals_oracle():
     cases.assert_same("me 4K frame, 8 runs of 255 CTUs", (me_frame.assemble_ctus(parts, 3840, 2160, 64),), (want,))
 
 
+def test_full_search_result_buffer_need_only_be_int_aligned():
+    """Small launches merge several workgroups' minima with a 64-bit atomic inside each block's 12-byte result slot: the slot's
+    aligned 8 bytes are found from the ADDRESS, so a result array that starts on an odd int (a view into a larger buffer) works."""
+    import torch
+    from hevcasm_amd import batch as B
+    c = [x for x in cases.me_cases() if x[0] == "me_64x64_r64_corners"][0][2]
+    want = cases.run_oracle("me", c)[0]
+    n = c["n"]
+    for shift in (0, 1, 2, 3):
+        big = torch.full((3 * n + 8,), 77, dtype=torch.int32, device="cuda")
+        out = big[shift: shift + 3 * n].view(n, 3)
+        B.me_full_search(B.u8(c["src"]), c["stride_src"], B.u8(c["ref"]), c["stride_ref"], B.off32(c["src_off"]), B.off32(c["ref_off"]), c["w"], c["h"], c["range"], out=out)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy(), want), shift
+        assert int(big[:shift].eq(77).all()) and int(big[shift + 3 * n:].eq(77).all())        # nothing written beside the results
+
+
 def test_full_search_frame_rows_ragged_edges():
     """Frames whose width and height are not multiples of the CTU (right column, bottom row and the corner CTU are
     narrower / shorter), ranges that are not multiples of 16, more ranks than CTU rows: every split equals the oracle."""
