@@ -640,7 +640,7 @@ template <int AHEAD> struct StripStream4
 	{
 		const uint32_t a = min(off & ~3u, last_load);
 		where[slot] = off - a;
-		const u32x4 v = *reinterpret_cast<const u32x4 *>(plane + (size_t)a);      // dword-aligned
+		const u32x4 v = reinterpret_cast<const U4 *>(plane + (size_t)a)->v;      // dword-aligned when the plane base is (any base works)
 		pending[slot][0] = v.x; pending[slot][1] = v.y; pending[slot][2] = v.z; pending[slot][3] = v.w;
 		off = med3_u32(off + step, lo, hi);
 	}
