@@ -134,9 +134,9 @@ def host_cores(max_procs):
     except (OSError, ValueError):
         pass
     n = max(1, min(max_procs, usable))
-    note = "%d processes: os.cpu_count() = %d, usable by this process = %d" % (n, total, usable)
+    note = "%d procs; os.cpu_count()=%d, usable=%d" % (n, total, usable)
     if n < usable:
-        note += ", capped at %d (one GPU's share of the host on this pool; --cpu-procs to change)" % max_procs
+        note += ", capped at %d (--cpu-procs)" % max_procs
     return n, dict(host_cpus=total, usable_cpus=usable, note=note)
 
 
@@ -169,9 +169,7 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
     sad16 = sum(r[(16, 16, 1)] for r in per_proc)
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference", value_per_core=round(total / procs_n / 1e6, 3),
-                sample="reference C path (gcc -O3, HEVCASM_C_REF tables) via oracle/_ref/refdrv: %d processes x %d (size, ways) combos x %d blocks "
-                       "(cache-resident: this path is compute-bound at ~1 Mblock/s per core, residency does not move it) "
-                       "repeated for %d ms each, same size mix as the GPU step" % (procs_n, len(combos), sample_blocks, ms_each),
+                sample="reference C (refdrv, gcc -O3): %d procs x %d (size, ways) x %d blocks x %d ms, same mix" % (procs_n, len(combos), sample_blocks, ms_each),
                 sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3), **cores_info)
 
 
@@ -209,10 +207,138 @@ def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
     names = [n for n, bit in (("SSE2", capi.SSE2), ("AVX2", capi.AVX2)) if mask & bit]
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="port", value_per_core=round(total / procs_n / 1e6, 3),
-                sample="this library's host table entries (mask %#x: %s intrinsics kernels where the reference has x86 asm, C elsewhere), per-block calls, "
-                       "%d processes x %d (size, ways) combos x %d blocks (memory-resident, like the GPU's inputs) repeated for %d ms each, same size mix"
+                sample="host tables, mask %#x (%s intrinsics): %d procs x %d combos x %d blocks x %d ms, same mix"
                        % (mask, "/".join(names) or "no SIMD", procs_n, len(combos), sample_blocks, ms_each),
                 sad16x16_single_ref_mblocks_per_s=round(sum(r.get((16, 16, 1), 0.0) for r in per_proc) / 1e6, 3), **cores_info)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The driver's record keeps the SCALAR members of config / roofline / cpu_baseline and cuts strings at 120 characters (VERDICT
+# round 3): everything the metric names is therefore flattened into scalar keys; the row lists go to the top-level "detail".
+
+FAMILY_KEYS = {   # (family, kernel + size as bench_families reports them) -> key prefix
+    ("sad", "sad 16x16 single-ref"): "sad16",
+    ("inter_pred", "pred_uni_8tap 16x16"): "pred_uni_luma16", ("inter_pred", "pred_bi_8tap 16x16"): "pred_bi_luma16",
+    ("inter_pred", "pred_uni_4tap 8x8"): "pred_uni_chroma8_1plane", ("inter_pred", "pred_bi_4tap 8x8"): "pred_bi_chroma8_1plane",
+    ("inter_pred", "pred_uni_4tap Cb+Cr 8x8"): "pred_uni_chroma8", ("inter_pred", "pred_bi_4tap Cb+Cr 8x8"): "pred_bi_chroma8",
+    ("inter_pred_256f", "pred_uni_4tap Cb+Cr 8x8"): "pred_uni_chroma8_256f", ("inter_pred_256f", "pred_bi_4tap Cb+Cr 8x8"): "pred_bi_chroma8_256f",
+    ("inter_pred_256f", "pred_uni_8tap 16x16"): "pred_uni_luma16_256f", ("inter_pred_256f", "pred_bi_8tap 16x16"): "pred_bi_luma16_256f",
+    ("inter_pred_latency", "pred_uni_8tap 16x16"): "pred_uni_luma16_1frame", ("inter_pred_latency", "pred_bi_8tap 16x16"): "pred_bi_luma16_1frame",
+    ("inter_pred_latency", "pred_uni_4tap 8x8"): "pred_uni_chroma8_1frame", ("inter_pred_latency", "pred_bi_4tap 8x8"): "pred_bi_chroma8_1frame",
+    ("inter_pred_latency", "pred_uni frame graph 16x16 luma + 2 x 8x8 chroma"): "pred_uni_frame_graph",
+    ("inter_pred_latency", "pred_bi frame graph 16x16 luma + 2 x 8x8 chroma"): "pred_bi_frame_graph",
+}
+for _n in (8, 16, 32):
+    for _fam, _sfx in (("", ""), ("_large_launch", "_2p28")):
+        FAMILY_KEYS[("idct" + _fam, "inverse_transform_add dct%d" % _n)] = "idct%d%s" % (_n, _sfx)
+        FAMILY_KEYS[("idct" + _fam, "dequant_inverse_transform_add dct%d" % _n)] = "fused_idct%d%s" % (_n, _sfx)
+        FAMILY_KEYS[("fdct" + _fam, "transform dct%d" % _n)] = "fdct%d%s" % (_n, _sfx)
+
+
+def flatten_families(rows):
+    """roofline.per_family rows -> flat scalar keys: <prefix>_frac (of the 8 TB/s HBM peak), _gbs (algorithmic), _ms (per launch), _mblocks (per s)."""
+    out = {}
+    for r in rows or []:
+        if r.get("family") == "full_search":
+            out.update(me_frame_ms=r["ms"], me_frames_per_s=r["frames_per_s"], me_gsad_per_s=r["gsad_evals_per_s"], me_valu_frac=r["frac_of_valu"],
+                       me_valu_frac_nominal=r.get("frac_of_valu_nominal"), me_valu_peak_tdiffs=r["peak"], me_hbm_frac=r["frac"])
+            continue
+        key = FAMILY_KEYS.get((r.get("family"), r.get("kernel")))
+        if key is None:
+            continue
+        out[key + "_frac"] = r["frac"]
+        out[key + "_gbs"] = r["gbs"]
+        out[key + "_ms"] = r["ms"]
+        out[key + "_mblocks"] = r["mblocks_per_s"]
+    return out
+
+
+def scalars_only(d):
+    """What the driver's record keeps of a config / roofline / cpu_baseline object: scalar members, strings cut at 120 characters."""
+    out = {}
+    for k, v in (d or {}).items():
+        if isinstance(v, (dict, list, tuple)):
+            continue
+        out[k] = v[:120] if isinstance(v, str) else v
+    return out
+
+
+CPU_FAMILY_CASES = (   # key, what
+    ("pred_uni_luma16", ("pred", 8, 16, 16, False)), ("pred_bi_luma16", ("pred", 8, 16, 16, True)),
+    ("pred_uni_chroma8", ("pred", 4, 8, 8, False)), ("pred_bi_chroma8", ("pred", 4, 8, 8, True)),
+    ("idct8", ("inv", 3, False)), ("idct16", ("inv", 4, False)), ("idct32", ("inv", 5, False)), ("fused_idct32", ("inv", 5, True)),
+)
+
+
+def cpu_family_legs(budget_s, max_procs=16, sample_pus=8100):
+    """CPU baselines BESIDE inter prediction and the inverse transforms (north_star: "alongside ... timed on the node's host cores ... in
+    the same run"; SURVEY 8(d) "CPU beside it"), one process per usable core, same generators as the GPU rows:
+      ref_<key>_mblocks  the REFERENCE's own C table entries (pred_inter.c:154-228, :490-530; residual_decode.c:371-413, quantize.c:53-62 in
+                         front when fused) through oracle/_ref/refdrv;
+      simd_<key>_mblocks this library's host table entries under the host's x86 mask (intrinsics kernels where the reference has assembly),
+                         per-block calls, hevcasm_amd/lib/hevcasm_host_bench.
+    Samples: one 1080p frame's worth of PUs (8100 16x16 luma PUs; as many 8x8 chroma PUs), 2^19 coefficients per transform size."""
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    from hevcasm_amd import capi, workload as wl
+    from oracle import pyref
+    procs_n, _ = host_cores(max_procs)
+    out = {"family_cores": procs_n, "family_sample_pus": sample_pus, "family_sample_coeffs": 1 << 19}
+    ms_each = max(50, int(1000.0 * budget_s / 2 / len(CPU_FAMILY_CASES)))
+    if pyref.available():
+        cases = {}
+        for key, what in CPU_FAMILY_CASES:
+            if what[0] == "pred":
+                _, taps, w, h, bi = what
+                cases[key] = wl.pred_case(taps, w, h, sample_pus, 4000 + taps + bi, bi=bi, frame=(1920, 1080) if taps == 8 else (960, 540))
+            else:
+                cases[key] = wl.inverse_case(0, what[1], (1 << 19) >> (2 * what[1]), 4100 + what[1], "natural", frame=(wl.FRAME_W, wl.FRAME_H))
+
+        def ref_worker(_):
+            rates = {}
+            with pyref.RefProc() as p:
+                for key, what in CPU_FAMILY_CASES:
+                    c = cases[key]
+                    if what[0] == "pred":
+                        refs = 2 if what[4] else 1
+                        secs, n = p.bench_pred(what[1], c["dst_bytes"], c["stride_dst"], [c["ref%d" % r] for r in range(refs)], c["stride_ref"], c["dst_off"],
+                                               [c["ref%d_off" % r] for r in range(refs)], [c["frac%d" % r] for r in range(refs)], what[2], what[3], ms_each)
+                    else:
+                        secs, n = p.bench_inverse(0, what[1], c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"], c["pred_off"], c["coeffs"],
+                                                  ms_each, dequant=(51, 14) if what[2] else None)
+                    rates[key] = n / secs
+            return rates
+
+        with ThreadPoolExecutor(procs_n) as ex:
+            per = list(ex.map(ref_worker, range(procs_n)))
+        for key, _ in CPU_FAMILY_CASES:
+            out["ref_%s_mblocks" % key] = round(sum(r[key] for r in per) / 1e6, 4)
+    exe = os.path.join(os.path.dirname(capi.LIB_PATH), "hevcasm_host_bench")
+    if os.path.exists(exe):
+        mask = capi.lib().hevcasm_instruction_set_support() & ~capi.HIP
+        out["simd_mask"] = "%#x" % mask
+
+        def simd_worker(i):
+            rates = {}
+            for fam, blocks in (("pred", sample_pus), ("inv", (1 << 19) >> 6)):
+                o = subprocess.run([exe, "%x" % mask, str(ms_each), str(blocks), str(77 + i), fam], capture_output=True, text=True,
+                                   env=dict(os.environ, HEVCASM_DISABLE_HIP="1"), timeout=600)
+                if o.returncode != 0:
+                    raise RuntimeError("hevcasm_host_bench %s failed: %s" % (fam, o.stderr[-300:]))
+                for line in o.stdout.splitlines():
+                    t = line.split()
+                    if t[0].startswith("pred"):
+                        key = "%s_%s" % (t[0], "luma16" if t[1] == "8" else "chroma8")
+                    else:
+                        key = ("fused_idct%d" if t[2] == "1" else "idct%d") % (1 << int(t[1]))
+                    rates[key] = int(t[-2]) / float(t[-1])
+            return rates
+
+        with ThreadPoolExecutor(procs_n) as ex:
+            per = list(ex.map(simd_worker, range(procs_n)))
+        for key in per[0]:
+            out["simd_%s_mblocks" % key] = round(sum(r[key] for r in per) / 1e6, 4)
+    return out
 
 
 def main():
@@ -223,6 +349,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=1 << 20, help="blocks per size per GPU (config #2: 1 Mi)")
     ap.add_argument("--sizes", default="all", help="'all' (20 sizes >= 8x8) or a comma list like 16x16,64x64")
     ap.add_argument("--cpu-seconds", type=float, default=16.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--cpu-sample-blocks", type=int, default=8192, help="blocks per size and process of BOTH CPU columns (memory-resident at the default)")
     ap.add_argument("--cpu-procs", type=int, default=16, help="host processes of the CPU baseline legs (one GPU's share of the host)")
     ap.add_argument("--no-families", action="store_true", help="skip the per-family measurements (inter prediction, transforms, full search) after the timed region")
     ap.add_argument("--me-split", default="ctus", choices=("rows", "ctus"), help="me5: ranks own raster runs of CTUs balanced to one CTU (default; each still holds whole CTU rows + halo), or whole CTU rows")
@@ -300,10 +427,15 @@ def main():
     # per-kernel durations from the HIP events recorded inside the timed region
     per = {}
     for key, n, e0, e1 in events:
-        d = per.setdefault(key, dict(ms=0.0, launches=0, blocks=0))
-        d["ms"] += e0.elapsed_time(e1)
+        d = per.setdefault(key, dict(ms=0.0, launches=0, blocks=0, each=[]))
+        t = e0.elapsed_time(e1)
+        d["ms"] += t
+        d["each"].append(t)
         d["launches"] += 1
         d["blocks"] += n
+    # the step as the sum of its launches' event times, step by step: median and min beside the mean the contract's value is made of
+    per_step = len(events) // max(1, args.steps)
+    step_ms = [sum(e0.elapsed_time(e1) for (_, _, e0, e1) in events[i * per_step:(i + 1) * per_step]) for i in range(args.steps)]
     detail = []
     for (w, h, ways), d in per.items():
         bytes_total = algorithmic_bytes(w, h, ways) * d["blocks"]
@@ -311,6 +443,7 @@ def main():
         detail.append(dict(kernel="sad_multiref_4" if ways == 4 else "sad", size="%dx%d" % (w, h), ms_per_pass=round(d["ms"] / args.steps, 4),
                            launches_per_pass=d["launches"] // args.steps, mblocks_per_s=round(d["blocks"] / (d["ms"] * 1e-3) / 1e6, 1),
                            algorithmic_gb_per_s=round(gbs, 1), frac_of_hbm_peak=round(gbs / HBM_PEAK_GBS, 4), total_ms=d["ms"],
+                           launch_ms_median=round(float(np.median(d["each"])), 4), launch_ms_min=round(min(d["each"]), 4),
                            bytes_per_block=algorithmic_bytes(w, h, ways)))
     dom = max(detail, key=lambda r: r["total_ms"])
     dom_key = (int(dom["size"].split("x")[0]), int(dom["size"].split("x")[1]), 4 if dom["kernel"] != "sad" else 1)
@@ -346,51 +479,69 @@ def main():
         try:
             per_family = measure_families()
         except Exception as e:   # noqa: BLE001 -- a failure here must not cost the line its timed result
-            fam_error = repr(e)[:300]
+            fam_error = repr(e)[:110]
 
     if rank == 0:
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(sizes, 2048, args.cpu_seconds, args.cpu_procs)
-            if cpu:
-                cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
-                # 16 Ki blocks per size and process: 16 processes x up to 260 MB of frames, beyond the host's last-level cache, so that this
-                # column is a memory-resident figure like the GPU's (with 2 Ki blocks everything sits in L3 and the figure doubles)
+            cpu = cpu_baseline(sizes, args.cpu_sample_blocks, args.cpu_seconds, args.cpu_procs)
+        if cpu:
+            cpu["gpu_multiple"] = round(value / cpu["value"], 1)      # this GPU run / the host cores above, same mix
+            cpu["sample_blocks"] = args.cpu_sample_blocks
+        # the host-SIMD column is measured whether or not the reference build is there: same block count per size as the
+        # reference column (16 Ki blocks per size and process = up to 260 MB of frames per process: memory-resident, like the GPU's inputs)
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu or dict(value=None, unit="Mblocks/s", cores=0, kind="port", sample="reference build (oracle/_ref/refdrv) absent: host-SIMD column only")
+            try:
+                simd = host_simd_baseline(sizes, args.cpu_sample_blocks, min(args.cpu_seconds, 8.0), args.cpu_procs)
+                if simd:
+                    cpu.update(simd_value=simd["value"], simd_cores=simd["cores"], simd_gpu_multiple=round(value / simd["value"], 1),
+                               simd_sad16_mblocks=simd["sad16x16_single_ref_mblocks_per_s"], simd_sample=simd["sample"])
+            except Exception as e:   # noqa: BLE001 -- a host-side failure must not discard the GPU result
+                cpu["simd_error"] = repr(e)[:110]
+            if not args.no_families:
                 try:
-                    simd = host_simd_baseline(sizes, 16384, min(args.cpu_seconds, 8.0), args.cpu_procs)
-                    if simd:
-                        simd["gpu_multiple"] = round(value / simd["value"], 1)
-                except Exception as e:   # noqa: BLE001 -- a host-side failure must not discard the GPU result
-                    simd = dict(value=None, error=repr(e)[:300])
-                cpu["simd"] = simd
+                    cpu.update(cpu_family_legs(min(args.cpu_seconds, 10.0), args.cpu_procs))
+                except Exception as e:   # noqa: BLE001
+                    cpu["family_error"] = repr(e)[:110]
         head = head[0] if head else None
         if per_family is not None and head:
             per_family.insert(0, dict(family="sad", kernel="sad 16x16 single-ref", config="#2, inside the timed region", ms=head["ms_per_pass"], mblocks_per_s=head["mblocks_per_s"],
                                       gbs=head["algorithmic_gb_per_s"], frac=head["frac_of_hbm_peak"], bytes_per_block=head["bytes_per_block"]))
+        flat = flatten_families(per_family)
+        if cpu:   # GPU rate over the CPU legs of the same family (Mblocks/s both)
+            for key, _ in CPU_FAMILY_CASES:
+                g = flat.get(key + "_mblocks")
+                for col in ("ref", "simd"):
+                    c = cpu.get("%s_%s_mblocks" % (col, key))
+                    if g and c:
+                        cpu["%s_%s_gpu_multiple" % (col, key)] = round(g / c, 1)
+        roofline = {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
+                    "launch_ms_median": dom["launch_ms_median"], "launch_ms_min": dom["launch_ms_min"],
+                    "bytes_per_block": algorithmic_bytes(*dom_key),
+                    # what a plain read stream reaches on this part (profiles/r01_hbm_stream.txt: tools/ubench/hbm_stream.hip, 4.3 GB, streaming loads)
+                    "measured_read_stream_gbs": 7043.6,
+                    "traffic_over_stream": round(traffic / dom_avg_s / 1e9 / 7043.6, 4) if traffic else None,
+                    # SURVEY 8(d)'s literal 5WH+16 counts the four overlapping candidates as disjoint: what it would read
+                    "survey_5wh16_gbs": round((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9, 1) if dom_key[2] == 4 else None,
+                    "note": "4-way priced at COMPULSORY bytes (src + plane share + descriptors): candidates overlap; see DESIGN.md 5",
+                    "per_family_error": fam_error}
+        roofline.update(flat)     # every other kernel the metric and BASELINE.json's configs name: same run, outside the timed region, scalar keys
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
             "value": round(value, 1), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: batched SAD + 4-way multiref SAD, %d block sizes %s, %d blocks per size per GPU, "
-                                   "ref displaced +-7 px, device-resident frames" % (len(sizes), "8x8..64x64" if args.sizes == "all" else args.sizes, args.blocks),
+            "config": {"workload": "configs[1]: SAD + 4-way SAD, %d sizes %s, %d blocks/size/GPU, ref +-7 px, frames in HBM"
+                                   % (len(sizes), "8x8..64x64" if args.sizes == "all" else args.sizes, args.blocks),
                        "blocks_per_step_per_gpu": blocks_per_step, "launches_per_step": n_launches, "parallelism": "batch split x%d, no collectives" % world,
-                       "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1), **library_record()},
-            "roofline": {"bound": "hbm", "kernel": "%s %s" % (dom["kernel"], dom["size"]), "achieved": round(dom_bytes / dom_avg_s / 1e9, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(dom_bytes / dom_avg_s / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(dom_bytes), "avg_launch_ms": round(dom_avg_s * 1e3, 4),
-                         "bytes_per_block": algorithmic_bytes(*dom_key),
-                         # what a plain read stream reaches on this part (profiles/r01_hbm_stream.txt: tools/ubench/hbm_stream.hip, 4.3 GB, streaming loads)
-                         "measured_read_stream_gbs": 7043.6,
-                         "traffic_over_stream": round(traffic / dom_avg_s / 1e9 / 7043.6, 4) if traffic else None,
-                         "note": "4-way kernels are priced at their COMPULSORY bytes (source block + the block's share of the reference plane + "
-                                 "descriptors and results): the four candidates overlap and HBM sees each plane byte once (traffic = measured HBM "
-                                 "bytes per launch, rocprofv3 PMC passes); SURVEY 8(d)'s 5WH+16 counts the candidates as disjoint and would read %.0f GB/s"
-                                 % ((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9) if dom_key[2] == 4 else None,
-                         # every other kernel the metric and BASELINE.json's configs name, same run, outside the timed region
-                         "per_family": per_family, "per_family_error": fam_error},
+                       "frame": "%dx%d" % (wl.FRAME_W, wl.FRAME_H), "input_generation_s": round(gen_s, 1),
+                       "step_ms_median": round(float(np.median(step_ms)), 3), "step_ms_min": round(min(step_ms), 3), **library_record()},
+            "roofline": roofline,
             "cpu_baseline": cpu,
-            "detail": detail,
+            "detail": detail, "per_family": per_family,
         }
         print(json.dumps(line))
     if world > 1:
@@ -436,6 +587,8 @@ def measure_families():
     fam.SINK = []
     fam.bench_pred(frames=64, only=((16, 16),))            # luma 8-tap 16x16 + chroma 4-tap 8x8, uni and bi, all fractional phases
     collect("#3, 64 frames of 1080p per launch", lambda r: "inter_pred")
+    fam.bench_pred(frames=256, only=((16, 16),))           # the same rows at 4x the PUs per launch: ramp-up and tail against the steady state
+    collect("#3, 256 frames of 1080p per launch", lambda r: "inter_pred_256f")
     fam.bench_pred_latency()                                  # the same PUs, ONE frame per launch; and luma + Cb + Cr of a frame as one HIP graph
     collect("#3, one 1080p frame", lambda r: "inter_pred_latency")
     fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32
@@ -450,7 +603,8 @@ def measure_families():
                      gbs=round(me["bytes"] / me["ms"] / 1e6, 1), frac=round(me["bytes"] / me["ms"] / 1e6 / HBM_PEAK_GBS, 4),
                      bound="valu", gsad_evals_per_s=round(me["sad_evals"] / me["ms"] / 1e6, 2),
                      achieved=round(me["byte_diffs"] / me["ms"] / 1e9, 2), peak=round(peak, 1), unit="T byte differences/s",
-                     frac_of_valu=round(me["byte_diffs"] / me["ms"] / 1e9 / peak, 4), peak_source=src))
+                     frac_of_valu=round(me["byte_diffs"] / me["ms"] / 1e9 / peak, 4), peak_source=src,
+                     frac_of_valu_nominal=round(me["byte_diffs"] / me["ms"] / 1e9 / NOMINAL_QSAD_TBYTEDIFFS, 4)))
     torch.cuda.empty_cache()
     return rows
 
@@ -541,6 +695,7 @@ def bench_me5(args, rank, world, device):
     part = (first, last, slabs[0]["out"].cpu().numpy() if slabs else np.zeros((0, 3), dtype=np.int32))
     table = gather_me_results(part, fw, fh, ctu, device=device if world > 1 and dist.get_backend() == "nccl" else "cpu", unit="ctus")
 
+    exit_code = 0
     if rank == 0:
         n_ctus = rows * cols
         heights = [min(ctu, fh - r * ctu) for r in range(rows)]
@@ -555,28 +710,38 @@ def bench_me5(args, rank, world, device):
         if args.cpu_seconds > 0:
             cpu = me_cpu_baseline(frames0, table, ctu, R, min(args.cpu_seconds, 12.0), args.cpu_procs)
         value = n_ctus * args.steps / elapsed / 1e6
+        achieved = my_diffs / (kernel_ms * 1e-3) / 1e12
+        checked = (cpu or {}).get("checked_ctus")
+        mismatches = (cpu or {}).get("mismatches")
         line = {
             "metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak",
             "value": round(value, 4), "unit": "Mblocks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[4]: full-search motion estimation, SAD over +-64, one 3840x2160 frame per step = 2040 CTUs "
-                                   "(33 rows of 64x64, one of 64x48); a block = one CTU = 16 641 SAD evaluations",
-                       "parallelism": "%s split x%d (rank 0: CTUs %d..%d = rows %d..%d), each rank holds the rows of its CTUs + the +-64-row halo of the reference; no data-path collective"
-                                      % ("CTU rows" if args.me_split == "rows" else "CTU runs", world, first, last, row0, row1),
+            # valid: the GPU's answers equal the reference's on every CTU checked; null when the check did not run (no refdrv, --cpu-seconds 0)
+            "valid": None if checked is None else mismatches == 0,
+            "config": {"workload": "configs[4]: full search +-64, 3840x2160 frame/step = 2040 CTUs (33 rows 64x64 + one 64x48); block = CTU",
+                       "parallelism": "%s split x%d, rows + 64-row halo per rank, no collective" % ("CTU rows" if args.me_split == "rows" else "CTU runs", world),
+                       "me_split": args.me_split, "ctus_per_rank": last - first, "rank0_first_ctu": first, "rank0_rows": "%d..%d" % (row0, row1),
+                       "slowest_rank_ms": round(elapsed / args.steps * 1e3, 4), "rank0_kernel_ms": round(kernel_ms, 4),
                        "frames_per_s": round(args.steps / elapsed, 1), "gsad_evals_per_s": round(sad_evals * args.steps / elapsed / 1e9, 2), **library_record()},
-            "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": round(my_diffs / (kernel_ms * 1e-3) / 1e12, 2), "peak": round(peak, 1),
-                         "unit": "T byte differences/s", "frac": round(my_diffs / (kernel_ms * 1e-3) / 1e12 / peak, 4), "traffic": None,
-                         "avg_launch_ms": round(kernel_ms, 4), "peak_source": peak_src,
-                         "hbm": {"algorithmic_bytes_per_frame": alg_bytes, "gbs": round(alg_bytes * args.steps / elapsed / 1e9, 1),
-                                 "frac_of_hbm_peak": round(alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5)},
-                         "note": "full search is bound by the issue rate of the byte-SAD instruction, not by HBM (1.7 k byte differences per byte fetched); "
-                                 "achieved = rank 0's byte differences per launch / its average launch duration (HIP events around the timed launches)"},
+            "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": round(achieved, 2), "peak": round(peak, 1),
+                         "unit": "T byte differences/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac_nominal": round(achieved / NOMINAL_QSAD_TBYTEDIFFS, 4), "peak_nominal": round(NOMINAL_QSAD_TBYTEDIFFS, 1),
+                         "avg_launch_ms": round(kernel_ms, 4), "peak_source": peak_src[:118],
+                         "hbm_algorithmic_bytes_per_frame": alg_bytes, "hbm_gbs": round(alg_bytes * args.steps / elapsed / 1e9, 1),
+                         "hbm_frac": round(alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                         "note": "bound by the v_qsad_pk_u16_u8 issue rate, not HBM (1.7 k byte differences per byte fetched); rank 0's launches"},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
+        if mismatches:
+            print("bench.py: %d of %d CTUs differ from the reference's hevcasm_sad composition" % (mismatches, checked), file=sys.stderr)
+            exit_code = 1
     if world > 1:
         dist.destroy_process_group()
+    if exit_code:
+        sys.exit(exit_code)
 
 
 def me_cpu_baseline(frame, gpu_table, ctu, R, budget_s, max_procs):
@@ -619,9 +784,8 @@ def me_cpu_baseline(frame, gpu_table, ctu, R, budget_s, max_procs):
     bad = [idx for _, o in res for idx, r in o if not np.array_equal(r, gpu_table[idx])]
     return dict(value=round(rate / 1e6, 6), unit="Mblocks/s", cores=procs_n, kind="reference", ctus_per_s=round(rate, 2),
                 gsad_evals_per_s=round(rate * (2 * R + 1) ** 2 / 1e9, 4),
-                sample="reference hevcasm_sad (C path, gcc -O3, via oracle/_ref/refdrv) composed per candidate over +-%d: %d CTUs of the frame (a stride over "
-                       "all rows incl. the 64x48 bottom row), %d processes, up to %.0f s each" % (R, n, procs_n, budget_s),
-                checked_against_gpu=dict(ctus=n, mismatches=len(bad)), **cores_info)
+                sample="reference hevcasm_sad (refdrv) per candidate, +-%d: %d CTUs (stride over all rows), %d procs, <= %.0f s each" % (R, n, procs_n, budget_s),
+                checked_ctus=n, mismatches=len(bad), **cores_info)
 
 
 if __name__ == "__main__":

@@ -87,8 +87,18 @@ def pred_bi(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off
     return dst
 
 
+def _same_plane_shape(name, a, b):
+    """The second plane of a two-plane call is addressed with the first one's offsets and strides: it must be a tensor of the same kind."""
+    assert a.dtype == torch.uint8 and b.dtype == torch.uint8, "%s planes must be uint8" % name
+    assert a.is_contiguous() and b.is_contiguous(), "%s planes must be contiguous" % name
+    assert b.numel() >= a.numel(), "the second %s plane is shorter than the first (%d < %d bytes)" % (name, b.numel(), a.numel())
+    assert a.device == b.device, "the two %s planes are on different devices" % name
+
+
 def pred_uni_2planes(dst_a, dst_b, stride_dst, ref_a, ref_b, stride_ref, dst_off, ref_off, frac, taps, w, h):
     """Cb and Cr (one PU list, two planes) in one launch."""
+    _same_plane_shape("dst", dst_a, dst_b)
+    _same_plane_shape("ref", ref_a, ref_b)
     check(lib().hevcasm_hip_pred_uni_8to8_batch_2planes(dst_a.data_ptr(), dst_b.data_ptr(), stride_dst, ref_a.data_ptr(), ref_b.data_ptr(), stride_ref,
                                                         dst_off.data_ptr(), ref_off.data_ptr(), frac.data_ptr(), taps, w, h, dst_off.numel(), _stream()),
           "pred_uni_8to8_batch_2planes")
@@ -96,6 +106,9 @@ def pred_uni_2planes(dst_a, dst_b, stride_dst, ref_a, ref_b, stride_ref, dst_off
 
 
 def pred_bi_2planes(dst_a, dst_b, stride_dst, ref0_a, ref0_b, ref1_a, ref1_b, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1, taps, w, h):
+    _same_plane_shape("dst", dst_a, dst_b)
+    _same_plane_shape("ref0", ref0_a, ref0_b)
+    _same_plane_shape("ref1", ref1_a, ref1_b)
     check(lib().hevcasm_hip_pred_bi_8to8_batch_2planes(dst_a.data_ptr(), dst_b.data_ptr(), stride_dst, ref0_a.data_ptr(), ref0_b.data_ptr(),
                                                        ref1_a.data_ptr(), ref1_b.data_ptr(), stride_ref, dst_off.data_ptr(), ref0_off.data_ptr(),
                                                        ref1_off.data_ptr(), frac0.data_ptr(), frac1.data_ptr(), taps, w, h, dst_off.numel(), _stream()),
@@ -150,9 +163,21 @@ def quantize_reconstruct(rec, stride_rec, pred, stride_pred, rec_off, pred_off, 
     return rec
 
 
+def _result_rows(out, n, like):
+    """The (dx, dy, cost) table of n answers: allocated, or the caller's, checked -- the entry points write 12 n bytes through a raw pointer
+    (and, for small launches, memset them first), so a short, strided, int64 or other-device `out` would be overrun or silently misread."""
+    if out is None:
+        return torch.empty((n, 3), dtype=torch.int32, device=like.device)
+    assert out.dtype == torch.int32, "out must be int32, not %s" % out.dtype
+    assert out.is_contiguous(), "out must be contiguous"
+    assert out.numel() >= 3 * n, "out holds %d ints, %d answers need %d" % (out.numel(), n, 3 * n)
+    assert out.device == like.device, "out is on %s, the planes on %s" % (out.device, like.device)
+    return out
+
+
 def me_full_search(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, search_range, out=None):
     n = src_off.numel()
-    out = torch.empty((n, 3), dtype=torch.int32, device=src.device) if out is None else out
+    out = _result_rows(out, n, src)
     check(lib().hevcasm_hip_me_full_search_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(),
                                                  ref_off.data_ptr(), out.data_ptr(), rect(w, h), search_range, n, _stream()),
           "me_full_search_batch")
@@ -163,7 +188,7 @@ def me_full_search_frame_rows(cur, cur_byte0, stride_cur, ref, ref_byte0, stride
     """Full search over CTU rows [row0, row1) of a frame.  ``cur`` / ``ref`` are device tensors holding (a slab of) the
     planes; ``cur_byte0`` / ``ref_byte0`` are the byte positions in them of the pixel in column 0 of CTU row ``row0``."""
     cols = -(-frame_w // ctu)
-    out = torch.empty(((row1 - row0) * cols, 3), dtype=torch.int32, device=cur.device) if out is None else out
+    out = _result_rows(out, (row1 - row0) * cols, cur)
     check(lib().hevcasm_hip_me_full_search_frame_rows(cur.data_ptr() + cur_byte0, stride_cur, ref.data_ptr() + ref_byte0, stride_ref,
                                                       frame_w, frame_h, ctu, search_range, row0, row1, out.data_ptr(), _stream()),
           "me_full_search_frame_rows")
@@ -173,7 +198,7 @@ def me_full_search_frame_rows(cur, cur_byte0, stride_cur, ref, ref_byte0, stride
 def me_full_search_frame_ctus(cur, cur_byte0, stride_cur, ref, ref_byte0, stride_ref, frame_w, frame_h, ctu, search_range, first_ctu, n_ctus, out=None):
     """Full search over CTUs [first_ctu, first_ctu + n_ctus) of a frame in raster order; ``cur_byte0`` / ``ref_byte0`` are the byte
     positions of the pixel in column 0 of the CTU row that holds ``first_ctu``."""
-    out = torch.empty((n_ctus, 3), dtype=torch.int32, device=cur.device) if out is None else out
+    out = _result_rows(out, n_ctus, cur)
     check(lib().hevcasm_hip_me_full_search_frame_ctus(cur.data_ptr() + cur_byte0, stride_cur, ref.data_ptr() + ref_byte0, stride_ref,
                                                       frame_w, frame_h, ctu, search_range, first_ctu, n_ctus, out.data_ptr(), _stream()),
           "me_full_search_frame_ctus")
@@ -183,7 +208,7 @@ def me_full_search_frame_ctus(cur, cur_byte0, stride_cur, ref, ref_byte0, stride
 def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0, out=None):
     """Fused quarter-pel refinement: out[i] = (qx, qy, cost) of the best of the 49 displacements."""
     n = src_off.numel()
-    out = torch.empty((n, 3), dtype=torch.int32, device=src.device) if out is None else out
+    out = _result_rows(out, n, src)
     check(lib().hevcasm_hip_subpel_refine_batch(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(),
                                                 ref_off.data_ptr(), out.data_ptr(), rect(w, h), metric, n, _stream()),
           "subpel_refine_batch")

@@ -127,6 +127,7 @@ __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, 
 
 int set_error(int code, const char *what);     // records thread-local text, returns code
 int check_device();                            // 0 or HEVCASM_HIP_ENODEV; the current device must be a gfx950; clears the thread's stale HIP error
+int device_cus();                              // compute units of the current device (cached; 256 on an unpartitioned MI355X)
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
 #define HEVC_HIP_TRY(expr) \

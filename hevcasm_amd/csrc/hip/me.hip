@@ -277,11 +277,24 @@ __global__ __launch_bounds__(kThreads) void me_decode_kernel(int *result, uint32
 
 using namespace hevc;
 
-// workgroups per block: 1 when the launch fills the chip's workgroup slots (4 per CU at 64x64 / +-64) by itself
-static int me_parts(size_t n_blocks, int range)
+// Workgroups per block.  One when the launch fills the device's workgroup slots by itself; a launch too small for that (one rank's share of a
+// frame split over 8 GPUs) cuts every block's candidate ROWS into 2 or 4 parts.  Slots = compute units of the CURRENT device (a CPX / DPX
+// partition has 32 / 128) x the workgroups a CU holds at this launch's LDS footprint (160 KiB of LDS, 8 workgroups of 256 threads: four at
+// 64x64 / +-64).  Splitting costs a memset, a decode launch and re-staged window rows, so it is only done where a block is a large piece of
+// work -- W H (2 range + 1)^2 of at least 2^23 byte differences (32x32 / +-64 upwards; a list of 16x16 / +-16 blocks never splits) -- and while
+// the part-workgroups stay within 1.5 rounds of the slots (on 256 CUs at 64x64 / +-64: up to 384 blocks in 4 parts, up to 768 in 2; the only
+// geometry measured, profiles/r03_me_shard_launches.txt).
+static int me_parts(size_t n_blocks, int W, int H, int range, size_t lds_whole)
 {
 	static const int forced = getenv("HEVCASM_ME_PARTS") ? atoi(getenv("HEVCASM_ME_PARTS")) : 0;    // measurement switch, read once per process
-	int parts = (forced >= 1 && forced <= 8) ? forced : n_blocks <= 384 ? 4 : n_blocks <= 768 ? 2 : 1;
+	int parts = 1;
+	if (forced >= 1 && forced <= 8) parts = forced;
+	else if ((size_t)W * H * (2 * range + 1) * (2 * range + 1) >= ((size_t)1 << 23))
+	{
+		const size_t per_cu = lds_whole ? (160 * 1024) / ((lds_whole + 1023) & ~(size_t)1023) : 8;
+		const size_t slots = (size_t)device_cus() * (per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu);
+		parts = 2 * n_blocks * 4 <= 3 * slots ? 4 : 2 * n_blocks * 2 <= 3 * slots ? 2 : 1;
+	}
 	while (parts > 1 && 2 * range + 1 < 8 * parts) --parts;              // every part gets candidate rows
 	return parts;
 }
@@ -304,8 +317,9 @@ static int me_launch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *re
 {
 	int win_stride;
 	// the domain does not depend on the batch: a window must fit LDS whole, whether or not this launch cuts it into parts
-	if (me_lds_bytes(W, H, range, H + 2 * range, &win_stride) > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	const int parts = me_parts(n_blocks, range);
+	const size_t lds_whole = me_lds_bytes(W, H, range, H + 2 * range, &win_stride);
+	if (lds_whole > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
+	const int parts = me_parts(n_blocks, W, H, range, lds_whole);
 	const int per = (2 * range + 1 + parts - 1) / parts;             // candidate rows per workgroup
 	const size_t shmem = me_lds_bytes(W, H, range, H + per - 1, &win_stride);
 	if (parts > 1) HEVC_HIP_TRY(hipMemsetAsync(result, 0xff, 12 * n_blocks, st));

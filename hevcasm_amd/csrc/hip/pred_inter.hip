@@ -863,7 +863,7 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 	const bool ahead8 = H % 8 == 0 && W >= 6 && !(BI && W < 8);
 #define STRIP(FASTV, AH) hipLaunchKernelGGL((pred_strip4_kernel<BI, FASTV, AH>), dim3(grid, p2.count), dim3(kThreads), 0, st, \
 		dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
-	if (ahead8) { if (H % 8 == 0) STRIP(true, 8); else STRIP(false, 8); }
+	if (ahead8) STRIP(true, 8);            // H % 8 == 0 here: always the branch-free row loop
 	else if (H % 4 == 0) STRIP(true, 4);
 	else STRIP(false, 4);
 #undef STRIP

@@ -79,6 +79,23 @@ int check_device()
 	return 0;
 }
 
+// compute units of the calling thread's current device (256 on an MI355X in SPX mode, 32 / 128 when the part is partitioned CPX / DPX);
+// cached per device; 256 if the query fails
+int device_cus()
+{
+	static std::atomic<int> cus[kMaxDevices];
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+	int v = cus[dev].load(std::memory_order_acquire);
+	if (v <= 0)
+	{
+		hipDeviceProp_t p;
+		v = hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+		cus[dev].store(v, std::memory_order_release);
+	}
+	return v;
+}
+
 }  // namespace hevc
 
 using namespace hevc;

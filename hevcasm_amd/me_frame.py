@@ -148,7 +148,7 @@ def assemble_ctus(parts, frame_w, frame_h, ctu):
 
 def hip_rows_fn(device=None, stream_sync=True):
     """rows_fn backed by hevcasm_hip_me_full_search_frame_rows: uploads the slab it is given (the rank's H2D copy, halo
-    included) and searches it.  Returns (fn, state) -- state keeps the device tensors for repeated timing."""
+    included) and searches it, returning the answers as a numpy array.  Returns fn."""
     import torch
     from . import batch as B
 

@@ -140,7 +140,10 @@ int hevcasm_hip_pred_intra_batch(
  * 8 taps: exactly those bytes.  4 taps, PUs up to 8 wide or 16 wide: the kernel loads whole 4-byte-aligned words, 16 bytes at a
  * time, never below the lowest nor above the highest word that holds a byte of the footprints of the (at most 64)
  * consecutive PUs of the batch that one wavefront handles -- i.e. it may read bytes between those footprints, and up to 3
- * bytes beside the first / last of them inside their words, all of which a frame plane contains.
+ * bytes beside the first / last of them inside their words.  PRECONDITION of that 4-tap path (not checked by the launcher, which
+ * sees only offsets): every address between the lowest and the highest footprint byte of 64 consecutive PUs of the batch must be
+ * mapped -- true whenever `ref` and all offsets lie in ONE contiguous allocation (a frame plane, a frame stack), which is what the
+ * base + u32 offset addressing of this API presumes anyway; a batch gathered from separately mapped regions must be split per region.
  * Writes exactly nPbW x nPbH bytes per block. */
 int hevcasm_hip_pred_uni_8to8_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref,
@@ -224,7 +227,13 @@ int hevcasm_hip_pred_bi_8to8_batch_2planes(
 
 /* For each block: SAD at every displacement (dx, dy) in [-range, range]^2 around
  * ref + ref_off[i]; result[3i..3i+2] = { dx, dy, cost } of the minimum, ties resolved to the
- * first candidate in raster order of (dy, dx). */
+ * first candidate in raster order of (dy, dx).
+ * OWNERSHIP OF result (this entry point and the two frame_* ones): the 12 * n bytes of `result` belong to the call from the
+ * moment it is issued until `stream` has passed its last launch.  A launch too small to fill the device cuts every block's
+ * candidates over several workgroups and then uses the result slots as scratch: they are preset to 0xff bytes
+ * (hipMemsetAsync), hold running 64-bit minimum keys, and are rewritten as (dx, dy, cost) by a final decode launch -- so a
+ * reader on another stream, or unrelated data aliased inside those bytes, sees or loses intermediate contents, and after a
+ * failed call (non-zero return) the slots hold no answers at all.  result must be 4-byte aligned; nothing else is assumed. */
 int hevcasm_hip_me_full_search_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *result,

@@ -17,7 +17,7 @@ BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
 OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL, OP_INTRA, OP_SSD_LINEAR = 8, 9, 10, 11, 12, 13, 14, 15, 16
-OP_SELFTEST, OP_BENCH_SAD = 20, 30
+OP_SELFTEST, OP_BENCH_SAD, OP_BENCH_PRED, OP_BENCH_INV = 20, 30, 31, 32
 
 
 def available():
@@ -161,6 +161,20 @@ class RefProc:
                       [_u8(src), _u8(ref), _u32(src_off), _u32(ref_off)])
         secs, blocks = struct.unpack("<dd", o[0][:16])
         return secs, blocks
+
+    def bench_pred(self, taps, dst_bytes, stride_dst, refs, stride_ref, dst_off, ref_offs, fracs, w, h, min_ms):
+        """Times the reference's pred_uni (one reference) / pred_bi (two) table entries over the PU list -> (seconds, PUs)."""
+        bi = len(refs) == 2
+        bufs = [_u8(r) for r in refs] + [_u32(dst_off)] + [_u32(o) for o in ref_offs] + [_u8(f) for f in fracs]
+        o = self.call(OP_BENCH_PRED, [stride_dst, stride_ref, taps, w, h, len(dst_off), dst_bytes, int(bi), min_ms], bufs)
+        return struct.unpack("<dd", o[0][:16])
+
+    def bench_inverse(self, tr_type, log2n, dst_bytes, stride_dst, pred, stride_pred, dst_off, pred_off, coeffs, min_ms, dequant=None):
+        """Times the reference's inverse_transform_add entry (dequant = (scale, shift): hevcasm_quantize_inverse in front) -> (seconds, blocks)."""
+        scale, shift = dequant if dequant else (0, 0)
+        o = self.call(OP_BENCH_INV, [stride_dst, stride_pred, tr_type, log2n, len(dst_off), dst_bytes, int(dequant is not None), scale, shift, min_ms],
+                      [_u8(pred), _u32(dst_off), _u32(pred_off), _i16(coeffs)])
+        return struct.unpack("<dd", o[0][:16])
 
 
 def _u8(a):

@@ -83,7 +83,7 @@ static double now_s(void)
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
 	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14, OP_INTRA = 15, OP_SSD_LINEAR = 16,
-	OP_SELFTEST = 20, OP_BENCH_SAD = 30
+	OP_SELFTEST = 20, OP_BENCH_SAD = 30, OP_BENCH_PRED = 31, OP_BENCH_INV = 32
 };
 
 int main(void)
@@ -407,6 +407,83 @@ int main(void)
 				blocks += (double)n;
 				t1 = now_s();
 			} while (t1 - t0 < min_s);
+			r[0] = t1 - t0; r[1] = blocks; memcpy(&r[2], &sum, 8);
+			out[0].p = (uint8_t *)r; out[0].bytes = 24; nout = 1;
+			break;
+		}
+		case OP_BENCH_PRED: /* CPU baseline leg beside inter prediction (config #3): par: stride_dst, stride_ref, taps, w, h, n, dst_bytes, bi(0|1), min_ms;
+		                       bufs as OP_PRED_UNI (bi = 0) or OP_PRED_BI (bi = 1).  The reference's own table entries (pred_inter.c:154-228 uni,
+		                       :490-530 bi), whole passes over the PU list until min_ms elapsed.  -> double[2] = { seconds, PUs } and i64 checksum */
+		{
+			const size_t n = (size_t)par[5];
+			const int bi = (int)par[7], taps = (int)par[2], w = (int)par[3], h = (int)par[4];
+			const uint32_t *dof = (const uint32_t *)in[bi ? 2 : 1].p, *r0 = (const uint32_t *)in[bi ? 3 : 2].p, *r1 = bi ? (const uint32_t *)in[4].p : 0;
+			const uint8_t *f0 = in[bi ? 5 : 3].p, *f1 = bi ? in[6].p : 0;
+			uint8_t *dst = (uint8_t *)calloc((size_t)par[6] + 64, 1);
+			const double min_s = (double)par[8] * 1e-3;
+			double *r = (double *)malloc(24);
+			double blocks = 0;
+			const double t0 = now_s();
+			double t1 = t0;
+			do
+			{
+				for (size_t i = 0; i < n; ++i)
+				{
+					const int xa = f0[i] & 15, ya = f0[i] >> 4;
+					if (bi)
+					{
+						const int xb = f1[i] & 15, yb = f1[i] >> 4;
+						(*hevcasm_get_pred_bi_8to8(&t_bi, taps, w, h, xa, ya, xb, yb))(dst + dof[i], par[0], in[0].p + r0[i], in[1].p + r1[i], par[1], w, h, xa, ya, xb, yb);
+					}
+					else
+						(*hevcasm_get_pred_uni_8to8(&t_uni, taps, w, h, xa, ya))(dst + dof[i], par[0], in[0].p + r0[i], par[1], w, h, xa, ya);
+				}
+				blocks += (double)n;
+				t1 = now_s();
+			} while (t1 - t0 < min_s);
+			int64_t sum = 0;
+			for (size_t i = 0; i < (size_t)par[6]; i += 97) sum += dst[i];
+			free(dst);
+			r[0] = t1 - t0; r[1] = blocks; memcpy(&r[2], &sum, 8);
+			out[0].p = (uint8_t *)r; out[0].bytes = 24; nout = 1;
+			break;
+		}
+		case OP_BENCH_INV: /* CPU baseline leg beside the inverse transforms (config #4): par: stride_dst, stride_pred, trType, log2, n, dst_bytes,
+		                      fused(0|1), scale, shift, min_ms; bufs as OP_INV.  The reference's table entries (residual_decode.c:371-413, with
+		                      quantize.c:53-62 in front when fused).  -> double[2] = { seconds, blocks } and i64 checksum */
+		{
+			const size_t n = (size_t)par[4];
+			const int log2n = (int)par[3];
+			const size_t nn = (size_t)1 << (2 * log2n);
+			const uint32_t *dof = (const uint32_t *)in[1].p, *pof = (const uint32_t *)in[2].p;
+			const int16_t *c = (const int16_t *)in[3].p;
+			hevcasm_inverse_transform_add *f = *hevcasm_get_inverse_transform_add(&t_inv, (int)par[2], log2n);
+			hevcasm_quantize_inverse *dq = *hevcasm_get_quantize_inverse(&t_deq);
+			uint8_t *dst = (uint8_t *)calloc((size_t)par[5] + 64, 1);
+			const double min_s = (double)par[9] * 1e-3;
+			double *r = (double *)malloc(24);
+			double blocks = 0;
+			const double t0 = now_s();
+			double t1 = t0;
+			do
+			{
+				for (size_t i = 0; i < n; ++i)
+				{
+					HEVCASM_ALIGN(32, int16_t, tmp[32 * 32]);
+					const int16_t *ci = c + nn * i;
+					if (par[6])
+					{
+						dq(tmp, ci, (int)par[7], (int)par[8], (int)nn);
+						ci = tmp;
+					}
+					f(dst + dof[i], par[0], in[0].p + pof[i], par[1], ci);
+				}
+				blocks += (double)n;
+				t1 = now_s();
+			} while (t1 - t0 < min_s);
+			int64_t sum = 0;
+			for (size_t i = 0; i < (size_t)par[5]; i += 97) sum += dst[i];
+			free(dst);
 			r[0] = t1 - t0; r[1] = blocks; memcpy(&r[2], &sum, 8);
 			out[0].p = (uint8_t *)r; out[0].bytes = 24; nout = 1;
 			break;
