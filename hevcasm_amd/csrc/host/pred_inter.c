@@ -11,6 +11,7 @@
 #include "pred_inter.h"
 #include "cpath.h"
 #include "perblock.h"
+#include "pred_x86.h"
 #include "hevcasm_test.h"
 
 #include <stdlib.h>
@@ -22,11 +23,17 @@ void hevcasm_populate_pred_uni_8to8(hevcasm_table_pred_uni_8to8 *table, hevcasm_
 	{
 		hevcasm_pred_uni_8to8 *f = 0;
 		if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = taps == 8 ? hevcasm_c_pred_uni_8tap : hevcasm_c_pred_uni_4tap;
-		if (mask & HEVCASM_HIP) f = taps == 8 ? hevcasm_hip1_pred_uni_8tap : hevcasm_hip1_pred_uni_4tap;
+		hevcasm_pred_uni_8to8 *copy = f, *filter = f;
+#if defined(__x86_64__) || defined(__i386__)
+		/* where the reference selects its assembly (pred_inter.c:296-346): SSE2 block copies for integer vectors, SSE4.1 filters otherwise */
+		if (mask & HEVCASM_SSE2) copy = hevcasm_sse2_pred_uni_copy;
+		if (mask & HEVCASM_SSE41) filter = taps == 8 ? hevcasm_sse4_pred_uni_8tap : hevcasm_sse4_pred_uni_4tap;
+#endif
+		if (mask & HEVCASM_HIP) copy = filter = taps == 8 ? hevcasm_hip1_pred_uni_8tap : hevcasm_hip1_pred_uni_4tap;
 		for (int w = 0; w <= 8 * taps; w += taps)
 			for (int xFrac = 0; xFrac < 2; ++xFrac)
 				for (int yFrac = 0; yFrac < 2; ++yFrac)
-					*hevcasm_get_pred_uni_8to8(table, taps, w, 0, xFrac, yFrac) = f;
+					*hevcasm_get_pred_uni_8to8(table, taps, w, 0, xFrac, yFrac) = (xFrac | yFrac) ? filter : copy;
 	}
 }
 
@@ -36,10 +43,16 @@ void hevcasm_populate_pred_bi_8to8(hevcasm_table_pred_bi_8to8 *table, hevcasm_in
 	{
 		hevcasm_pred_bi_8to8 *f = 0;
 		if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = taps == 8 ? hevcasm_c_pred_bi_8tap : hevcasm_c_pred_bi_4tap;
-		if (mask & HEVCASM_HIP) f = taps == 8 ? hevcasm_hip1_pred_bi_8tap : hevcasm_hip1_pred_bi_4tap;
+		hevcasm_pred_bi_8to8 *copy = f, *filter = f;
+#if defined(__x86_64__) || defined(__i386__)
+		/* reference pred_inter.c:570-593: pavgb when all four fractions are zero (SSE2), the SSE4.1 filters otherwise */
+		if (mask & HEVCASM_SSE2) copy = hevcasm_sse2_pred_bi_copy;
+		if (mask & HEVCASM_SSE41) filter = taps == 8 ? hevcasm_sse4_pred_bi_8tap : hevcasm_sse4_pred_bi_4tap;
+#endif
+		if (mask & HEVCASM_HIP) copy = filter = taps == 8 ? hevcasm_hip1_pred_bi_8tap : hevcasm_hip1_pred_bi_4tap;
 		for (int w = 0; w <= 8 * taps; w += 2 * taps)
 			for (int frac = 0; frac < 2; ++frac)
-				*hevcasm_get_pred_bi_8to8(table, taps, w, 0, frac, frac, frac, frac) = f;
+				*hevcasm_get_pred_bi_8to8(table, taps, w, 0, frac, frac, frac, frac) = frac ? filter : copy;
 	}
 }
 

@@ -9,6 +9,7 @@
 #include "quantize.h"
 #include "cpath.h"
 #include "perblock.h"
+#include "quant_x86.h"
 #include "hevcasm_test.h"
 
 #include <stdlib.h>
@@ -18,6 +19,9 @@ void hevcasm_populate_quantize_inverse(hevcasm_table_quantize_inverse *table, he
 {
 	hevcasm_quantize_inverse *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize_inverse;
+#if defined(__x86_64__) || defined(__i386__)
+	if (mask & HEVCASM_SSE41) f = hevcasm_sse4_quantize_inverse;      /* where the reference selects its assembly (quantize.c:71) */
+#endif
 	if (mask & HEVCASM_HIP) f = hevcasm_hip1_quantize_inverse;
 	*hevcasm_get_quantize_inverse(table) = f;
 }
@@ -26,6 +30,9 @@ void hevcasm_populate_quantize(hevcasm_table_quantize *table, hevcasm_instructio
 {
 	hevcasm_quantize *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize;
+#if defined(__x86_64__) || defined(__i386__)
+	if (mask & HEVCASM_SSE41) f = hevcasm_sse4_quantize;      /* where the reference selects its assembly (quantize.c:195) */
+#endif
 	if (mask & HEVCASM_HIP) f = hevcasm_hip1_quantize;
 	*hevcasm_get_quantize(table) = f;
 }
@@ -34,6 +41,9 @@ void hevcasm_populate_quantize_reconstruct(hevcasm_table_quantize_reconstruct *t
 {
 	hevcasm_quantize_reconstruct *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize_reconstruct;
+#if defined(__x86_64__) || defined(__i386__)
+	if (mask & HEVCASM_SSE41) f = hevcasm_sse4_quantize_reconstruct;      /* where the reference selects its assembly (quantize.c:311-318) */
+#endif
 	if (mask & HEVCASM_HIP) f = hevcasm_hip1_quantize_reconstruct;
 	for (int log2 = 2; log2 <= 5; ++log2) *hevcasm_get_quantize_reconstruct(table, log2) = f;
 }

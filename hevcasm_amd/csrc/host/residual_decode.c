@@ -8,6 +8,7 @@
 #include "residual_decode.h"
 #include "cpath.h"
 #include "perblock.h"
+#include "transform_x86.h"
 #include "hevcasm_test.h"
 
 #include <stdlib.h>
@@ -17,25 +18,33 @@ void hevcasm_populate_inverse_transform_add(hevcasm_table_inverse_transform_add 
 {
 	static hevcasm_inverse_transform_add *const c_path[5] = { hevcasm_c_idst_4, hevcasm_c_idct_4, hevcasm_c_idct_8, hevcasm_c_idct_16, hevcasm_c_idct_32 };
 	static hevcasm_inverse_transform_add *const hip_path[5] = { hevcasm_hip1_idst_4, hevcasm_hip1_idct_4, hevcasm_hip1_idct_8, hevcasm_hip1_idct_16, hevcasm_hip1_idct_32 };
-	hevcasm_inverse_transform_add *const *src = 0;
+	hevcasm_inverse_transform_add *f[5] = { 0, 0, 0, 0, 0 };
 	(void)encoder; /* every kernel here is exact on all inputs: residual_decode.h */
-	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) src = c_path;
-	if (mask & HEVCASM_HIP) src = hip_path;
-	*hevcasm_get_inverse_transform_add(table, 1, 2) = src ? src[0] : 0;
+	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) memcpy(f, c_path, sizeof(f));
+#if defined(__x86_64__)
+	/* where the reference selects its assembly (residual_decode.c:475-497); our AVX2 32x32 is exact, so it needs no `encoder` condition */
+	if (mask & HEVCASM_SSSE3) { f[2] = hevcasm_ssse3_idct_8; f[3] = hevcasm_ssse3_idct_16; }
+	if (mask & HEVCASM_AVX2) { f[0] = hevcasm_avx2_idst_4; f[1] = hevcasm_avx2_idct_4; f[2] = hevcasm_avx2_idct_8; f[3] = hevcasm_avx2_idct_16; f[4] = hevcasm_avx2_idct_32; }
+#endif
+	if (mask & HEVCASM_HIP) memcpy(f, hip_path, sizeof(f));
+	*hevcasm_get_inverse_transform_add(table, 1, 2) = f[0];
 	for (int log2 = 2; log2 <= 5; ++log2)
-		*hevcasm_get_inverse_transform_add(table, 0, log2) = src ? src[log2 - 1] : 0;
+		*hevcasm_get_inverse_transform_add(table, 0, log2) = f[log2 - 1];
 }
 
 void hevcasm_populate_transform(hevcasm_table_transform *table, hevcasm_instruction_set mask)
 {
 	static hevcasm_transform *const c_path[5] = { hevcasm_c_dst_4, hevcasm_c_dct_4, hevcasm_c_dct_8, hevcasm_c_dct_16, hevcasm_c_dct_32 };
 	static hevcasm_transform *const hip_path[5] = { hevcasm_hip1_dst_4, hevcasm_hip1_dct_4, hevcasm_hip1_dct_8, hevcasm_hip1_dct_16, hevcasm_hip1_dct_32 };
-	hevcasm_transform *const *src = 0;
-	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) src = c_path;
-	if (mask & HEVCASM_HIP) src = hip_path;
-	*hevcasm_get_transform(table, 1, 2) = src ? src[0] : 0;
+	hevcasm_transform *f[5] = { 0, 0, 0, 0, 0 };
+	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) memcpy(f, c_path, sizeof(f));
+#if defined(__x86_64__)
+	if (mask & HEVCASM_SSSE3) f[3] = hevcasm_ssse3_dct_16;      /* reference residual_decode.c:918-923 */
+#endif
+	if (mask & HEVCASM_HIP) memcpy(f, hip_path, sizeof(f));
+	*hevcasm_get_transform(table, 1, 2) = f[0];
 	for (int log2 = 2; log2 <= 5; ++log2)
-		*hevcasm_get_transform(table, 0, log2) = src ? src[log2 - 1] : 0;
+		*hevcasm_get_transform(table, 0, log2) = f[log2 - 1];
 }
 
 typedef struct

@@ -4,6 +4,7 @@
 #include "ssd.h"
 #include "cpath.h"
 #include "perblock.h"
+#include "quant_x86.h"
 #include "hevcasm_test.h"
 
 #include <stdlib.h>
@@ -12,8 +13,12 @@ void hevcasm_populate_ssd(hevcasm_table_ssd *table, hevcasm_instruction_set mask
 {
 	hevcasm_ssd *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_ssd;
-	if (mask & HEVCASM_HIP) f = hevcasm_hip1_ssd;
-	for (int log2 = 2; log2 <= 6; ++log2) *hevcasm_get_ssd(table, log2) = f;
+	hevcasm_ssd *wide = f;
+#if defined(__x86_64__) || defined(__i386__)
+	if (mask & HEVCASM_AVX) wide = hevcasm_avx_ssd;      /* reference ssd.c:80-85: 16x16, 32x32, 64x64 only */
+#endif
+	if (mask & HEVCASM_HIP) f = wide = hevcasm_hip1_ssd;
+	for (int log2 = 2; log2 <= 6; ++log2) *hevcasm_get_ssd(table, log2) = log2 >= 4 ? wide : f;
 }
 
 typedef struct

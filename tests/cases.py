@@ -116,7 +116,22 @@ def pred_bi_cases(n=16, seed=400, sizes=None):
         out.append(("bi%d_zero_frac" % taps, "pred_bi", wl.pred_case(taps, 16, 16, 8, seed + 50 + taps, bi=True, fracs=(0, 0))))
     out.append(("bi8_max", "pred_bi", wl.pred_case(8, 32, 32, 6, seed + 60, bi=True, kind="max")))
     out.append(("bi8_checker", "pred_bi", _checker(wl.pred_case(8, 64, 64, 4, seed + 61, bi=True))))
+    out.append(("bi8_wrap", "pred_bi", _wrap14(wl.pred_case(8, 16, 16, 6, seed + 62, bi=True, fracs=(2, 2)))))
     return out
+
+
+def _wrap14(c):
+    """Reference planes on which the 14-bit intermediate of bi-prediction leaves int16: 255 under the positive taps of the half-pel filter and 0
+    under the negative ones in BOTH directions (and the complement in the negative rows), so that the second-pass sum >> 6 reaches 33 150.  The
+    reference stores it into an int16_t (pred_inter.c:125), i.e. it WRAPS; an implementation that saturates, or keeps 32 bits, differs here."""
+    positive = (1, 3, 4, 6)
+    stride = c["stride_ref"]
+    for r in (0, 1):
+        plane = c["ref%d" % r]
+        idx = np.arange(plane.size)
+        y, x = idx // stride, idx % stride
+        plane[:] = np.where(np.isin((x + 5 * r) % 8, positive) == np.isin((y + 3 * r) % 8, positive), 255, 0).astype(np.uint8)
+    return c
 
 
 def inverse_cases(n=40, seed=500):

@@ -71,9 +71,10 @@ def test_table_layouts_match_reference_abi():
 @pytest.mark.parametrize("name", ["sad", "sad_multiref", "ssd", "hadamard_satd", "pred_uni_8to8", "pred_bi_8to8", "transform",
                                   "quantize_inverse", "quantize", "quantize_reconstruct"])
 def test_selector_masks(name):
-    """NULL = unsupported (reference convention): x86 SIMD bits alone select nothing, except for SAD and 4-way SAD, where
-    they select the intrinsics kernels of csrc/host/sad_x86.c exactly where the reference selects its assembly (reference
-    sad.c:63-86, :128-167); C bits select the C path; the HIP bit selects different (per-block HIP) entries."""
+    """NULL = unsupported (reference convention): x86 SIMD bits alone select exactly the slots for which the reference has assembly
+    under those bits -- the intrinsics kernels of csrc/host/{sad,pred,transform,quant}_x86.c (reference sad.c:63-86, :128-167;
+    pred_inter.c:296-346, :570-593; residual_decode.c:475-497, :918-923; quantize.c:71, :195, :311-318; ssd.c:80-85) -- and nothing
+    else; C bits select the C path; the HIP bit selects different (per-block HIP) entries."""
     L = capi.lib()
     slots = 300
 
@@ -89,6 +90,17 @@ def test_selector_masks(name):
         if name == "sad":
             assert sum(bool(x) for x in simd) == 11      # the eleven named sizes; the shared generic slot only ever gets the C function
             assert pop(capi.C_REF | capi.SSE2)[:11] == pop(capi.SSE2)[:11] and pop(capi.C_REF | capi.SSE2)[11] == c_ref[11]
+    elif L.hevcasm_instruction_set_support() & capi.SSE2:
+        all_x86 = pop(capi.SSE2 | capi.SSE3 | capi.SSSE3 | capi.SSE41 | capi.SSE42 | capi.AVX | capi.AVX2)
+        assert all(s != c for s, c in zip(all_x86, c_ref) if s)                      # never the C function behind an x86 bit
+        want = {"ssd": 3,                                                             # 16x16, 32x32, 64x64 (AVX)
+                "hadamard_satd": 0,                                                   # (f265's SATD assembly has no stand-in here)
+                "pred_uni_8to8": 2 * 9 * 4, "pred_bi_8to8": 2 * 5 * 2,                # copy slots (SSE2) + fractional slots (SSE4.1)
+                "transform": 1,                                                       # forward 16x16 (SSSE3)
+                "quantize_inverse": 1, "quantize": 1, "quantize_reconstruct": 4}[name]
+        assert sum(bool(x) for x in all_x86) == want, name
+        # SSE2 | AVX2 alone: only what the reference puts behind exactly those two bits
+        assert sum(bool(x) for x in simd) == {"pred_uni_8to8": 2 * 9, "pred_bi_8to8": 2 * 5}.get(name, 0), name
     else:
         assert not any(simd)
     assert any(c_ref) and c_ref == c_opt

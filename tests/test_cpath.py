@@ -108,6 +108,10 @@ def test_hadamard_satd(oracle_lib):
 
 
 def test_pred_uni_and_bi(oracle_lib):
+    _check_pred(capi.C_REF)
+
+
+def _check_pred(mask):
     for name, family, c in cases.pred_uni_cases(n=6) + cases.pred_bi_cases(n=4):
         taps, w, h, n = c["taps"], c["w"], c["h"], c["n"]
         want = cases.run_oracle(family, c)[0]
@@ -117,51 +121,71 @@ def test_pred_uni_and_bi(oracle_lib):
             x0, y0 = int(c["frac0"][i]) & 15, int(c["frac0"][i]) >> 4
             if family == "pred_uni":
                 idx = (((taps // 4 - 1) * 9 + (w + taps - 1) // taps) * 2 + (1 if x0 else 0)) * 2 + (1 if y0 else 0)
-                f = C.CFUNCTYPE(None, VP, PD, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_uni_8to8", 72, idx))
+                f = C.CFUNCTYPE(None, VP, PD, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_uni_8to8", 72, idx, mask))
                 f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(ref0, c["ref0_off"][i]), c["stride_ref"], w, h, x0, y0)
             else:
                 ref1 = np.ascontiguousarray(c["ref1"])
                 x1, y1 = int(c["frac1"][i]) & 15, int(c["frac1"][i]) >> 4
                 idx = ((taps // 4 - 1) * 5 + (w + 2 * taps - 1) // (2 * taps)) * 2 + (1 if (x0 or y0 or x1 or y1) else 0)
-                f = C.CFUNCTYPE(None, VP, PD, VP, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_bi_8to8", 20, idx))
+                f = C.CFUNCTYPE(None, VP, PD, VP, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_pred_bi_8to8", 20, idx, mask))
                 f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(ref0, c["ref0_off"][i]), _ptr(ref1, c["ref1_off"][i]), c["stride_ref"], w, h, x0, y0, x1, y1)
         got = cases._dst_rows(dst, c["stride_dst"], c["dst_off"], w, h)
         cases.assert_same(name, (got,), (want,))
 
 
 def test_transforms(oracle_lib):
+    assert _check_transforms(capi.C_REF) == (0, 0)
+
+
+def _check_transforms(mask, encoder=0):
+    """Every inverse / forward case through the table entries of `mask`; returns how many (inverse, forward) cases found a NULL slot."""
+    null_inv = null_fwd = 0
     for name, family, c in cases.inverse_cases(n=10) + cases.forward_cases(n=10):
         tr, lg, n = c["tr_type"], c["log2n"], c["n"]
         size = 1 << lg
         idx = 0 if tr else lg - 1
+        buf = (C.c_void_p * 5)()
+        if family == "inverse":
+            capi.lib().hevcasm_populate_inverse_transform_add(buf, mask, encoder)
+        else:
+            capi.lib().hevcasm_populate_transform(buf, mask)
+        if not buf[idx]:
+            null_inv += family == "inverse"
+            null_fwd += family != "inverse"
+            continue
         want = cases.run_oracle(family, c)[0]
         if family == "inverse":
-            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP)(_slot("hevcasm_populate_inverse_transform_add", 5, idx, extra=(0,)))
+            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP)(buf[idx])
             dst = np.zeros(c["dst_bytes"], dtype=np.uint8)
             pred, coeffs = np.ascontiguousarray(c["pred"]), np.ascontiguousarray(c["coeffs"])
             for i in range(n):
                 f(_ptr(dst, c["dst_off"][i]), c["stride_dst"], _ptr(pred, c["pred_off"][i]), c["stride_pred"], _ptr(coeffs, 2 * size * size * i))
             cases.assert_same(name, (cases._dst_rows(dst, c["stride_dst"], c["dst_off"], size, size),), (want,))
         else:
-            f = C.CFUNCTYPE(None, VP, VP, PD)(_slot("hevcasm_populate_transform", 5, idx))
+            f = C.CFUNCTYPE(None, VP, VP, PD)(buf[idx])
             src = np.ascontiguousarray(c["src"])
             out = np.zeros(n * size * size, dtype=np.int16)
             for i in range(n):
                 f(_ptr(out, 2 * size * size * i), _ptr(src, 2 * int(c["src_off"][i])), c["src_stride"])
             cases.assert_same(name, (out,), (want,))
+    return null_inv, null_fwd
 
 
 def test_quant_family(oracle_lib):
+    _check_quant(capi.C_REF)
+
+
+def _check_quant(mask):
     for name, family, c in cases.quant_cases():
         want = cases.run_oracle(family, c)
         if family == "dequant":
-            f = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize_inverse", 1, 0))
+            f = C.CFUNCTYPE(None, VP, VP, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize_inverse", 1, 0, mask))
             src = np.ascontiguousarray(c["src"])
             out = np.zeros_like(src)
             f(_ptr(out), _ptr(src), c["scale"], c["shift"], src.size)
             cases.assert_same(name, (out,), want)
         elif family == "quant":
-            f = C.CFUNCTYPE(C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize", 1, 0))
+            f = C.CFUNCTYPE(C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize", 1, 0, mask))
             src = np.ascontiguousarray(c["src"])
             out = np.zeros_like(src)
             npb = c["n_per_block"]
@@ -169,9 +193,93 @@ def test_quant_family(oracle_lib):
             cases.assert_same(name, (out, np.array(cbf, dtype=np.int32)), want)
         else:
             size = c["ncbs"]
-            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP, C.c_int)(_slot("hevcasm_populate_quantize_reconstruct", 4, int(np.log2(size)) - 2))
+            f = C.CFUNCTYPE(None, VP, PD, VP, PD, VP, C.c_int)(_slot("hevcasm_populate_quantize_reconstruct", 4, int(np.log2(size)) - 2, mask))
             rec = np.zeros(c["rec_bytes"], dtype=np.uint8)
             pred, res = np.ascontiguousarray(c["pred"]), np.ascontiguousarray(c["res"])
             for i in range(len(c["rec_off"])):
                 f(_ptr(rec, c["rec_off"][i]), c["stride_rec"], _ptr(pred, c["pred_off"][i]), c["stride_pred"], _ptr(res, 2 * size * size * i), size)
             cases.assert_same(name, (cases._dst_rows(rec, c["stride_rec"], c["rec_off"], size, size),), want)
+
+
+def _x86(bits):
+    have = capi.lib().hevcasm_instruction_set_support()
+    if (have & bits) != bits:
+        pytest.skip("host lacks the instruction sets %#x" % bits)
+
+
+def test_pred_x86_simd_entries(oracle_lib):
+    """The SSE2 / SSE4.1 prediction entries (csrc/host/pred_x86.c: the reference's x86 kernels written with intrinsics, pred_inter_a.asm:174-600)
+    against the oracle on every prediction case -- all PU sizes, every fraction pair, both clip rails, 2-wide chroma PUs -- and the table shape of
+    single-bit masks: SSE2 alone fills only the integer-vector slots, SSE4.1 alone only the fractional ones (reference pred_inter.c:296-346, :570-593)."""
+    _x86(capi.SSE2 | capi.SSE41)
+    _check_pred(capi.SSE2 | capi.SSE41)
+    L = capi.lib()
+    for mask, want_copy, want_filter in ((capi.SSE2, True, False), (capi.SSE41, False, True)):
+        uni, bi = (C.c_void_p * 72)(), (C.c_void_p * 20)()
+        L.hevcasm_populate_pred_uni_8to8(uni, mask)
+        L.hevcasm_populate_pred_bi_8to8(bi, mask)
+        for t in range(2):
+            for wc in range(9):
+                for xf in range(2):
+                    for yf in range(2):
+                        assert bool(uni[((t * 9 + wc) * 2 + xf) * 2 + yf]) == (want_filter if (xf or yf) else want_copy), (mask, t, wc, xf, yf)
+            for wc in range(5):
+                for fr in range(2):
+                    assert bool(bi[(t * 5 + wc) * 2 + fr]) == (want_filter if fr else want_copy), (mask, t, wc, fr)
+
+
+def test_pred_x86_truncation_of_the_14_bit_intermediate(oracle_lib):
+    """Bi-prediction keeps 14-bit intermediates in int16 BY TRUNCATION (reference pred_inter.c:125 stores an int into an int16_t): a pattern
+    whose second-pass sum exceeds 32767 -- 255 under every positive tap, 0 under every negative one, in both directions -- must wrap exactly as
+    the C path does, not saturate."""
+    _x86(capi.SSE2 | capi.SSE41)
+    from oracle import pyoracle
+    taps, w, h, stride = 8, 8, 8, 64
+    pos = [k for k in range(8) if [-1, 4, -11, 40, 40, -11, 4, -1][k] > 0]
+    ref = np.zeros((h + 24) * stride, dtype=np.uint8).reshape(-1, stride)
+    for y in range(ref.shape[0]):
+        for x in range(stride):
+            # pixel (x, y) is 255 when the taps that see it from output (4, 4)+origin are positive in both directions, complementary rows give the negative lobes
+            ref[y, x] = 255 if ((x - 1) % 8 in pos) == ((y - 1) % 8 in pos) else 0
+    flat = np.ascontiguousarray(ref.reshape(-1))
+    off = np.array([8 * stride + 8], dtype=np.uint32)
+    frac = np.array([2 | (2 << 4)], dtype=np.uint8)
+    want = pyoracle.pred_bi_batch(taps, w * h, w, flat, flat, stride, np.array([0], dtype=np.uint32), off, off, frac, frac, w, h)
+    buf = (C.c_void_p * 20)()
+    capi.lib().hevcasm_populate_pred_bi_8to8(buf, capi.SSE41)
+    f = C.CFUNCTYPE(None, VP, PD, VP, VP, PD, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int)(buf[(1 * 5 + 1) * 2 + 1])
+    dst = np.zeros(w * h, dtype=np.uint8)
+    f(_ptr(dst), w, _ptr(flat, off[0]), _ptr(flat, off[0]), stride, w, h, 2, 2, 2, 2)
+    assert np.array_equal(dst, want)
+
+
+def test_transform_x86_simd_entries(oracle_lib):
+    """The SSSE3 / AVX2 transform entries (csrc/host/transform_x86.c) against the oracle on every transform case (full-range, +-32767, alternating,
+    DC-only coefficients; 9-bit and full-range residuals), and the table shape of single-bit masks: SSSE3 = inverse 8x8 / 16x16 and forward 16x16,
+    AVX2 = every inverse size (reference residual_decode.c:475-497, :918-923)."""
+    _x86(capi.SSSE3 | capi.AVX2)
+    n_inv = len(cases.inverse_cases(n=10))
+    per_size_inv = n_inv // 5
+    null_inv, null_fwd = _check_transforms(capi.SSSE3)
+    assert null_inv == 3 * per_size_inv and null_fwd == 4 * (len(cases.forward_cases(n=10)) // 5)
+    assert _check_transforms(capi.AVX2)[0] == 0
+    assert _check_transforms(capi.AVX2, encoder=1)[0] == 0
+    assert _check_transforms(capi.C_REF | capi.SSSE3 | capi.AVX2) == (0, 0)
+
+
+def test_quant_and_ssd_x86_simd_entries(oracle_lib):
+    """The SSE4.1 (de)quantiser / reconstruction entries and the AVX SSD entries (csrc/host/quant_x86.c) against the oracle: reference parameters,
+    HEVC-style sweeps, src = -32768 (where the reference's own pabsw assembly differs from its C: SURVEY appendix A), full-range residuals."""
+    _x86(capi.SSE41 | capi.AVX)
+    _check_quant(capi.SSE41)
+    buf = (C.c_void_p * 5)()
+    capi.lib().hevcasm_populate_ssd(buf, capi.AVX)
+    assert [bool(v) for v in buf] == [False, False, True, True, True]        # reference ssd.c:80-85
+    for name, family, c in cases.ssd_cases(n=12):
+        w, h = c["w"], c["h"]
+        if w != h or w < 16:
+            continue
+        src, ref = np.ascontiguousarray(c["src"]), np.ascontiguousarray(c["ref"])
+        f = C.CFUNCTYPE(C.c_int, VP, PD, VP, PD, C.c_int, C.c_int)(buf[int(np.log2(w)) - 2])
+        got = [f(_ptr(src, c["src_off"][i]), c["stride_src"], _ptr(ref, c["ref_off"][i]), c["stride_ref"], w, h) for i in range(c["n"])]
+        assert np.array_equal(np.array(got), cases.run_oracle(family, c)[0]), name
