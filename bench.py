@@ -560,6 +560,19 @@ NOMINAL_QSAD_TBYTEDIFFS = 256 * 4 * 64 * 16 / 16.0 * 2.4e9 / 1e12     # quarter 
 
 
 def qsad_peak():
+    """(T byte differences/s, where the number comes from).  First choice: hevcasm_amd/lib/ubench_qsad_rate run NOW on this box (a 6 ms kernel:
+    8 waves per SIMD of independent v_qsad_pk_u16_u8 chains) -- boxes of this pool differ in sustained clock by more than the full search's
+    distance from its roof, so a stored figure from another box misprices it either way; then the stored round-3 measurement; then the nominal rate."""
+    import subprocess
+    try:
+        from hevcasm_amd import capi
+        exe = os.path.join(os.path.dirname(capi.LIB_PATH), "ubench_qsad_rate")
+        out = subprocess.run([exe, "live"], capture_output=True, text=True, timeout=120)
+        v = float(out.stdout.strip().splitlines()[-1])
+        if out.returncode == 0 and 50.0 < v < 400.0:
+            return v, "measured live: hevcasm_amd/lib/ubench_qsad_rate (tools/ubench/qsad_rate.hip), same box, same run"
+    except Exception:   # noqa: BLE001 -- no probe, no GPU, nonsense output: fall through to the stored figure
+        pass
     try:
         with open(os.path.join(ROOT, "profiles", "r03_qsad_rate.json")) as f:
             return float(json.load(f)["v_qsad_pk_u16_u8_tera_byte_differences_per_s"]), "measured: tools/ubench/qsad_rate.hip, profiles/r03_qsad_rate.txt"

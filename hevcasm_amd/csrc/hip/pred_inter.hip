@@ -103,6 +103,10 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 }
 // (bi-prediction keeps the compiler's own choice: with the single instructions its two streams need 174 registers, 2 waves per SIMD instead of 3)
 template <bool LEAN> __device__ __forceinline__ int first_dot(uint32_t a, uint32_t b) { return LEAN ? dot2_first(a, b) : dot2(a, b, 0); }
+// The 14-bit intermediate of bi-prediction: (int16_t)(S >> 6).  The reference's second pass assigns its int sum to an int16_t (pred_inter.c:125
+// through the 16-bit dst of :519-527), so a sum beyond int16 WRAPS -- reachable: 255 under every positive tap and 0 under every negative one in both
+// directions gives 33 150 (tests/cases.py: bi8_wrap).  One v_bfe_i32 (bits 6..21, sign-extended) where a plain shift is one v_ashrrev_i32.
+__device__ __forceinline__ int trunc16_shr6(int s) { return __builtin_amdgcn_sbfe(s, 6, 16); }
 __device__ __forceinline__ uint32_t med3_u32(uint32_t x, uint32_t lo, uint32_t hi)
 {
 	uint32_t r;
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 			int t[4];
 #pragma unroll
 			for (int b = 0; b < 4; ++b)
-				t[b] = BI ? (s[0][4 * m + b] >> 6) + (s[NREF - 1][4 * m + b] >> 6) + 64 : s[0][4 * m + b];   // uni: 2048 already inside (vertical()'s seed)
+				t[b] = BI ? trunc16_shr6(s[0][4 * m + b]) + trunc16_shr6(s[NREF - 1][4 * m + b]) + 64 : s[0][4 * m + b];   // uni: 2048 already inside (vertical()'s seed)
 			constexpr int SHIFT = BI ? 7 : 12;
 			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
 			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
@@ -795,7 +799,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 			int t[4];
 #pragma unroll
 			for (int q = 0; q < 4; ++q)
-				t[q] = BI ? (s[0][4 * m + q] >> 6) + (s[NREF - 1][4 * m + q] >> 6) + 64 : s[0][4 * m + q];
+				t[q] = BI ? trunc16_shr6(s[0][4 * m + q]) + trunc16_shr6(s[NREF - 1][4 * m + q]) + 64 : s[0][4 * m + q];
 			constexpr int SHIFT = BI ? 7 : 12;
 			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
 			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);

@@ -104,6 +104,30 @@ __device__ __forceinline__ int dot2(uint32_t pair, int c_lo, int c_hi, int acc)
 	return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, pair), __builtin_bit_cast(s16x2, c), acc, false);
 }
 
+// The FIRST product of a sum.  Left to the compiler, every sum starts as v_mov acc, 0 (or bias) + v_dot2c_i32_i16 acc, literal, pair: the VOP2
+// form accumulates in place and takes its coefficient pair as a literal, so it needs its accumulator preset -- 74 v_mov in the 32x32 kernel, a tenth of
+// its vector instructions, in a kernel whose VALU is 73-84 % busy at large launches (profiles/r04_pred_transform_counters.txt).  The VOP3P form takes
+// the addend as an operand (inline 0, or the bias held in a register) and the coefficient pair from an SGPR (an s_mov on the scalar unit): no v_mov.
+#ifndef HEVCASM_DOT2_FIRST_PLAIN
+__device__ __forceinline__ int dot2_first(uint32_t pair, int c_lo, int c_hi)
+{
+	int r;
+	const uint32_t c = ((uint32_t)c_lo & 0xffffu) | ((uint32_t)c_hi << 16);
+	asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(pair), "s"(c));
+	return r;
+}
+__device__ __forceinline__ int dot2_first(uint32_t pair, int c_lo, int c_hi, int bias /* in a VGPR */)
+{
+	int r;
+	const uint32_t c = ((uint32_t)c_lo & 0xffffu) | ((uint32_t)c_hi << 16);
+	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(pair), "s"(c), "v"(bias));
+	return r;
+}
+#else
+__device__ __forceinline__ int dot2_first(uint32_t pair, int c_lo, int c_hi) { return dot2(pair, c_lo, c_hi, 0); }
+__device__ __forceinline__ int dot2_first(uint32_t pair, int c_lo, int c_hi, int bias) { return dot2(pair, c_lo, c_hi, bias); }
+#endif
+
 // n-point stage of the N-point inverse transform; its inputs are every (N / n)-th row, found in
 // pairs p[base ...].  out[i] = bias + sum over those rows.
 template <int N, int n> struct InversePacked
@@ -115,9 +139,9 @@ template <int N, int n> struct InversePacked
 #pragma unroll
 		for (int k = 0; k < n / 2; ++k)
 		{
-			int o = 0;
+			int o = dot2_first(p[base], dct<n>(1, k), dct<n>(3, k));
 #pragma unroll
-			for (int q = 0; q < n / 4; ++q) o = dot2(p[base + q], dct<n>(4 * q + 1, k), dct<n>(4 * q + 3, k), o);
+			for (int q = 1; q < n / 4; ++q) o = dot2(p[base + q], dct<n>(4 * q + 1, k), dct<n>(4 * q + 3, k), o);
 			out[k] = e[k] + o;
 			out[n - 1 - k] = e[k] - o;
 		}
@@ -127,18 +151,18 @@ template <int N> struct InversePacked<N, 2>
 {
 	static __device__ __forceinline__ void run(const uint32_t (&p)[N / 2], int base, int bias, int (&out)[2])
 	{
-		out[0] = dot2(p[base], 64, 64, bias);
-		out[1] = dot2(p[base], 64, -64, bias);
+		out[0] = dot2_first(p[base], 64, 64, bias);
+		out[1] = dot2_first(p[base], 64, -64, bias);
 	}
 };
 
 // 4-point inverse DST-VII on the same pair order as the 4-point DCT: p[0] = (s1, s3), p[1] = (s0, s2)
 __device__ __forceinline__ void dst4_inverse_packed(const uint32_t (&p)[2], int bias, int (&o)[4])
 {
-	o[0] = dot2(p[1], 29, 84, dot2(p[0], 74, 55, bias));
-	o[1] = dot2(p[1], 55, -29, dot2(p[0], 74, -84, bias));
-	o[2] = dot2(p[1], 74, -74, dot2(p[0], 0, 74, bias));
-	o[3] = dot2(p[1], 84, 55, dot2(p[0], -74, -29, bias));
+	o[0] = dot2(p[1], 29, 84, dot2_first(p[0], 74, 55, bias));
+	o[1] = dot2(p[1], 55, -29, dot2_first(p[0], 74, -84, bias));
+	o[2] = dot2(p[1], 74, -74, dot2_first(p[0], 0, 74, bias));
+	o[3] = dot2(p[1], 84, 55, dot2_first(p[0], -74, -29, bias));
 }
 
 template <int N, bool DST> __device__ __forceinline__ void inverse_packed(const uint32_t (&p)[N / 2], int bias, int (&out)[N])
@@ -244,6 +268,19 @@ template <int N, bool STREAM = false> __device__ __forceinline__ void global_row
 		}
 	}
 }
+// the same as N / 2 raw dwords (int16 pairs as they lie in memory)
+template <int N, bool STREAM = false> __device__ __forceinline__ void global_row_load_raw(const int16_t *p, uint32_t (&d)[N / 2])
+{
+	constexpr int CB = N >= 8 ? 16 : 8;
+#pragma unroll
+	for (int q = 0; q < 2 * N / CB; ++q)
+	{
+		Chunk<CB> c;
+		if (STREAM) c.load_stream(reinterpret_cast<const uint8_t *>(p) + q * CB); else c.load(reinterpret_cast<const uint8_t *>(p) + q * CB);
+#pragma unroll
+		for (int k = 0; k < CB / 4; ++k) d[q * (CB / 4) + k] = c.d[k];
+	}
+}
 template <int N, bool STREAM = false> __device__ __forceinline__ void global_row_store(int16_t *p, const int (&v)[N])
 {
 	constexpr int CB = N >= 8 ? 16 : 8;
@@ -312,30 +349,32 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 
 	// row t of the coefficient block -> column-major pairs in P1 (dequantised on the way when fused)
 	// coefficients are read once: as streaming loads at 16x16 (-4 %); at 32x32 two lanes share each line and it costs 8 %
-	global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
+	uint32_t raw[N / 2];
+	if (DEQUANT) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
+	else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
 #pragma unroll
 	for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
 	__builtin_amdgcn_sched_barrier(0);
-	if (DEQUANT)
-	{
-		// quantize.c:53-62.  scale < 2^15 (checked by the entry point) and the levels are int16: telling the
-		// compiler so turns a quarter-rate v_mul_lo_u32 per coefficient into a full-rate v_mad_i32_i24
-		const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;
-#pragma unroll
-		for (int k = 0; k < N; ++k) v[k] = (v[k] * scale24 + round) >> shift;   // the clip to int16 is the saturating pack below
-	}
 	{
 		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
 		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
 		if (DEQUANT)
 		{
+			// quantize.c:53-62: clip16((level * scale + round) >> shift).  scale < 2^15 (checked by the entry point) and the levels are int16, so the
+			// product is v_mad_i32_i16, which picks either half of the loaded dword by op_sel (no unpacking of the pair) and adds the rounding
+			// constant; the clip to int16 is the saturating pack.  2.5 vector instructions per level (was 3.5: r04_fused_dct32_order.txt has the
+			// before / after; the fused kernel is VALU-bound at large launches, its extra instructions are what it costs over the plain one)
 			typedef short s16x2v __attribute__((ext_vector_type(2)));
+			const int round = 1 << (shift - 1);
 #pragma unroll
-			for (int x = 0; x < N; x += 2)
+			for (int k = 0; k < N / 2; ++k)
 			{
-				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(v[x], v[x + 1]));   // v_cvt_pk_i16_i32 saturates
-				row[2 * x] = (int16_t)two;                 // ds_write_b16
-				row[2 * x + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
+				int lo, hi;
+				asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(lo) : "v"(raw[k]), "s"(scale), "v"(round));
+				asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(raw[k]), "s"(scale), "v"(round));
+				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo >> shift, hi >> shift));   // v_cvt_pk_i16_i32 saturates
+				row[4 * k] = (int16_t)two;                 // ds_write_b16
+				row[4 * k + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
 			}
 		}
 		else
@@ -353,8 +392,15 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	inverse_packed<N, DST>(p, 64, w);
 	{
 		int16_t *col = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p2) + my_pair_bytes);
+		// the clip to int16 is the saturating pack of two rows' values; its halves go out as ds_write_b16 / ds_write_b16_d16_hi
+		typedef short s16x2w __attribute__((ext_vector_type(2)));
 #pragma unroll
-		for (int y = 0; y < N; ++y) col[y * (T::S2 * 2)] = (int16_t)clip3(-32768, 32767, w[y] >> 7);
+		for (int y = 0; y < N; y += 2)
+		{
+			const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2w)__builtin_amdgcn_cvt_pk_i16(w[y] >> 7, w[y + 1] >> 7));
+			col[y * (T::S2 * 2)] = (int16_t)two;
+			col[(y + 1) * (T::S2 * 2)] = (int16_t)(two >> 16);
+		}
 	}
 	__syncthreads();
 

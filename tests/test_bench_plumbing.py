@@ -39,8 +39,10 @@ def test_qsad_roof_is_the_measured_one():
     peak, src = bench.qsad_peak()
     with open(os.path.join(ROOT, "profiles", "r03_qsad_rate.json")) as f:
         rec = json.load(f)
-    assert peak == rec["v_qsad_pk_u16_u8_tera_byte_differences_per_s"] and "measured" in src
-    assert 0.85 < peak / bench.NOMINAL_QSAD_TBYTEDIFFS < 1.0       # 17.2 cycles per instruction against the nominal 16
+    assert "measured" in src
+    if "live" not in src:          # no GPU here: the stored round-3 measurement (on a GPU box the probe runs and its figure is that box's)
+        assert peak == rec["v_qsad_pk_u16_u8_tera_byte_differences_per_s"]
+    assert 0.75 < peak / bench.NOMINAL_QSAD_TBYTEDIFFS < 1.05      # 17.2 cycles per instruction against the nominal 16, at the box's clock
 
 
 def test_gather_without_a_process_group_is_the_identity():

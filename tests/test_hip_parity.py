@@ -170,6 +170,48 @@ def test_pred_full_size_properties():
         assert np.array_equal(cases._dst_rows(got, c["stride_dst"], c["dst_off"][a:], w, h), cases._dst_rows(want, c["stride_dst"], c["dst_off"][a:], w, h))
 
 
+@pytest.mark.parametrize("taps", [8, 4])
+def test_pred_one_1080p_frame_of_every_pu_size(taps):
+    """BASELINE.json configs[2] literally: one 1920x1080 luma frame (8 taps) / one 960x540 chroma plane (4 taps) tiled by each of the 24 HEVC PU
+    sizes of reference pred_inter.c:438-444 in turn (22 for bi, :687-693).  Per size: integer vectors copy the reference block exactly, bi-prediction
+    of a block with itself returns it, and with fractions over all phases the LAST 200 PUs of the frame equal the oracle, uni and bi (the frame's
+    tail: partial waves, partial workgroups, the strip / stream / segment launch choices of every size at its real launch size)."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    fw, fh = (1920, 1080) if taps == 8 else (960, 540)
+    for (lw, lh) in wl.PU_SIZES:
+        w, h = lw * taps // 8, lh * taps // 8
+        n = (fw // w) * (fh // h)
+        c = wl.pred_case(taps, w, h, n, 3100 + lw + 3 * lh, frame=(fw, fh), fracs=(0, 0))
+        ref, dst_off, ref_off, frac = B.u8(c["ref0"]), B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"])
+        dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.pred_uni(dst, c["stride_dst"], ref, c["stride_ref"], dst_off, ref_off, frac, taps, w, h)
+        torch.cuda.synchronize()
+        assert np.array_equal(cases._dst_rows(dst.cpu().numpy(), c["stride_dst"], c["dst_off"], w, h), cases._dst_rows(c["ref0"], c["stride_ref"], c["ref0_off"], w, h)), (taps, w, h, "copy")
+        bi_ok = (lw, lh) in wl.PU_SIZES_BI
+        if bi_ok:
+            dst2 = torch.zeros_like(dst)
+            B.pred_bi(dst2, c["stride_dst"], ref, ref, c["stride_ref"], dst_off, ref_off, ref_off, frac, frac, taps, w, h)
+            torch.cuda.synchronize()
+            assert torch.equal(dst, dst2), (taps, w, h, "bi of a block with itself")
+        a = max(0, n - 200)
+        c = wl.pred_case(taps, w, h, n, 3200 + lw + 3 * lh, bi=bi_ok, frame=(fw, fh))
+        dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.pred_uni(dst, c["stride_dst"], B.u8(c["ref0"]), c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.u8(c["frac0"]), taps, w, h)
+        torch.cuda.synchronize()
+        want = pyoracle.pred_uni_batch(taps, c["dst_bytes"], c["stride_dst"], c["ref0"], c["stride_ref"], c["dst_off"][a:], c["ref0_off"][a:], c["frac0"][a:], w, h)
+        assert np.array_equal(cases._dst_rows(dst.cpu().numpy(), c["stride_dst"], c["dst_off"][a:], w, h), cases._dst_rows(want, c["stride_dst"], c["dst_off"][a:], w, h)), (taps, w, h, "uni")
+        if bi_ok:
+            dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+            B.pred_bi(dst, c["stride_dst"], B.u8(c["ref0"]), B.u8(c["ref1"]), c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]), B.off32(c["ref1_off"]),
+                      B.u8(c["frac0"]), B.u8(c["frac1"]), taps, w, h)
+            torch.cuda.synchronize()
+            want = pyoracle.pred_bi_batch(taps, c["dst_bytes"], c["stride_dst"], c["ref0"], c["ref1"], c["stride_ref"], c["dst_off"][a:], c["ref0_off"][a:], c["ref1_off"][a:],
+                                          c["frac0"][a:], c["frac1"][a:], w, h)
+            assert np.array_equal(cases._dst_rows(dst.cpu().numpy(), c["stride_dst"], c["dst_off"][a:], w, h), cases._dst_rows(want, c["stride_dst"], c["dst_off"][a:], w, h)), (taps, w, h, "bi")
+
+
 def test_pred_two_planes_equal_two_single_plane_calls():
     """Cb and Cr in one launch (hevcasm_hip_pred_*_batch_2planes: one PU list, two planes of the destination and of each
     reference) give exactly the bytes of two single-plane calls, which the cases above compare with the oracle; plane a

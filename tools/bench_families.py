@@ -168,13 +168,13 @@ def bench_pred_latency(reps=30):
         torch.cuda.empty_cache()
 
 
-def bench_transform(coeffs_per_launch=1 << 26, only=None):
+def bench_transform(coeffs_per_launch=1 << 26, only=None, label=""):
     for tr, lg in wl.TRANSFORMS:
         if only and (tr, lg) not in only:
             continue
         size = 1 << lg
         n = coeffs_per_launch >> (2 * lg)
-        tag = "dst4" if tr else "dct%d" % size
+        tag = ("dst4" if tr else "dct%d" % size) + label
         cs = [wl.inverse_case(tr, lg, n, 70 + i, "natural", frame=(wl.FRAME_W, wl.FRAME_H)) for i in range(2)]
         devs = [dict(pred=B.u8(c["pred"]), pred_off=B.off32(c["pred_off"]), dst=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"),
                      dst_off=B.off32(c["dst_off"]), coeffs=B.i16(c["coeffs"])) for c in cs]

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstring>
 #define ITER 2048
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 enum { SAD, QSAD, MQSAD, MQSAD32, SADPAIR };
@@ -65,9 +66,13 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t *out, uint32
 	out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+static int g_cus = 256;
+static bool g_quiet = false;
+static double g_last = 0;      // T byte differences/s of the last run
+
 template <int OP> void run(const char *name, double diffs_per_inst, double insts_per_iter)
 {
-	const int blocks = 256 * 8;   // 8 workgroups of 4 waves per CU -> 8 waves per SIMD
+	const int blocks = g_cus * 8;   // 8 workgroups of 4 waves per CU -> 8 waves per SIMD
 	uint32_t *out;
 	hipMalloc(&out, blocks * 256 * 4);
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -81,13 +86,25 @@ template <int OP> void run(const char *name, double diffs_per_inst, double insts
 	}
 	const double insts_per_simd = 8.0 * ITER * insts_per_iter;
 	const double wall_cycles = best * 1e-3 * 2.4e9;
-	const double chip = 256.0 * 4 * 64 * diffs_per_inst * insts_per_simd / (best * 1e-3);    // byte differences per second, whole chip
-	printf("%-18s %.3f ms  %.2f cycles per wave-instruction @2.4 GHz  ->  %.1f T byte differences/s per chip\n", name, best, wall_cycles / insts_per_simd, chip / 1e12);
+	const double chip = (double)g_cus * 4 * 64 * diffs_per_inst * insts_per_simd / (best * 1e-3);    // byte differences per second, whole chip
+	g_last = chip / 1e12;
+	if (!g_quiet) printf("%-18s %.3f ms  %.2f cycles per wave-instruction @2.4 GHz  ->  %.1f T byte differences/s per chip\n", name, best, wall_cycles / insts_per_simd, chip / 1e12);
 	hipFree(out);
 }
 
-int main()
+// `qsad_rate live`: only the v_qsad_pk_u16_u8 rate, as one number (T byte differences/s) -- what bench.py prices the full search against,
+// measured in the same run on the same box (clocks differ from box to box by more than the kernel's distance from this roof)
+int main(int argc, char **argv)
 {
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, 0) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+	if (argc > 1 && !strcmp(argv[1], "live"))
+	{
+		g_quiet = true;
+		run<QSAD>("v_qsad_pk_u16_u8", 16, 16);
+		printf("%.3f\n", g_last);
+		return 0;
+	}
 	run<SAD>("v_sad_u8", 4, 16); run<QSAD>("v_qsad_pk_u16_u8", 16, 16); run<MQSAD>("v_mqsad_pk_u16_u8", 16, 16); run<MQSAD32>("v_mqsad_u32_u8", 16, 16);
 	run<SADPAIR>("4 sad_u8 + alignbyte", 16.0 / 5, 20);
 	return 0;

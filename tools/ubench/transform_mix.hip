@@ -1,0 +1,83 @@
+// The memory side of the inverse transform + add kernels with the arithmetic taken out: what rate does THIS access mix reach on gfx950?
+//   per N x N block: 2 N^2 bytes of coefficients read as one contiguous run (16-byte lane loads), N prediction rows of N bytes read and N
+//   destination rows of N bytes written, rows a frame stride apart, blocks tiling 1920 x 1152 frames in raster order (tools/bench_families.py's
+//   layout: prediction stride 1920, destination stride 1952), lanes dealt as transform.hip deals them (add stage: consecutive lanes = the same row
+//   of consecutive blocks).  Reads : writes = 3 : 1, 4 N^2 algorithmic bytes per block.
+// Every transform kernel of every size takes 0.21-0.23 ms for 2^28 coefficients whatever its arithmetic (profiles/r04_transform_valu_trim_ab.txt);
+// this probe says how much of that is the access mix itself.   hipcc --offload-arch=gfx950 -O3 transform_mix.hip -o transform_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+template <int N> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *pred, const int16_t *coeffs, uint32_t n_blocks, int per_row, int per_frame)
+{
+	constexpr int BPWG = 256 / N;
+	// XCD-contiguous workgroup order, as the library's kernels use
+	const uint32_t nwg = gridDim.x, per_xcd = (nwg + 7) / 8, wg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (wg >= nwg) return;
+	const uint32_t local = threadIdx.x / N, t = threadIdx.x % N;
+	uint32_t blk = wg * BPWG + local;
+	if (blk >= n_blocks) blk = n_blocks - 1;
+	// coefficients: row t of block blk, 2 N bytes
+	const u32x4 *c = reinterpret_cast<const u32x4 *>(coeffs + (size_t)blk * N * N + t * N);
+	u32x4 acc = c[0];
+#pragma unroll
+	for (int q = 1; q < 2 * N / 16; ++q) { const u32x4 v = c[q]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+	// add stage deal: lane = (row t2, block local2)
+	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
+	uint32_t blk2 = wg * BPWG + local2;
+	if (blk2 >= n_blocks) blk2 = n_blocks - 1;
+	const uint32_t f = blk2 / per_frame, r = blk2 % per_frame, by = r / per_row, bx = r % per_row;
+	const size_t po = ((size_t)f * 1152 + by * N + t2) * 1920 + bx * N, dof = ((size_t)f * 1152 + by * N + t2) * 1952 + 16 + bx * N;
+	const u32x4 *p = reinterpret_cast<const u32x4 *>(pred + po);
+	u32x4 *d = reinterpret_cast<u32x4 *>(dst + dof);
+	// the exchange through LDS that makes the stores depend on the coefficient loads of OTHER lanes (as the transposes do)
+	__shared__ uint32_t x[256];
+	x[threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	__syncthreads();
+	const uint32_t mixin = x[(threadIdx.x * 7 + 3) & 255];
+#pragma unroll
+	for (int q = 0; q < N / 16; ++q)
+	{
+		u32x4 v = p[q];
+		v.x ^= mixin; v.y += mixin; v.z ^= mixin; v.w += mixin;
+		d[q] = v;
+	}
+}
+
+template <int N> void run(size_t coeffs_total)
+{
+	const size_t n = coeffs_total / (N * N);
+	const int per_row = 1920 / N, per_frame = per_row * (1152 / N);
+	const size_t frames = (n + per_frame - 1) / per_frame;
+	uint8_t *dst, *pred; int16_t *co;
+	if (hipMalloc(&dst, frames * 1152 * 1952 + 64) || hipMalloc(&pred, frames * 1152 * 1920 + 64) || hipMalloc(&co, coeffs_total * 2)) { printf("alloc failed\n"); return; }
+	hipMemset(pred, 1, frames * 1152 * 1920); hipMemset(co, 2, coeffs_total * 2);
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	const uint32_t grid = (uint32_t)((n + 256 / N - 1) / (256 / N));
+	std::vector<float> ms;
+	for (int rep = 0; rep < 8; ++rep)
+	{
+		hipEventRecord(e0); mix<N><<<grid, 256>>>(dst, pred, co, (uint32_t)n, per_row, per_frame); hipEventRecord(e1); hipDeviceSynchronize();
+		float t; hipEventElapsedTime(&t, e0, e1);
+		if (rep) ms.push_back(t);
+	}
+	float best = 1e9f, sum = 0;
+	for (float t : ms) { best = t < best ? t : best; sum += t; }
+	const double bytes = 4.0 * coeffs_total;
+	printf("%2dx%-2d  2^%d coefficients  mean %.4f ms  min %.4f ms  ->  %.0f GB/s algorithmic (%.3f of 8 TB/s)\n", N, N, (int)(63 - __builtin_clzll(coeffs_total)), sum / ms.size(), best,
+			bytes / (sum / ms.size() * 1e-3) / 1e9, bytes / (sum / ms.size() * 1e-3) / 8e12);
+	hipFree(dst); hipFree(pred); hipFree(co);
+}
+
+int main()
+{
+	for (size_t total : { (size_t)1 << 26, (size_t)1 << 28 })
+	{
+		run<16>(total);
+		run<32>(total);
+	}
+	return 0;
+}
