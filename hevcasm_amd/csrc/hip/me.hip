@@ -128,6 +128,9 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const int full_items = cnt * nfg;
 	const int whole = full_items & ~(kThreads - 1);             // dealt as full items
 	const int quarters = 4 * (full_items - whole) + cnt * rem_q;
+	// (Round 4: dealing the lanes so that every 16-lane group of a ds_read_b128 covers all 64 LDS banks -- two candidate rows 384 bytes apart per group
+	// instead of rows 192 bytes apart, which collide 2-way -- removes the bank conflicts of profiles/r03_me_counters.txt and changes nothing:
+	// +0.9 % on the 4K frame, profiles/r04_me_lane_deal_ab.txt.  The LDS is 41 % busy; the kernel waits on the v_qsad issue rate.  Natural deal kept.)
 	for (int item = threadIdx.x; item < whole; item += kThreads)
 	{
 		const int cy = item / nfg, g = item - cy * nfg;   // candidates (cy, 16 g .. 16 g + 15)

@@ -289,6 +289,11 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	}
 };
 
+// luma bi-prediction on the branch-free loop starts its horizontal sums on the VOP3P dot product too (round 4: 156 -> 164 registers, still three
+// waves per SIMD; -2.2 % over the 22 PU sizes, -4.6 ... +0.9 %: profiles/r04_pred_bi_lean_ab.txt); the other bi variants would lose a wave
+#ifndef HEVCASM_BI_LEAN
+#define HEVCASM_BI_LEAN 1
+#endif
 template <bool B> struct Flag { static constexpr bool value = B; };
 
 // a second set of planes for the same PU list (null dst = none), as byte distances from the first set
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 			}
 			uint32_t ve[Stream::NX], vo[Stream::NX];
 			rs[r].template vertical<!BI>(i, 0x00200020u, ve, vo);
-			rs[r].template horizontal<!BI>(ve, vo, s[r]);
+			rs[r].template horizontal<(!BI || (HEVCASM_BI_LEAN && FAST && TAPS == 8))>(ve, vo, s[r]);
 		}
 		// shift, saturate to [0, 255] and pack: v_ashr_pk_u8_i32 does two pixels per instruction
 		uint32_t px[NDW];
@@ -676,7 +681,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
 	int W, int H, int S /* strips per PU */, int PPW /* PUs per wave */, uint32_t n_blocks,
-	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
+	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1, int log2_segments)
 {
 	if (blockIdx.y)
 	{
@@ -687,7 +692,14 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int TAPS = 4, UNROLL = AHEAD > TAPS ? AHEAD : TAPS;
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	// row segments (round 4): a small launch of tall PUs is few, long waves -- 64 frames of 8x32 chroma PUs are 1920 waves of 32 rows, not two
+	// per SIMD -- so such launches cut every PU into 2 or 4 segments of rows, one wave each (neighbouring waves: the 3 window rows two segments
+	// share come from the L2), exactly as pred_stream_kernel does; the segment is the PU as far as the rest of the kernel is concerned
+	const uint32_t seg = wave & ((1u << log2_segments) - 1u);
+	wave >>= log2_segments;
+	H >>= log2_segments;
+	const uint32_t seg_row0 = seg * (uint32_t)H;
 	const int lane = threadIdx.x & 63;
 	int sub = lane / S;
 	int strip = lane - sub * S;
@@ -709,7 +721,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 		const int frac = (r ? frac1 : frac0)[pu];
 		const bool fx = (frac & 15) != 0, fy = (frac >> 4) != 0;
 		const int need = cols + (fx ? TAPS - 1 : 0);
-		const uint32_t first = (r ? ref1_off : ref0_off)[pu] - (fy ? step_ref : 0u) + (uint32_t)(8 * strip - (fx ? 1 : 0));
+		const uint32_t first = (r ? ref1_off : ref0_off)[pu] + seg_row0 * step_ref - (fy ? step_ref : 0u) + (uint32_t)(8 * strip - (fx ? 1 : 0));
 		const uint32_t last = first + (uint32_t)(H - 1 + (fy ? TAPS - 1 : 0)) * step_ref;
 		rs[r].plane = r ? ref1 : ref0;
 		rs[r].off = first;
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 		rs[r].last_load = hi_w - 16u;          // >= lo_w: the launcher guarantees a span of at least 16 bytes
 		(void)lo_w;
 	}
-	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * strip);
+	uint32_t out_off = dst_off[pu] + seg_row0 * step_dst + (uint32_t)(8 * strip);
 
 	// prologue: window rows 0 .. 2 into slots 0 .. 2, rows 3 .. 6 in flight
 #pragma unroll
@@ -860,15 +872,26 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 		int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
 {
 	const int strips = (W + 7) / 8, ppw = kWave / strips;
-	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
+	// Small launches of tall PUs: segments of 8 or 16 rows, one wave each (see the kernel).  Only where the segment keeps the 8-rows-in-flight
+	// branch-free loop (a multiple of 8 rows).  Same box, 64 frames per launch: profiles/r04_pred_strip_segments_ab.txt
+	static const bool no_segments = getenv("HEVCASM_PRED_NOSEGMENTS") != nullptr;     // A/B switch, read once per process
+	size_t waves = ceil_div(n, (size_t)ppw) * (size_t)p2.count;
+	int log2_segments = 0;
+	while (!no_segments && log2_segments < 2 && waves < 16384 && (H >> (log2_segments + 1)) >= 8 && (H >> (log2_segments + 1)) % 8 == 0)
+	{
+		++log2_segments;
+		waves *= 2;
+	}
+	const uint32_t grid = ceil_div(waves / (size_t)p2.count, (size_t)(kThreads / kWave));
+	const int Hs = H >> log2_segments;
 	// Rows in flight: 4 (the ring turns once per unrolled group of TAPS rows) or 8 -- with 8, an 8-row PU has its whole 11-row window in
 	// flight before the first row is computed.  Same box (profiles/r03_pred_strip_ab.txt): 8x8 uni -18 %, 8x16 -8 % / -11 % (uni / bi), 16x16 -5 %,
 	// 6x8 uni -10 %; heights that are not multiples of 8 take the general row loop with it and lose 20-30 %, 2-wide and bi 6-wide lose 8-16 %.
-	const bool ahead8 = H % 8 == 0 && W >= 6 && !(BI && W < 8);
+	const bool ahead8 = Hs % 8 == 0 && W >= 6 && !(BI && W < 8);
 #define STRIP(FASTV, AH) hipLaunchKernelGGL((pred_strip4_kernel<BI, FASTV, AH>), dim3(grid, p2.count), dim3(kThreads), 0, st, \
-		dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
-	if (ahead8) STRIP(true, 8);            // H % 8 == 0 here: always the branch-free row loop
-	else if (H % 4 == 0) STRIP(true, 4);
+		dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1, log2_segments)
+	if (ahead8) STRIP(true, 8);            // Hs % 8 == 0 here: always the branch-free row loop
+	else if (Hs % 4 == 0) STRIP(true, 4);
 	else STRIP(false, 4);
 #undef STRIP
 	return launch_status("pred_strip4_kernel");

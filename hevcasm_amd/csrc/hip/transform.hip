@@ -349,8 +349,11 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 
 	// row t of the coefficient block -> column-major pairs in P1 (dequantised on the way when fused)
 	// coefficients are read once: as streaming loads at 16x16 (-4 %); at 32x32 two lanes share each line and it costs 8 %
+	// (the op_sel form of the fused dequantisation only at 32x32: at 16x16 it measured +2 % / +6 % at 2^26 / 2^28 coefficients, twice, same box:
+	// profiles/r04_transform_valu_trim_ab.txt -- that kernel is not VALU-bound and liked the older instruction mix better)
+	constexpr bool DEQ_OPSEL = DEQUANT && N == 32;
 	uint32_t raw[N / 2];
-	if (DEQUANT) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
+	if (DEQ_OPSEL) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
 	else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
 #pragma unroll
 	for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	{
 		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
 		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
-		if (DEQUANT)
+		if (DEQ_OPSEL)
 		{
 			// quantize.c:53-62: clip16((level * scale + round) >> shift).  scale < 2^15 (checked by the entry point) and the levels are int16, so the
 			// product is v_mad_i32_i16, which picks either half of the loaded dword by op_sel (no unpacking of the pair) and adds the rounding
@@ -375,6 +378,20 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo >> shift, hi >> shift));   // v_cvt_pk_i16_i32 saturates
 				row[4 * k] = (int16_t)two;                 // ds_write_b16
 				row[4 * k + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
+			}
+		}
+		else if (DEQUANT)
+		{
+			// telling the compiler that scale fits 24 bits turns a quarter-rate v_mul_lo_u32 per coefficient into a full-rate v_mad_i32_i24
+			typedef short s16x2v __attribute__((ext_vector_type(2)));
+			const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;
+#pragma unroll
+			for (int x = 0; x < N; x += 2)
+			{
+				const int a = (v[x] * scale24 + round) >> shift, b = (v[x + 1] * scale24 + round) >> shift;
+				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(a, b));   // v_cvt_pk_i16_i32 saturates: the clip to int16
+				row[2 * x] = (int16_t)two;                 // ds_write_b16
+				row[2 * x + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
 			}
 		}
 		else
