@@ -121,6 +121,20 @@ __device__ __forceinline__ uint32_t xcd_contiguous(uint32_t wg, uint32_t n_wg)
 	return start + k;
 }
 
+// wave-wide reductions of a 32-bit value (every lane ends up with the result)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, kWave));
+	return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, kWave));
+	return v;
+}
+
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
 // host side -------------------------------------------------------------------------------

@@ -597,20 +597,6 @@ static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, cons
 	return launch_status("pred_stream_kernel");
 }
 
-// wave-wide reductions of a 32-bit value (every lane ends up with the result)
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, d, kWave));
-	return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d, kWave));
-	return v;
-}
-
 // ---- 4-tap (chroma) prediction, one lane per 8-column strip ------------------------------------------------------------------
 //
 // A chroma PU row is narrow: an 8-wide PU's window is 11 bytes.  pred_stream_kernel gives it two lanes of 8 bytes (the second moved
