@@ -258,19 +258,46 @@ __device__ __forceinline__ void block_cost_sums(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int H /* rows of this part */, uint32_t lane, uint32_t blk, uint32_t row_first /* the part starts at this row of the block */, uint32_t (&total)[WAYS])
+	int H /* rows of this part */, uint32_t lane, uint32_t blk, uint32_t row_first /* the part starts at this row of the block */, uint32_t (&total)[WAYS],
+	int scalar_first = -1 /* >= 0: wave-uniform index of the wave's first block, all BPW of which exist: descriptors by scalar loads */)
 {
 	typedef Tiling<W, C, R> T;
 	constexpr int LPR = T::LPR, BPW = T::BPW;
+	// scalar descriptors where a wave holds 2 .. 16 blocks (one block: the caller's index is uniform already; 32 blocks: the picking costs more than it saves)
+	constexpr bool SCALAR_DESC = BPW >= 2 && BPW <= 16 && BPW * T::LPB == kWave;
 
 	typedef Deal<W, C, R, WAYS> D;
 	const uint32_t row0 = D::row(lane), chunk = D::chunk(lane);
 
-	// descriptor loads first: independent, one memory round trip
-	const uint32_t so = src_off[blk];
+	// Descriptors.  Left as per-lane vector loads they are a wave's first trip through the CU's vector-memory pipeline, which returns in order: a new
+	// wave's offsets queue behind the row loads of the waves already resident -- 5 k of a 16x16 wave's 11 k cycles pass before they arrive
+	// (profiles/r01_wave_timestamps.txt).  A wave's BPW blocks are consecutive in the arrays, so (round 4) a FULL wave fetches them with SCALAR loads
+	// (s_load_dwordx8 / x16 through the scalar cache: a separate, unordered path) and each lane then picks its block's words with v_cndmask on the
+	// bits of its block index.  scalar_first = the wave's first block (wave-uniform), or -1: the last, partial wave and the one-block-per-wave callers.
+	uint32_t so;
 	uint32_t ro[WAYS];
+	if (SCALAR_DESC && scalar_first >= 0)
+	{
+		const uint32_t sub = D::sub_block(lane);
+		uint32_t sv[BPW];
 #pragma unroll
-	for (int k = 0; k < WAYS; ++k) ro[k] = ref_off[(size_t)blk * WAYS + k];
+		for (int j = 0; j < BPW; ++j) sv[j] = src_off[(uint32_t)scalar_first + (uint32_t)j];
+		so = pick_by_index<BPW>(sv, sub);
+#pragma unroll
+		for (int k = 0; k < WAYS; ++k)
+		{
+			uint32_t rv[BPW];
+#pragma unroll
+			for (int j = 0; j < BPW; ++j) rv[j] = ref_off[(size_t)((uint32_t)scalar_first + (uint32_t)j) * WAYS + k];
+			ro[k] = pick_by_index<BPW>(rv, sub);
+		}
+	}
+	else
+	{
+		so = src_off[blk];
+#pragma unroll
+		for (int k = 0; k < WAYS; ++k) ro[k] = ref_off[(size_t)blk * WAYS + k];
+	}
 
 	// Addresses are a uniform base (SGPR pair) + a 32-bit per-lane offset (one VGPR per plane and
 	// candidate, one integer add per row step): every byte of every block lies within 4 GiB of its
@@ -448,10 +475,10 @@ __device__ __forceinline__ void block_cost_body(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live)
+	int *__restrict__ out, int H, uint32_t lane, uint32_t blk, bool live, int scalar_first = -1)
 {
 	uint32_t total[WAYS];
-	block_cost_sums<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, total);
+	block_cost_sums<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, total, scalar_first);
 	if (live && Deal<W, C, R, WAYS>::leader(lane))
 	{
 		if (WAYS == 4)
@@ -478,7 +505,7 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	typedef Tiling<W, C, R> T;
 	constexpr int BPW = T::BPW;
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t sub = Deal<W, C, R, WAYS>::sub_block(lane);
 	// Lanes past the batch (or the spare lanes of a wave when 64 % LPB != 0) redo the last valid
@@ -486,7 +513,13 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	uint32_t blk = wave * BPW + (sub < (uint32_t)BPW ? sub : BPW - 1);
 	const bool live = sub < (uint32_t)BPW && blk < n_blocks;
 	if (blk >= n_blocks) blk = n_blocks - 1;
-	block_cost_body<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live);
+	// a wave all of whose blocks exist reads its descriptors by scalar loads (block_cost_sums); HEVCASM_SAD_VECTOR_DESC = the A/B switch
+#ifndef HEVCASM_SAD_VECTOR_DESC
+	const int scalar_first = (wave + 1u) * (uint32_t)BPW <= n_blocks ? (int)(wave * (uint32_t)BPW) : -1;
+#else
+	const int scalar_first = -1;
+#endif
+	block_cost_body<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live, scalar_first);
 }
 
 // ---- 4-way SAD of wide blocks whose candidates lie close together: the union window goes through LDS ----------------
@@ -770,8 +803,15 @@ template <int W> struct StripPlan
 	static constexpr int MAX_DX = PITCH - W - 15 - 3 - 4;
 };
 
+// waves per workgroup of sad4_strip_kernel.  A wave reads only its own window, so the barrier that orders the LDS-DMA writes before the reads need not
+// wait for anybody else: one-wave workgroups (the generic kernels want four: their waves share L1 lines; here the sharing is inside the wave)
+#ifndef HEVCASM_SAD4_STRIP_WAVES
+#define HEVCASM_SAD4_STRIP_WAVES 1
+#endif
+constexpr int kStripWaves = HEVCASM_SAD4_STRIP_WAVES;
+
 template <int W, int U>
-__global__ __launch_bounds__(kThreads) void sad4_strip_kernel(
+__global__ __launch_bounds__(kStripWaves * kWave) void sad4_strip_kernel(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
@@ -783,7 +823,7 @@ __global__ __launch_bounds__(kThreads) void sad4_strip_kernel(
 
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave_in_wg = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t wave = wg * (kThreads / kWave) + wave_in_wg;
+	const uint32_t wave = wg * kStripWaves + wave_in_wg;
 	const uint32_t sub = lane >> 3, row0 = (lane & 7u) / P::LPR, chunk = lane % P::LPR;
 	uint32_t blk = wave * P::BPW + sub;
 	const bool live = blk < n_blocks;
@@ -795,12 +835,32 @@ __global__ __launch_bounds__(kThreads) void sad4_strip_kernel(
 	const uint32_t sr32 = (uint32_t)stride_ref, ss32 = (uint32_t)stride_src;
 
 	// ---- where the wave's 32 candidates lie ----
-	const uint32_t so = src_off[blk];
-	uint32_t o[4];
+	// Descriptors by SCALAR loads (the wave's 8 + 32 words are consecutive; see block_cost_sums): the lowest and the highest candidate start come out of
+	// scalar min / max chains, each lane picks its own block's words with v_cndmask.  Only a wave all of whose blocks exist; the batch's last, partial
+	// wave takes the generic code.
+	const uint32_t first = __builtin_amdgcn_readfirstlane(wave * P::BPW);
+	const bool full = first + P::BPW <= n_blocks;
+	uint32_t so = 0, o[4] = { 0, 0, 0, 0 }, base = 0, top_start = 0;
+	if (full)
+	{
+		uint32_t sv[P::BPW], rv[4][P::BPW];
 #pragma unroll
-	for (int k = 0; k < 4; ++k) o[k] = ref_off[(size_t)blk * 4 + k] + ref_mis;
-	const uint32_t base = wave_min_u32(min(min(o[0], o[1]), min(o[2], o[3])));        // the lowest candidate start of the wave: row 0 of the window
-	bool close = inv_stride != 0u;
+		for (int j = 0; j < P::BPW; ++j) sv[j] = src_off[first + (uint32_t)j];
+#pragma unroll
+		for (int j = 0; j < P::BPW; ++j)
+#pragma unroll
+			for (int k = 0; k < 4; ++k) rv[k][j] = ref_off[(size_t)(first + (uint32_t)j) * 4 + k];
+		base = rv[0][0]; top_start = rv[0][0];
+#pragma unroll
+		for (int j = 0; j < P::BPW; ++j)
+#pragma unroll
+			for (int k = 0; k < 4; ++k) { base = min(base, rv[k][j]); top_start = max(top_start, rv[k][j]); }
+		base += ref_mis; top_start += ref_mis;        // (offsets from the word-aligned plane base)
+		so = pick_by_index<P::BPW>(sv, sub);
+#pragma unroll
+		for (int k = 0; k < 4; ++k) o[k] = pick_by_index<P::BPW>(rv[k], sub) + ref_mis;
+	}
+	bool close = inv_stride != 0u && full;
 	int dx[4];
 	uint32_t Y[4];
 #pragma unroll
@@ -815,9 +875,9 @@ __global__ __launch_bounds__(kThreads) void sad4_strip_kernel(
 		dx[k] = r - 32;
 		Y[k] = q;
 	}
-	const int xmin = (int)wave_min_u32((uint32_t)(min(min(dx[0], dx[1]), min(dx[2], dx[3])) + 64)) - 64;      // (biased: the reduction is unsigned)
-	const int xmax = (int)wave_max_u32((uint32_t)(max(max(dx[0], dx[1]), max(dx[2], dx[3])) + 64)) - 64;
-	const uint32_t ymax = wave_max_u32(max(max(Y[0], Y[1]), max(Y[2], Y[3])));
+	const int xmin = (int)wave_min_u32_scalar((uint32_t)(min(min(dx[0], dx[1]), min(dx[2], dx[3])) + 64)) - 64;      // (biased: the reduction is unsigned)
+	const int xmax = (int)wave_max_u32_scalar((uint32_t)(max(max(dx[0], dx[1]), max(dx[2], dx[3])) + 64)) - 64;
+	const uint32_t ymax = wave_max_u32_scalar(max(max(Y[0], Y[1]), max(Y[2], Y[3])));
 	close = close && (xmax - xmin) <= P::MAX_DX && ymax <= (uint32_t)P::SPAN;
 	const bool windowed = __builtin_amdgcn_readfirstlane((int)(__ballot(!close) == 0ull)) != 0;
 
@@ -830,8 +890,7 @@ __global__ __launch_bounds__(kThreads) void sad4_strip_kernel(
 		const uint32_t left = (a_min - (wo & ~3u) + 15u) & ~15u;       // 0, 16 or 32
 		const uint32_t wbase = a_min - left;
 		// the highest word that holds a candidate byte: nothing at or above a_max + 4 may be read
-		uint32_t top = max(max(o[0], o[1]), max(o[2], o[3])) + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1);
-		const uint32_t a_max = wave_max_u32(top) & ~3u;
+		const uint32_t a_max = (top_start + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1)) & ~3u;
 		const uint32_t rows_n = (uint32_t)H + ymax, n_pieces = rows_n * (uint32_t)P::PR;
 
 		// source rows first (ordinary streaming loads into registers), then the window pieces (LDS-DMA)
@@ -945,9 +1004,9 @@ template <int W> static int launch_strip(const Args &a)
 {
 	typedef StripPlan<W> P;
 	const uint32_t inv = (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;
-	const uint32_t grid = ceil_div(a.n, (size_t)(P::BPW * (kThreads / kWave)));
-	const size_t lds = (size_t)(kThreads / kWave) * (size_t)(a.H + P::SPAN) * P::PITCH;
-#define STRIP_SAD(UU) hipLaunchKernelGGL((sad4_strip_kernel<W, UU>), dim3(grid), dim3(kThreads), lds, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
+	const uint32_t grid = ceil_div(a.n, (size_t)(P::BPW * kStripWaves));
+	const size_t lds = (size_t)kStripWaves * (size_t)(a.H + P::SPAN) * P::PITCH;
+#define STRIP_SAD(UU) hipLaunchKernelGGL((sad4_strip_kernel<W, UU>), dim3(grid), dim3(kStripWaves * kWave), lds, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
 	switch (a.H / P::R)
 	{
 	case 1: if constexpr (W == 8) { STRIP_SAD(1); } break;
