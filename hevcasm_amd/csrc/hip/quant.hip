@@ -106,13 +106,16 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	// walk along ONE frame row across neighbouring blocks (contiguous for raster-ordered blocks).
 	const uint32_t tid = threadIdx.x;
 	const uint32_t xpart = tid % LPR, b = (tid / LPR) % BPWG, y = tid / (LPR * BPWG);
-	const size_t blk = (size_t)xcd_contiguous(blockIdx.x, gridDim.x) * BPWG + b;
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const size_t blk = (size_t)wg * BPWG + b;
 	if (blk >= n_blocks) return;
 	const uint32_t x = xpart * PX;
+	// (round 4: the workgroup's offsets by scalar loads, as in sad.hip: -3 ... +3 %, nothing: profiles/r04_scalar_offsets_elsewhere_ab.txt)
+	const uint32_t po = pred_off[blk], ro = rec_off[blk];
 
 	Chunk<PX> p;
 	Chunk<2 * PX> r;
-	p.load(pred + pred_off[blk] + y * stride_pred + x);
+	p.load(pred + po + y * stride_pred + x);
 	// The residual of a 16x16 / 32x32 block is read once and a row is a whole number of 32-byte sectors per lane group:
 	// streaming loads leave the L1 to the prediction rows (16x16 0.066 -> 0.058 ms, 32x32 0.066 -> 0.057 per 2^26
 	// pixels; 8x8, whose 16-byte rows share lines across instructions, loses 7 % with them and keeps ordinary loads).
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 		const int v3 = clip3(0, 255, (int)(pd >> 24) + sext_hi(r.d[2 * k + 1]));
 		o.d[k] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
 	}
-	o.store(rec + rec_off[blk] + y * stride_rec + x);
+	o.store(rec + ro + y * stride_rec + x);
 }
 
 // 4x4 blocks: one lane per block (32 bytes of residual in two 16-byte loads, four row dwords in and

@@ -264,7 +264,10 @@ __device__ __forceinline__ void block_cost_sums(
 	typedef Tiling<W, C, R> T;
 	constexpr int LPR = T::LPR, BPW = T::BPW;
 	// scalar descriptors where a wave holds 2 .. 16 blocks (one block: the caller's index is uniform already; 32 blocks: the picking costs more than it saves)
-	constexpr bool SCALAR_DESC = BPW >= 2 && BPW <= 16 && BPW * T::LPB == kWave;
+#ifndef HEVCASM_SAD_SCALAR_DESC_MAX
+#define HEVCASM_SAD_SCALAR_DESC_MAX 16
+#endif
+	constexpr bool SCALAR_DESC = BPW >= 2 && BPW <= HEVCASM_SAD_SCALAR_DESC_MAX && BPW * T::LPB == kWave;
 
 	typedef Deal<W, C, R, WAYS> D;
 	const uint32_t row0 = D::row(lane), chunk = D::chunk(lane);
@@ -774,197 +777,9 @@ __global__ __launch_bounds__(kThreads) void sad4_window_kernel(
 	}
 }
 
-// ---- 4-way SAD of NARROW blocks (8 and 16 wide) whose candidates lie close together: one union window per WAVE, by LDS-DMA ----
-//
-// The generic kernel's narrow 4-way launches are bound by the CU's address unit (68-85 % busy: profiles/r04_sad4_counters.txt): every
-// candidate row of every block is its own lane load -- 16x16: 20 wave-level loads per 8 blocks, of which a lane uses 8 of the 12 bytes it
-// fetches -- and a wave-level load costs the address unit >= 16 cycles whatever its lanes carry.  Rounds 2-3 put the candidates' union window in
-// LDS three ways (per block, per 64-pixel run, per workgroup), staged through registers and ds_write, and lost or tied at these widths.
-// This form stages by LDS-DMA instead (global_load_lds_dwordx4: per-lane source address, destination = a wave-uniform LDS base + 16 * lane; no
-// registers, no ds_write, every trip in flight at once) and shares ONE window among the wave's 8 blocks:
-//   * a wave owns 8 consecutive blocks of the batch (8 lanes each: W / 8 lanes to a row, 8 / (W / 8) rows in flight, as the generic kernel);
-//   * window = the aligned 16-byte pieces that cover all 32 candidates: PR pieces per row, rows 0 .. H - 1 + (largest row displacement);
-//     16x16: 11 pieces x 30 rows = 5 wave-level loads instead of 16; 8x8: 7 x 22 = 2.4 instead of 8;
-//   * the wave qualifies when all 32 candidates lie within SPAN = 16 rows and WINW - W columns of each other (decided from the offsets alone, like
-//     sad4_window_kernel: offset differences split into rows and columns with the row stride); any other wave runs the generic code at this
-//     kernel's mapping (block_cost_sums, same deal of lanes);
-//   * memory touched: only aligned words between the lowest and the highest word that hold a byte of any of the wave's candidates: pieces start
-//     at the lowest such word + a multiple of 16, pieces outside that range are not loaded (their lanes are switched off), and the one piece that
-//     holds the highest word is loaded dword by dword.
-template <int W> struct StripPlan
-{
-	static constexpr int LPR = W / 8, R = 8 / LPR;             // lanes per row, rows in flight (8 lanes per block)
-	static constexpr int BPW = 8;                              // blocks per wave
-	static constexpr int SPAN = 16;                            // candidates at most this many rows apart
-	static constexpr int PR = W == 16 ? 11 : 7;                // 16-byte pieces per window row
-	static constexpr int PITCH = PR * 16;                      // LDS row pitch = window width in bytes: 176 / 112
-	// the widest span of candidate starts that still fits: the window begins up to 15 + 3 bytes left of the leftmost candidate (pieces are aligned to the
-	// lowest candidate word mod 16), and the compute phase reads 12 bytes from the aligned word that holds a lane's first byte
-	static constexpr int MAX_DX = PITCH - W - 15 - 3 - 4;
-};
-
-// waves per workgroup of sad4_strip_kernel.  A wave reads only its own window, so the barrier that orders the LDS-DMA writes before the reads need not
-// wait for anybody else: one-wave workgroups (the generic kernels want four: their waves share L1 lines; here the sharing is inside the wave)
-#ifndef HEVCASM_SAD4_STRIP_WAVES
-#define HEVCASM_SAD4_STRIP_WAVES 1
-#endif
-constexpr int kStripWaves = HEVCASM_SAD4_STRIP_WAVES;
-
-template <int W, int U>
-__global__ __launch_bounds__(kStripWaves * kWave) void sad4_strip_kernel(
-	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
-	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
-	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, uint32_t n_blocks, uint32_t inv_stride /* floor(2^32 / stride_ref) + 1; 0: every wave takes the generic code */)
-{
-	typedef StripPlan<W> P;
-	constexpr int H = U * P::R;
-	extern __shared__ __attribute__((aligned(16))) uint8_t strip_lds[];
-
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t wave_in_wg = threadIdx.x >> 6, lane = threadIdx.x & 63;
-	const uint32_t wave = wg * kStripWaves + wave_in_wg;
-	const uint32_t sub = lane >> 3, row0 = (lane & 7u) / P::LPR, chunk = lane % P::LPR;
-	uint32_t blk = wave * P::BPW + sub;
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;          // spare lanes redo the last block: every lane runs the same loads, only real leaders store
-	uint8_t *const lds = strip_lds + wave_in_wg * ((H + P::SPAN) * P::PITCH);
-
-	const uint32_t ref_mis = (uint32_t)(reinterpret_cast<uintptr_t>(ref) & 3u);
-	const uint8_t *const ref_al = ref - ref_mis;
-	const uint32_t sr32 = (uint32_t)stride_ref, ss32 = (uint32_t)stride_src;
-
-	// ---- where the wave's 32 candidates lie ----
-	// Descriptors by SCALAR loads (the wave's 8 + 32 words are consecutive; see block_cost_sums): the lowest and the highest candidate start come out of
-	// scalar min / max chains, each lane picks its own block's words with v_cndmask.  Only a wave all of whose blocks exist; the batch's last, partial
-	// wave takes the generic code.
-	const uint32_t first = __builtin_amdgcn_readfirstlane(wave * P::BPW);
-	const bool full = first + P::BPW <= n_blocks;
-	uint32_t so = 0, o[4] = { 0, 0, 0, 0 }, base = 0, top_start = 0;
-	if (full)
-	{
-		uint32_t sv[P::BPW], rv[4][P::BPW];
-#pragma unroll
-		for (int j = 0; j < P::BPW; ++j) sv[j] = src_off[first + (uint32_t)j];
-#pragma unroll
-		for (int j = 0; j < P::BPW; ++j)
-#pragma unroll
-			for (int k = 0; k < 4; ++k) rv[k][j] = ref_off[(size_t)(first + (uint32_t)j) * 4 + k];
-		base = rv[0][0]; top_start = rv[0][0];
-#pragma unroll
-		for (int j = 0; j < P::BPW; ++j)
-#pragma unroll
-			for (int k = 0; k < 4; ++k) { base = min(base, rv[k][j]); top_start = max(top_start, rv[k][j]); }
-		base += ref_mis; top_start += ref_mis;        // (offsets from the word-aligned plane base)
-		so = pick_by_index<P::BPW>(sv, sub);
-#pragma unroll
-		for (int k = 0; k < 4; ++k) o[k] = pick_by_index<P::BPW>(rv[k], sub) + ref_mis;
-	}
-	bool close = inv_stride != 0u && full;
-	int dx[4];
-	uint32_t Y[4];
-#pragma unroll
-	for (int k = 0; k < 4; ++k)
-	{
-		const uint32_t d = o[k] - base;                                 // dy rows and dx columns above the lowest one, dx in [-32, stride - 32)
-		close = close && d <= (uint32_t)P::SPAN * sr32 + (uint32_t)P::PITCH;
-		const uint32_t nn = d + 32u;
-		uint32_t q = __umulhi(nn, inv_stride);                         // nn / stride, or one more
-		int r = (int)(nn - q * sr32);
-		if (r < 0) { q -= 1; r += (int)sr32; }
-		dx[k] = r - 32;
-		Y[k] = q;
-	}
-	const int xmin = (int)wave_min_u32_scalar((uint32_t)(min(min(dx[0], dx[1]), min(dx[2], dx[3])) + 64)) - 64;      // (biased: the reduction is unsigned)
-	const int xmax = (int)wave_max_u32_scalar((uint32_t)(max(max(dx[0], dx[1]), max(dx[2], dx[3])) + 64)) - 64;
-	const uint32_t ymax = wave_max_u32_scalar(max(max(Y[0], Y[1]), max(Y[2], Y[3])));
-	close = close && (xmax - xmin) <= P::MAX_DX && ymax <= (uint32_t)P::SPAN;
-	const bool windowed = __builtin_amdgcn_readfirstlane((int)(__ballot(!close) == 0ull)) != 0;
-
-	uint32_t total[4];
-	if (windowed)
-	{
-		// window origin: the lowest candidate word, moved left by whole pieces until it covers the leftmost candidate
-		const uint32_t a_min = base & ~3u;
-		const uint32_t wo = base + (uint32_t)xmin;                      // first byte any candidate needs in row 0's column range (modulo 2^32, like all of this)
-		const uint32_t left = (a_min - (wo & ~3u) + 15u) & ~15u;       // 0, 16 or 32
-		const uint32_t wbase = a_min - left;
-		// the highest word that holds a candidate byte: nothing at or above a_max + 4 may be read
-		const uint32_t a_max = (top_start + (uint32_t)(H - 1) * sr32 + (uint32_t)(W - 1)) & ~3u;
-		const uint32_t rows_n = (uint32_t)H + ymax, n_pieces = rows_n * (uint32_t)P::PR;
-
-		// source rows first (ordinary streaming loads into registers), then the window pieces (LDS-DMA)
-		Chunk<8> s[U];
-#pragma unroll
-		for (int u = 0; u < U; ++u) s[u].load_stream(src + (size_t)(so + (row0 + (uint32_t)(P::R * u)) * ss32 + chunk * 8u));
-
-		uint32_t prow = lane / (uint32_t)P::PR, pk = lane - prow * (uint32_t)P::PR;
-		constexpr uint32_t drow = 64u / P::PR, dk = 64u - drow * P::PR;
-		constexpr int MAX_TRIPS = ((H + P::SPAN) * P::PR + 63) / 64;
-		uint32_t edge = 0;      // this lane's piece of trip t holds the highest word: bit t
-#pragma unroll
-		for (int t = 0; t < MAX_TRIPS; ++t)
-		{
-			const uint32_t a = wbase + prow * sr32 + 16u * pk;          // offset from ref_al
-			const bool wanted = (uint32_t)(64 * t) + lane < n_pieces;
-			// inside [a_min, a_max + 4): compare as distances from a_min so that nothing wraps
-			const uint32_t rel = a - a_min;
-			const bool whole = wanted && rel <= a_max - a_min && rel + 12u <= a_max - a_min;
-			if (whole)
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)(ref_al + (size_t)a),
-						(__attribute__((address_space(3))) uint32_t *)(lds + 1024 * t), 16, 0, 0);
-			else if (wanted && rel <= a_max - a_min) edge |= 1u << t;
-			prow += drow; pk += dk;
-			if (pk >= (uint32_t)P::PR) { pk -= (uint32_t)P::PR; prow += 1; }
-		}
-		// the piece that holds a_max (at most one in the whole window): its 1 .. 3 words below a_max + 4, by ordinary loads and LDS stores
-		if (edge)
-		{
-			const uint32_t t = (uint32_t)__builtin_ctz(edge), p = 64u * t + lane;
-			const uint32_t er = p / (uint32_t)P::PR, ek = p - er * (uint32_t)P::PR;
-			const uint32_t a = wbase + er * sr32 + 16u * ek;
-			uint32_t *d = reinterpret_cast<uint32_t *>(lds + 16u * p);
-			for (uint32_t w = 0; a + 4u * w <= a_max && w < 4u; ++w) d[w] = *reinterpret_cast<const uint32_t *>(ref_al + (size_t)(a + 4u * w));
-		}
-		__syncthreads();          // the DMA pieces are LDS writes counted on vmcnt: the fence in front of the barrier waits for them
-
-		// candidate k of this lane's block: byte X[k] of window row Y[k]
-		const uint8_t *ck[4];
-		uint32_t sh[4];
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			const uint32_t X = (uint32_t)(dx[k] - xmin) + (wo - wbase) + chunk * 8u;       // window byte of this lane's first byte in candidate k's row 0
-			ck[k] = lds + (Y[k] + row0) * (uint32_t)P::PITCH + (X & ~3u);
-			sh[k] = X & 3u;
-		}
-		uint32_t acc[4] = { 0, 0, 0, 0 };
-#pragma unroll
-		for (int u = 0; u < U; ++u)
-		{
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-			{
-				const uint32_t *r = reinterpret_cast<const uint32_t *>(ck[k] + u * (P::R * P::PITCH));
-				const uint32_t w0 = r[0], w1 = r[1], w2 = r[2];
-				acc[k] = __builtin_amdgcn_sad_u8(s[u].d[0], __builtin_amdgcn_alignbyte(w1, w0, sh[k]), acc[k]);
-				acc[k] = __builtin_amdgcn_sad_u8(s[u].d[1], __builtin_amdgcn_alignbyte(w2, w1, sh[k]), acc[k]);
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < 4; ++k) total[k] = reduce_block<P::LPR, P::R>(acc[k]);
-	}
-	else
-	{
-		__syncthreads();          // (every wave of the workgroup passes one barrier, whichever path it takes)
-		block_cost_sums<W, 8, P::R, (U > 4 ? 4 : U), 4, OP_SAD, (U > 4), false>(src, stride_src, ref, stride_ref, src_off, ref_off, H, lane, blk, 0u, total);
-	}
-	if (live && (lane & 7u) == 0)
-	{
-		u32x4 v; v.x = total[0]; v.y = total[1]; v.z = total[2]; v.w = total[3];
-		reinterpret_cast<U4 *>(out + (size_t)blk * 4)->v = v;
-	}
-}
+// (Round 4: narrow 4-way blocks through ONE union window per wave of 8 blocks, staged by LDS-DMA -- sad4_strip_kernel -- was built in three forms,
+// bit-exact, and is 2 ... 35 % slower than the generic kernel at every size but 16x32 (-2 %): profiles/r04_sad4_strip_window_ab.txt.  A window wave's life
+// is serial -- descriptors, geometry, DMA, barrier, LDS reads -- where the generic wave's loads all go out at once.  Source: commit e9488f1.)
 
 struct Args
 {
@@ -986,37 +801,6 @@ template <int W> static int launch_window(const Args &a)
 	if (a.H == 16) WINDOW(16); else if (a.H == 32) WINDOW(32); else if (a.H == 48) WINDOW(48); else WINDOW(64);
 #undef WINDOW
 	return launch_status("sad4_window_kernel");
-}
-
-// sad4_strip_kernel applies to: four references, SAD, 8- or 16-wide, heights that are 1 / 2 / 4 (8-wide) or 2 / 3 / 4 / 8 (16-wide) rows per lane,
-// and the strides sad4_window_kernel needs (rows of a window word-aligned with each other and disjoint, exact row / column split)
-template <int W> static bool strip_ok(const Args &a)
-{
-	typedef StripPlan<W> P;
-	static const bool no_strip = getenv("HEVCASM_SAD4_NOSTRIP") != nullptr;     // measurement switch, read once per process
-	if (no_strip || a.H % P::R) return false;
-	const int u = a.H / P::R;
-	const bool height = W == 16 ? (u == 2 || u == 3 || u == 4 || u == 8) : (u == 1 || u == 2 || u == 4);
-	return height && a.sr >= P::PITCH + 64 && a.sr <= (1 << 20) && (a.sr & 3) == 0;
-}
-
-template <int W> static int launch_strip(const Args &a)
-{
-	typedef StripPlan<W> P;
-	const uint32_t inv = (uint32_t)((1ull << 32) / (uint64_t)a.sr) + 1u;
-	const uint32_t grid = ceil_div(a.n, (size_t)(P::BPW * kStripWaves));
-	const size_t lds = (size_t)kStripWaves * (size_t)(a.H + P::SPAN) * P::PITCH;
-#define STRIP_SAD(UU) hipLaunchKernelGGL((sad4_strip_kernel<W, UU>), dim3(grid), dim3(kStripWaves * kWave), lds, a.st, a.src, a.ss, a.ref, a.sr, a.so, a.ro, a.out, (uint32_t)a.n, inv)
-	switch (a.H / P::R)
-	{
-	case 1: if constexpr (W == 8) { STRIP_SAD(1); } break;
-	case 2: STRIP_SAD(2); break;
-	case 3: if constexpr (W == 16) { STRIP_SAD(3); } break;
-	case 4: STRIP_SAD(4); break;
-	case 8: if constexpr (W == 16) { STRIP_SAD(8); } break;
-	}
-#undef STRIP_SAD
-	return launch_status("sad4_strip_kernel");
 }
 
 template <int W, int C, int R, int U, int WAYS, int OP, bool TIGHT> static int launch_cfg(const Args &a)
@@ -1066,11 +850,6 @@ template <int W, int C, int R, int WAYS, int OP, bool TIGHT> static int launch_r
 template <int W, int WAYS, int OP> static int launch_w(const Args &a)
 {
 	typedef Plan<W> P;
-	// four references, 8- and 16-wide: one union window per wave of 8 blocks, by LDS-DMA (round 4; decides per wave, generic code for far-apart candidates)
-	if constexpr (WAYS == 4 && OP == OP_SAD && (W == 8 || W == 16))
-	{
-		if (strip_ok<W>(a)) return launch_strip<W>(a);
-	}
 	if constexpr (W == 8)
 	{
 		if (a.sr < 8 && a.sr > -8) return launch_rows<W, P::C, P::R_SAFE, WAYS, OP, true>(a);

@@ -342,25 +342,9 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	uint32_t blk2 = wg * BPWG + local2;
 	const bool live2 = blk2 < n_blocks;
 	if (!live2) blk2 = n_blocks - 1;
-	// (round 4) the workgroup's BPWG offsets are consecutive words: a full workgroup fetches them with scalar loads -- a path of their own, not queued
-	// behind the vector loads in flight on the CU -- and each lane picks its block's with v_cndmask; the prediction load below no longer waits for a
-	// vector round trip of its own.  The batch's last, partial workgroup keeps the per-lane loads.
-	uint32_t po, dof;
-#ifndef HEVCASM_TRANSFORM_VECTOR_DESC
-	if ((wg + 1u) * (uint32_t)BPWG <= n_blocks)
-	{
-		uint32_t pv[BPWG], dv[BPWG];
-#pragma unroll
-		for (int j = 0; j < BPWG; ++j) { pv[j] = pred_off[wg * BPWG + (uint32_t)j]; dv[j] = dst_off[wg * BPWG + (uint32_t)j]; }
-		po = pick_by_index<BPWG>(pv, local2);
-		dof = pick_by_index<BPWG>(dv, local2);
-	}
-	else
-#endif
-	{
-		po = pred_off[blk2];
-		dof = dst_off[blk2];
-	}
+	// (round 4: the workgroup's offsets by scalar loads + v_cndmask, as the SAD kernels fetch their descriptors, measured -5 ... +6 % by kernel and
+	// size, nothing on balance: profiles/r04_scalar_offsets_elsewhere_ab.txt -- these kernels run at the rate of their access mix)
+	const uint32_t po = pred_off[blk2], dof = dst_off[blk2];
 	const uint8_t *pp = pred + po + t2 * stride_pred;
 	uint8_t *d = dst + dof + t2 * stride_dst;
 	constexpr int CB = N >= 16 ? 16 : N;
@@ -623,19 +607,7 @@ __global__ __launch_bounds__(kThreads) void forward_transform_kernel(
 		uint32_t blk1 = wg * BPWG + local1;
 		if (blk1 >= n_blocks) blk1 = n_blocks - 1;
 		int16_t *tile1 = tiles + local1 * Tile<N>::HALFWORDS;
-		// the offset of the lane's block: the workgroup's BPWG offsets by scalar loads where they are at most 16 (see inverse_transform_add_kernel)
-		uint32_t off1;
-#ifndef HEVCASM_TRANSFORM_VECTOR_DESC
-		if (BPWG <= 16 && (wg + 1u) * (uint32_t)BPWG <= n_blocks)
-		{
-			uint32_t sv[BPWG];
-#pragma unroll
-			for (int j = 0; j < BPWG; ++j) sv[j] = src_off[wg * BPWG + (uint32_t)j];
-			off1 = pick_by_index<BPWG>(sv, local1);
-		}
-		else
-#endif
-			off1 = src_off[blk1];
+		const uint32_t off1 = src_off[blk1];
 		global_row_load<N>(src + off1 + (ptrdiff_t)t1 * src_stride, v);
 		forward_1d<N, DST>(v, w);
 #pragma unroll

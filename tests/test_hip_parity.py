@@ -837,3 +837,49 @@ def test_prediction_and_reconstruction_at_the_top_of_the_4gib_window():
             assert np.array_equal(got[d // stride:d // stride + s, d % stride:d % stride + s], w2[d // stride:d // stride + s, d % stride:d % stride + s]), (lg, d)
     del ref, dst
     torch.cuda.empty_cache()
+
+
+def test_descriptor_arrays_at_odd_word_alignment():
+    """Round 4 fetches a full wave's (workgroup's) descriptors with SCALAR loads of 8 / 16 / 32 consecutive words (sad.hip: block_cost_sums;
+    transform.hip).  The API promises nothing beyond uint32 alignment for src_off / ref_off / pred_off / dst_off: arrays that start 1, 2 and 3
+    words into an allocation (views into a larger buffer) must give the same answers -- SAD one reference and four, SSD, inverse 16x16 / 32x32
+    (+ fused), forward 16x16 -- with batch sizes that leave a partial last wave (the per-lane path) behind the full ones."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+
+    def shifted(a, words):
+        t = torch.zeros(a.size + 8, dtype=torch.int32, device="cuda")
+        t[words:words + a.size] = torch.from_numpy(a.astype(np.int64).astype(np.uint32).view(np.int32)).cuda()
+        return t[words:words + a.size]
+
+    for words in (1, 2, 3):
+        for (w, h, ways, n) in ((16, 16, 1, 1000 + words), (16, 16, 4, 777), (8, 8, 1, 515), (32, 32, 4, 130), (24, 32, 4, 99), (64, 64, 1, 41)):
+            c = wl.sad_case(w, h, n, 5100 + w + words, ways=ways)
+            src, ref = B.u8(c["src"]), B.u8(c["ref"])
+            so, ro = shifted(c["src_off"], words), shifted(c["ref_off"], (words + 1) % 4)
+            if ways == 1:
+                got = B.sad(src, c["stride_src"], ref, c["stride_ref"], so, ro, w, h).cpu().numpy()
+                want = pyoracle.sad_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], w, h)
+                ssd = B.ssd(src, c["stride_src"], ref, c["stride_ref"], so, ro, w, h).cpu().numpy()
+                assert np.array_equal(ssd, pyoracle.ssd_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], w, h)), (words, w, h, "ssd")
+            else:
+                got = B.sad_multiref(src, c["stride_src"], ref, c["stride_ref"], so, ro, w, h).cpu().numpy()
+                want = pyoracle.sad_multiref_batch(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], c["ref_off"], w, h)
+            assert np.array_equal(got, want), (words, w, h, ways)
+        for lg in (4, 5):
+            n = 100 + 7 * words
+            c = wl.inverse_case(0, lg, n, 5200 + lg + words, "full")
+            pred, coeffs = B.u8(c["pred"]), B.i16(c["coeffs"])
+            dof, pof = shifted(c["dst_off"], words), shifted(c["pred_off"], 4 - words)
+            dst = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+            B.inverse_transform_add(dst, c["stride_dst"], pred, c["stride_pred"], dof, pof, coeffs, 0, lg)
+            want = pyoracle.inverse_transform_add_batch(0, lg, c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"], c["pred_off"], c["coeffs"])
+            assert np.array_equal(dst.cpu().numpy(), want), (words, lg, "inverse")
+            dst.zero_()
+            B.dequant_inverse_transform_add(dst, c["stride_dst"], pred, c["stride_pred"], dof, pof, coeffs, 51, 14, 0, lg)
+            want = pyoracle.dequant_inverse_transform_add_batch(0, lg, c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"], c["pred_off"], c["coeffs"], 51, 14)
+            assert np.array_equal(dst.cpu().numpy(), want), (words, lg, "fused")
+        f = wl.forward_case(0, 4, 90 + words, 5300 + words)
+        got = B.transform(B.i16(f["src"]), f["src_stride"], shifted(f["src_off"], words), 0, 4).cpu().numpy()
+        assert np.array_equal(got, pyoracle.transform_batch(0, 4, f["src"], f["src_stride"], f["src_off"])), (words, "forward")
