@@ -863,7 +863,7 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 	static const bool no_segments = getenv("HEVCASM_PRED_NOSEGMENTS") != nullptr;     // A/B switch, read once per process
 	size_t waves = ceil_div(n, (size_t)ppw) * (size_t)p2.count;
 	int log2_segments = 0;
-	while (!no_segments && log2_segments < 2 && waves < 16384 && (H >> (log2_segments + 1)) >= 8 && (H >> (log2_segments + 1)) % 8 == 0)
+	while (!no_segments && log2_segments < 2 && waves < 16384 && H % (2 << log2_segments) == 0 && (H >> (log2_segments + 1)) >= 8 && (H >> (log2_segments + 1)) % 8 == 0)
 	{
 		++log2_segments;
 		waves *= 2;

@@ -45,6 +45,31 @@ def test_prediction_random_sizes_and_fractions():
         cases.assert_same("fuzz %s taps=%d %dx%d n=%d" % (fam, taps, w, h, n), cases.run_hip(fam, c), cases.run_oracle(fam, c))
 
 
+def test_prediction_extreme_content():
+    """Planes of 0 / 255 only -- independent per pixel, or periodic in both directions with random 8-pixel masks -- drive the filters to the ends of
+    their range: both clip rails of uni-prediction, and the 14-bit intermediates of bi-prediction past int16, which the reference wraps
+    (pred_inter.c:125: an int stored to an int16_t; the periodic planes reach it, see cases._wrap14).  Random sizes, every fraction pair, both tap counts."""
+    rng = np.random.default_rng(20261009 + SEED)
+    for i in range(40):
+        taps = int(rng.choice([8, 4]))
+        lim = 64 if taps == 8 else 32
+        w, h = int(rng.integers(1, lim + 1)), int(rng.integers(1, lim + 1))
+        n = int(rng.integers(1, 24)) * NMUL
+        bi = bool(rng.integers(0, 4))                      # mostly bi: that is where the wrap lives
+        c = wl.pred_case(taps, w, h, n, 6500 + i, bi=bi, frame=(w * int(rng.integers(1, 4)), h * int(rng.integers(1, 4))))
+        stride = c["stride_ref"]
+        for r in range(2 if bi else 1):
+            plane = c["ref%d" % r]
+            if rng.integers(0, 3) == 0:
+                plane[:] = np.where(rng.integers(0, 2, size=plane.size) == 1, 255, 0).astype(np.uint8)
+            else:
+                mx, my = rng.integers(0, 2, size=8), rng.integers(0, 2, size=8)
+                idx = np.arange(plane.size)
+                plane[:] = np.where(mx[(idx % stride) % 8] == my[(idx // stride) % 8], 255, 0).astype(np.uint8)
+        fam = "pred_bi" if bi else "pred_uni"
+        cases.assert_same("fuzz extreme %s taps=%d %dx%d n=%d" % (fam, taps, w, h, n), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+
+
 def test_transforms_and_quantisers_random_parameters():
     rng = np.random.default_rng(20261006 + SEED)
     for i in range(60):

@@ -883,3 +883,18 @@ def test_descriptor_arrays_at_odd_word_alignment():
         f = wl.forward_case(0, 4, 90 + words, 5300 + words)
         got = B.transform(B.i16(f["src"]), f["src_stride"], shifted(f["src_off"], words), 0, 4).cpu().numpy()
         assert np.array_equal(got, pyoracle.transform_batch(0, 4, f["src"], f["src_stride"], f["src_off"])), (words, "forward")
+
+
+def test_pred_strip_segments_keep_every_row():
+    """Round 4 cuts small launches of tall 4-tap PUs into row segments (pred_strip4_kernel).  A height that the segment count does not divide must not
+    lose its last rows: found by the extreme-content fuzz group at 16x17 (the first form of the launcher's test accepted H = 17 as 2 x 8 rows).
+    Every height 8 .. 33 at the strip kernel's widths, uni and bi, few PUs (= a small launch: segments wherever the launcher allows them)."""
+    from hevcasm_amd import workload as wl
+    for w in (4, 8, 16):
+        for h in list(range(8, 34)):
+            if h > 32:
+                continue
+            for bi in (False, True):
+                c = wl.pred_case(4, w, h, 9, 8800 + 40 * w + h, bi=bi, frame=(2 * w, 2 * h))
+                fam = "pred_bi" if bi else "pred_uni"
+                cases.assert_same("strip segments %s %dx%d" % (fam, w, h), cases.run_hip(fam, c), cases.run_oracle(fam, c))
