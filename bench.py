@@ -235,6 +235,14 @@ for _n in (8, 16, 32):
         FAMILY_KEYS[("fdct" + _fam, "transform dct%d" % _n)] = "fdct%d%s" % (_n, _sfx)
 
 
+# Integer VALU roof of the part: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz (tools/ubench/valu_rates.hip measures one full-rate wave-instruction
+# per ~4 cycles per SIMD: profiles/r01_valu_issue_rates.txt), and the vector lane-operations the luma prediction kernels issue per output pixel of a
+# 16x16 PU (SQ_INSTS_VALU x 64 / pixels, rocprofv3 --pmc: profiles/r04_pred_transform_counters.txt).  Prediction is bound by this roof, not by HBM
+# (DESIGN.md 4.2): <key>_valu_frac says how much of it a row uses, next to the HBM fraction the metric asks for.
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
+PRED_LANE_OPS_PER_PIXEL = {"pred_uni_luma16": 20.1, "pred_bi_luma16": 43.7, "pred_uni_luma16_256f": 20.1, "pred_bi_luma16_256f": 43.7}
+
+
 def flatten_families(rows):
     """roofline.per_family rows -> flat scalar keys: <prefix>_frac (of the 8 TB/s HBM peak), _gbs (algorithmic), _ms (per launch), _mblocks (per s)."""
     out = {}
@@ -250,6 +258,8 @@ def flatten_families(rows):
         out[key + "_gbs"] = r["gbs"]
         out[key + "_ms"] = r["ms"]
         out[key + "_mblocks"] = r["mblocks_per_s"]
+        if key in PRED_LANE_OPS_PER_PIXEL:
+            out[key + "_valu_frac"] = round(r["mblocks_per_s"] * 1e6 * 256 * PRED_LANE_OPS_PER_PIXEL[key] / VALU_PEAK_LANE_OPS, 4)
     return out
 
 

@@ -83,6 +83,8 @@ def test_the_record_keeps_every_family_as_scalars():
     for k in want:
         for sfx in ("_frac", "_gbs", "_ms", "_mblocks"):
             assert isinstance(kept[k + sfx], float), k + sfx
+    for k in ("pred_uni_luma16_valu_frac", "pred_bi_luma16_valu_frac"):
+        assert 0.0 < kept[k] < 1.5, k
     for k in ("me_frame_ms", "me_valu_frac", "me_valu_frac_nominal", "me_gsad_per_s", "me_frames_per_s", "me_hbm_frac"):
         assert isinstance(kept[k], float), k
     for v in kept.values():
