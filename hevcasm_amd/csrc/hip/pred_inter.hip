@@ -357,43 +357,14 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	// uniform base + 32-bit lane offset: one VGPR and one add per row and plane instead of a 64-bit pointer.
 	const uint32_t step_ref = (uint32_t)stride_ref, step_dst = (uint32_t)stride_dst;
 	Stream rs[NREF];
-	// Descriptors (round 4, as sad.hip: block_cost_sums).  A wave's PUs are consecutive in the arrays; where a wave holds at most 32 of them (8-byte
-	// lanes) and 36 more descriptors exist behind its first one, the reference offsets and fraction bytes of the wave come by SCALAR loads -- not queued
-	// behind the resident waves' row loads in the CU's in-order vector-memory pipeline -- and each lane picks its PU's with v_cndmask.  Everything else
-	// (the batch's last waves, 4-byte lanes with up to 64 PUs per wave) keeps the per-lane loads.  dst_off is needed only at the first store: per-lane load.
-#ifndef HEVCASM_PRED_VECTOR_DESC
-	const uint32_t pu0 = (wave >> log2_segments) * (uint32_t)PPW;
-	const bool scalar_desc = NDW == 2 && PPW <= 32 && (unsigned long long)pu0 + 36ull <= (unsigned long long)n_blocks;
-#else
-	const uint32_t pu0 = 0;
-	const bool scalar_desc = false;
-#endif
+	// (Round 4: the wave's reference offsets and fraction bytes by scalar loads + v_cndmask, as the SAD kernels fetch their descriptors: bit-exact and
+	// 6-9 % slower on every luma size -- these kernels are VALU-bound and the selects cost more than the trip they shorten:
+	// profiles/r04_pred_scalar_descriptors_ab.txt.  Per-lane loads stay.)
 #pragma unroll
 	for (int r = 0; r < NREF; ++r)
 	{
-		int frac;
-		uint32_t ref_off_pu;
-		if (NDW == 2 && scalar_desc)
-		{
-			const uint32_t *offs = r ? ref1_off : ref0_off;
-			uint32_t rv[32];
-#pragma unroll
-			for (int q = 0; q < 32; ++q) rv[q] = offs[pu0 + (uint32_t)q];
-			ref_off_pu = pick_by_index<32>(rv, (uint32_t)sub);
-			// the wave's fraction bytes: the 9 aligned words that hold bytes pu0 .. pu0 + 31 of the array
-			const uintptr_t fa = reinterpret_cast<uintptr_t>((r ? frac1 : frac0) + pu0);
-			const uint32_t *fw = reinterpret_cast<const uint32_t *>(fa & ~(uintptr_t)3);
-			uint32_t fv[16];
-#pragma unroll
-			for (int q = 0; q < 16; ++q) fv[q] = q < 9 ? fw[q] : 0u;
-			const uint32_t fi = (uint32_t)(fa & 3u) + (uint32_t)sub;
-			frac = (int)((pick_by_index<16>(fv, fi >> 2) >> (8u * (fi & 3u))) & 0xffu);
-		}
-		else
-		{
-			frac = (r ? frac1 : frac0)[pu];
-			ref_off_pu = (r ? ref1_off : ref0_off)[pu];
-		}
+		const int frac = (r ? frac1 : frac0)[pu];
+		const uint32_t ref_off_pu = (r ? ref1_off : ref0_off)[pu];
 		const bool fx = (frac & 15) != 0, fy = (frac >> 4) != 0;
 		// the columns / rows the reference reads for this fraction: the filter margins only where it filters
 		const int window = fx ? W + TAPS - 1 : W;
