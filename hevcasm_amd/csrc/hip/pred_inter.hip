@@ -302,6 +302,8 @@ static ptrdiff_t plane_distance(const void *b, const void *a) { return (ptrdiff_
 
 
 // FAST: W % 4 == 0 and (rows per wave) % TAPS == 0 -- the row loop then has no branch around any load or store (see the loop).
+// (Round 4: holding the uni 16-rows-in-flight variant to 96 registers for a fifth wave per SIMD (5 dwords of scratch) costs 4-9 %, and a third wave for
+// the bi strip kernel (168 registers, 10 dwords of scratch) changes nothing: profiles/r04_pred_occupancy_ab.txt.  The compiler's own allocation stays.)
 template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW, bool FAST>
 __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int TAPS = 4, UNROLL = AHEAD > TAPS ? AHEAD : TAPS;
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	uint32_t wave = wg * (kThreads / kWave) + (threadIdx.x >> 6);
+	uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));      // (wave-uniform: the address arithmetic that follows stays in SGPRs)
 	// row segments (round 4): a small launch of tall PUs is few, long waves -- 64 frames of 8x32 chroma PUs are 1920 waves of 32 rows, not two
 	// per SIMD -- so such launches cut every PU into 2 or 4 segments of rows, one wave each (neighbouring waves: the 3 window rows two segments
 	// share come from the L2), exactly as pred_stream_kernel does; the segment is the PU as far as the rest of the kernel is concerned
