@@ -42,11 +42,13 @@ __attribute__((constructor)) static void build_tables(void)
 			direct_fdct16[i * 8 + q] = pair_coef(hevcasm_c_transform_coefficient(16, i, 2 * q), hevcasm_c_transform_coefficient(16, i, 2 * q + 1));   /* forward: M(k, i) = m[i][k] */
 }
 
-/* the plain-product table of a configuration (the only two that take that path) */
+/* the plain-product table of a configuration: only the inverse 4x4 DST and the forward 16x16 DCT take that path (a third would need its own table:
+ * trap rather than multiply by the wrong matrix) */
 static inline __attribute__((always_inline)) const int32_t *direct_coef(int N, int DST, int INVERSE)
 {
-	(void)N;
-	return (INVERSE && DST) ? direct_idst4 : direct_fdct16;
+	if (INVERSE && DST && N == 4) return direct_idst4;
+	if (!INVERSE && !DST && N == 16) return direct_fdct16;
+	__builtin_trap();
 }
 
 /* ---- 128-bit vectors: a group of 8 columns is two vectors of four 32-bit sums ---------------------------------------- */
