@@ -889,204 +889,12 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 	return launch_status("pred_strip4_kernel");
 }
 
-// ---- 8-tap uni-prediction, HORIZONTAL pass first, one lane per 8-column strip (round 4) ---------------------------------------------
-//
-// pred_stream_kernel filters vertically first and exchanges its results between lanes; a 16-wide PU takes three lanes of which two produce pixels,
-// and the VALU -- 62-70 % busy, the roof that bounds these kernels (profiles/r04_pred_valu_by_size.txt) -- spends 20 lane-operations per output
-// pixel at 16x16.  This kernel runs the reference's own order: a lane owns a STRIP of 8 output columns, loads the strip's 15-byte window row itself (two 8-byte
-// loads), filters it horizontally IN THE BYTE DOMAIN -- v_dot4_i32_i8 on (pixel - 128) against the taps as signed bytes, 16 dot products + 9 v_alignbyte
-// per row of 8 sums, exact: sum c (p - 128) + 128 * 64 -- keeps the sums as int16 ROW PAIRS (row 2m, row 2m + 1 in one register, four pairs per
-// column) and filters vertically with v_dot2_i32_i16: an even output row is four dot products of the pairs it starts on; an odd one takes (0, c0) of the
-// pair it ends, (c1, c2) (c3, c4) (c5, c6) of the next three and (c7, 0) of the pair that has just arrived: 4.5 per pixel.  No cross-lane traffic, every lane
-// stores pixels: about 12 lane-operations per pixel at 16x16.  W % 8 == 0 and H % 8 == 0; everything else stays with pred_stream_kernel.
-// Arithmetic = the reference's (pred_inter.c:154-179): first pass at full precision (|sum| <= 88 * 255 < 2^15), second pass (sum + 2048) >> 12, clipped; a zero
-// fraction is the tap {64} at position 0 (exact factor 64, as in pred_stream_kernel).
-// Footprint = the reference's, exactly: the strip's low 8 bytes [8 j - bx, 8 j - bx + 8) always lie inside the window (bx = 3 columns of margin only where
-// xFrac != 0); the high 8 bytes would pass the window's end in the PU's last strip -- by one byte where it filters, by eight where it does not -- and are
-// loaded from the last 8 bytes of the window instead (shifted back by that byte; for xFrac == 0 they only ever meet zero taps).  The row stream stays on the
-// last row the reference reads (v_med3_u32 on the offset): rows past it meet zero taps (yFrac == 0) or are the one row the pairing reads ahead.
-__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
-// the first product of a sum, with a wave-uniform constant as the addend: the VOP3P forms take it from an SGPR, where the compiler's v_dot4c / v_dot2c
-// (accumulate in place) cost a v_mov of the constant per sum -- 32 of about 190 vector instructions per pair of rows
-__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
-{
-	int r;
-	asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
-	return r;
-}
-__device__ __forceinline__ int dot2_first_k(uint32_t a, uint32_t b, int k)
-{
-	int r;
-	asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
-	return r;
-}
-
-template <int AHEAD>
-__global__ __launch_bounds__(kThreads) void pred_hfirst_uni8_kernel(
-	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
-	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref_off, const uint8_t *__restrict__ frac,
-	int W, int H, int S /* strips per PU = W / 8 */, int PPW /* PUs per wave */, uint32_t n_blocks, ptrdiff_t plane2_dst, ptrdiff_t plane2_ref)
-{
-	static_assert(AHEAD == 8, "the ring turns once per unrolled group of 8 rows");
-	if (blockIdx.y)
-	{
-		dst += plane2_dst;
-		ref += plane2_ref;
-	}
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
-	const int lane = threadIdx.x & 63;
-	int sub = lane / S;
-	int j = lane - sub * S;
-	const bool spare = sub >= PPW;
-	if (spare) { sub = PPW - 1; j = 0; }
-	uint32_t pu = wave * (uint32_t)PPW + (uint32_t)sub;
-	const bool in_batch = pu < n_blocks;
-	if (!in_batch) pu = n_blocks - 1;
-	const bool stores = in_batch && !spare;
-
-	const int fr = frac[pu];
-	const int xf = fr & 15, yf = fr >> 4;
-	const int bx = xf ? 3 : 0, ax = xf ? 4 : 0, by = yf ? 3 : 0, ay = yf ? 4 : 0;
-	const uint32_t step_ref = (uint32_t)stride_ref, step_dst = (uint32_t)stride_dst;
-
-	// taps.  Horizontal: signed bytes, taps 0..3 and 4..7 of phase xf.  Vertical: int16 pairs for the two row parities.
-	uint32_t cA = 0, cB = 0;
-	int v[8];
-#pragma unroll
-	for (int k = 0; k < 8; ++k)
-	{
-		const uint32_t tb = (kTaps.luma[k] >> (8 * (xf & 3))) & 0xffu;
-		if (k < 4) cA |= tb << (8 * k); else cB |= tb << (8 * (k - 4));
-		v[k] = __builtin_amdgcn_sbfe((int)kTaps.luma[k], (uint32_t)(8 * (yf & 3)), 8u);
-	}
-	auto pair16 = [](int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); };
-	const uint32_t E0 = pair16(v[0], v[1]), E1 = pair16(v[2], v[3]), E2 = pair16(v[4], v[5]), E3 = pair16(v[6], v[7]);
-	const uint32_t O0 = pair16(0, v[0]), O1 = pair16(v[1], v[2]), O2 = pair16(v[3], v[4]), O3 = pair16(v[5], v[6]), O4 = pair16(v[7], 0);
-
-	// the strip's 16 window bytes as ONE load, moved left where it would pass the window's end (the PU's last strip: by one byte where xFrac filters,
-	// by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide)
-	const int col_nat = 8 * j - bx;
-	const int col0 = min(col_nat, W + ax - 16);
-	const uint32_t sh_bytes = (uint32_t)(col_nat - col0);                       // 0, 1 or 8
-	const bool sh8 = sh_bytes >= 8u;
-	const uint32_t hsh = sh_bytes & 3u;
-	const int last_row = H + ay + by - 1;                                       // last stream row the reference reads (stream row 0 = PU row -by)
-	const uint32_t first_lo = ref_off[pu] + (uint32_t)(-by) * step_ref + (uint32_t)col0;
-	const uint32_t end_lo = first_lo + (uint32_t)last_row * step_ref;
-	const uint32_t lo_b = min(first_lo, end_lo), hi_b = max(first_lo, end_lo);
-	uint32_t off = first_lo;
-	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * j);
-
-	auto issue = [&](uint32_t (&d)[4])
-	{
-		const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
-		d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-		off = med3_u32(off + step_ref, lo_b, hi_b);
-	};
-	// 8 horizontal sums of one window row
-	auto hrow = [&](const uint32_t (&d)[4], int (&h)[8])
-	{
-		// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
-		const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
-		const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
-		const uint32_t x0 = __builtin_amdgcn_alignbyte(e1, e0, hsh), x1 = __builtin_amdgcn_alignbyte(e2, e1, hsh);
-		const uint32_t x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh), x3 = __builtin_amdgcn_alignbyte(0x80808080u, e3, hsh);
-		uint32_t g[12];
-		g[0] = x0; g[4] = x1; g[8] = x2;
-#pragma unroll
-		for (int q = 1; q < 4; ++q)
-		{
-			g[q] = __builtin_amdgcn_alignbyte(x1, x0, q);
-			g[4 + q] = __builtin_amdgcn_alignbyte(x2, x1, q);
-			g[8 + q] = __builtin_amdgcn_alignbyte(x3, x2, q);
-		}
-#pragma unroll
-		for (int x = 0; x < 8; ++x) h[x] = sdot4(g[x + 4], cB, sdot4_first(g[x], cA, 8192));     // sum c (p - 128) + 128 * 64
-	};
-
-	uint32_t P[4][8];             // P[m][c]: sums of (row 2 (i + m'), row 2 (i + m') + 1), column c
-	uint32_t ring[AHEAD][4];      // window rows 8 + ... in flight
-	{
-		uint32_t first8[8][4];
-#pragma unroll
-		for (int r = 0; r < 8; ++r) issue(first8[r]);
-#pragma unroll
-		for (int a = 0; a < AHEAD; ++a) issue(ring[a]);
-#pragma unroll
-		for (int m = 0; m < 4; ++m)
-		{
-			int h0[8], h1[8];
-			hrow(first8[2 * m], h0);
-			hrow(first8[2 * m + 1], h1);
-#pragma unroll
-			for (int c = 0; c < 8; ++c) P[m][c] = __builtin_amdgcn_perm((uint32_t)h1[c], (uint32_t)h0[c], 0x05040100);
-		}
-	}
-
-	auto store_row = [&](const int (&t)[8])
-	{
-		u32x2 px;
-		const uint32_t a0 = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], 12), a1 = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], 12);
-		const uint32_t b0 = __builtin_amdgcn_ashr_pk_u8_i32(t[4], t[5], 12), b1 = __builtin_amdgcn_ashr_pk_u8_i32(t[6], t[7], 12);
-		px.x = __builtin_amdgcn_perm(a1, a0, 0x05040100);
-		px.y = __builtin_amdgcn_perm(b1, b0, 0x05040100);
-		if (stores) __builtin_nontemporal_store(px, reinterpret_cast<u32x2_u *>(dst + (size_t)out_off));
-		out_off += step_dst;
-	};
-	// output rows 2 i and 2 i + 1; the pair whose rows they start on is slot i % 4, the pair that arrives (rows 2 i + 8, 2 i + 9) replaces it
-	auto two_rows = [&](auto loads_tag, const int ii)
-	{
-		constexpr bool LOADS = decltype(loads_tag)::value;
-		const int s0 = ii % 4, s1 = (ii + 1) % 4, s2 = (ii + 2) % 4, s3 = (ii + 3) % 4;
-		int odd[8], even[8];
-#pragma unroll
-		for (int c = 0; c < 8; ++c)
-		{
-			odd[c] = dot2_first_k(P[s0][c], O0, 2048);
-			even[c] = dot2(P[s3][c], E3, dot2(P[s2][c], E2, dot2(P[s1][c], E1, dot2_first_k(P[s0][c], E0, 2048))));
-		}
-		store_row(even);
-		int h0[8], h1[8];
-		hrow(ring[(2 * ii) % AHEAD], h0);
-		hrow(ring[(2 * ii + 1) % AHEAD], h1);
-		if (LOADS)
-		{
-			issue(ring[(2 * ii) % AHEAD]);
-			issue(ring[(2 * ii + 1) % AHEAD]);
-		}
-#pragma unroll
-		for (int c = 0; c < 8; ++c)
-		{
-			P[s0][c] = __builtin_amdgcn_perm((uint32_t)h1[c], (uint32_t)h0[c], 0x05040100);
-			odd[c] = dot2(P[s0][c], O4, dot2(P[s3][c], O3, dot2(P[s2][c], O2, dot2(P[s1][c], O1, odd[c]))));
-		}
-		store_row(odd);
-	};
-	const int groups = H / 8;
-	for (int g = 0; g < groups - 1; ++g)
-	{
-#pragma unroll
-		for (int ii = 0; ii < 4; ++ii) two_rows(Flag<true>(), ii);
-	}
-#pragma unroll
-	for (int ii = 0; ii < 4; ++ii) two_rows(Flag<false>(), ii);
-}
-
-static bool hfirst_applies(int W, int H)
-{
-	static const bool off = getenv("HEVCASM_PRED_NOHFIRST") != nullptr;      // measurement switch, read once per process
-	return !off && W % 8 == 0 && W >= 16 && H % 8 == 0;
-}
-
-static int launch_pred_hfirst_uni8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref, ptrdiff_t sr, const uint32_t *dof, const uint32_t *rof, const uint8_t *fr,
-		int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
-{
-	const int strips = W / 8, ppw = kWave / strips;
-	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
-	hipLaunchKernelGGL((pred_hfirst_uni8_kernel<8>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref, sr, dof, rof, fr, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0);
-	return launch_status("pred_hfirst_uni8_kernel");
-}
+// ---- measured and not adopted (round 4): 8-tap uni-prediction with the HORIZONTAL pass first ----------------------------------------
+// One lane per 8-column strip, the first pass in the byte domain (v_dot4_i32_i8 on pixel - 128), the 14-bit sums kept as int16 row pairs, the vertical
+// pass on v_dot2_i32_i16 over the pairs; no cross-lane traffic, no idle lane.  Bit-exact (every GPU prediction test, footprints included), 22 % fewer vector
+// instructions at 64x64 (11.2 lane-operations per pixel against 14.4) -- and 4 % SLOWER (geometric mean over the PU sizes it serves; 14 % with two 8-byte
+// loads per lane instead of one of 16): the same vector-L1 accesses (an unaligned lane load is charged by the bytes asked for), a third more HBM traffic, more
+// time waiting.  The stream kernel is not bound by its instruction count.  profiles/r04_pred_hfirst_ab.txt; source: commit cf83a19.
 
 template <int TAPS, bool BI>
 static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
@@ -1104,7 +912,6 @@ static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const ui
 	// 24- / 32-wide +-0 ... +20 % (the stream kernel's lanes share the vertical pass there).
 	const bool strip_pays = (W <= 8 && !(BI && W == 4)) || W == 16;
 	if (TAPS == 4 && strip_pays && H >= 2 && (sr >= 16 || sr <= -16) && !no_strip) return launch_pred_strip4<BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
-	if constexpr (TAPS == 8 && !BI) { if (hfirst_applies(W, H)) return launch_pred_hfirst_uni8(dst, sd, ref0, sr, dof, r0, f0, W, H, n, st, p2); }
 	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 }
