@@ -369,6 +369,9 @@ if __name__ == "__main__":
         if w == "pred8tap":                               # luma only, every PU size
             bench_pred(taps_only=8)
             continue
+        if w.startswith("pred8sub") and w[8:].isdigit():  # luma, square PU sizes, N frames per launch
+            bench_pred(frames=int(w[8:]), taps_only=8, only=((16, 16), (32, 32), (64, 64), (64, 32), (16, 64)))
+            continue
         if w.startswith("pred4sub") and w[8:].isdigit():  # chroma, a subset of PU sizes, N frames per launch (ramp / tail against steady state)
             bench_pred(frames=int(w[8:]), taps_only=4, only=((16, 16), (32, 32), (32, 64), (16, 64), (64, 64), (8, 16), (4, 16)))
             continue
