@@ -1,0 +1,139 @@
+// The memory side of the luma uni-prediction kernel with the arithmetic taken out: what rate does THIS access mix reach on gfx950?
+//   per W x H PU: H + 7 window rows of W + 7 bytes read (8-byte lane loads at byte alignment, ceil((W + 7) / 8) lanes per PU, 64 / that many PUs per
+//   wave, D rows in flight per lane), H destination rows of W bytes written (8 bytes per producing lane), rows a frame stride apart, PUs tiling
+//   1920 x 1080 frames in raster order, the window displaced by an integer motion vector in [-8, 8]^2 (tools/bench_families.py's layout: destination
+//   stride 1920, reference frames with a 16-pixel border).  Workgroups in XCD-contiguous order, as the library's kernels take them.
+// Two kernels with very different instruction counts (pred_stream_kernel and the H-first experiment, profiles/r04_pred_hfirst_ab.txt) take the same time;
+// this probe says how much of that time is the access mix itself.  Modes: 0 = loads and stores, 1 = loads only (one store per lane at the end),
+// 2 = stores only (one load per lane at the start).   hipcc --offload-arch=gfx950 -O3 pred_mix.hip -o pred_mix
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int LB> struct Vec;
+template <> struct Vec<8> { typedef u32x2 T; };
+template <> struct Vec<16> { typedef u32x4 T; };
+template <int LB> struct __attribute__((packed, aligned(1))) UV { typename Vec<LB>::T v; };
+__device__ inline uint32_t fold(u32x2 v) { return v.x + v.y; }
+__device__ inline uint32_t fold(u32x4 v) { return (v.x + v.y) ^ (v.z + v.w); }
+
+constexpr int FW = 1920, FH = 1080, RS = FW + 32, RH = FH + 32;
+
+template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent)
+{
+	const uint32_t nwg = gridDim.x, q = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
+	const uint32_t wg = xcd * q + (xcd < r8 ? xcd : r8) + k;
+	const uint32_t wave = wg * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+	const uint32_t local = lane / L, j = lane % L;
+	uint32_t pu = wave * ppw + local;
+	const bool active = local < (uint32_t)ppw && pu < n;
+	if (pu >= n) pu = n - 1;
+	const uint32_t f = pu / per_frame, rr = pu % per_frame, by = rr / per_row, bx = rr % per_row;
+	const uint32_t h = pu * 2654435761u;
+	const int mvx = coherent ? 3 : (int)((h >> 8) % 17u) - 8, mvy = coherent ? -2 : (int)((h >> 17) % 17u) - 8;
+	const int mvx1 = coherent ? -5 : (int)((h >> 3) % 17u) - 8, mvy1 = coherent ? 4 : (int)((h >> 12) % 17u) - 8;
+	typedef typename Vec<LB>::T V;
+	size_t ro = ((size_t)f * RH + 16 + by * H - 3 + mvy) * RS + 16 + bx * W - 3 + mvx + LB * j;
+	if (ALIGNED) ro &= ~(size_t)3;              // the aligned words around the lane's bytes (a real kernel then loads one dword more and realigns in registers)
+	const size_t dof = ((size_t)f * FH + by * H) * FW + bx * W + LB * j;
+	const bool stores = active && (int)j < W / LB;
+	const int rows = H + 7;
+	size_t ro1 = ((size_t)f * RH + 16 + by * H - 3 + mvy1) * RS + 16 + bx * W - 3 + mvx1 + LB * j;
+	if (ALIGNED) ro1 &= ~(size_t)3;
+	V ring[D], ring1[REFS == 2 ? D : 1];
+	uint32_t acc = lane;
+	if (mode == 2)
+	{
+		const V v = reinterpret_cast<const UV<LB> *>(ref + ro)->v;
+		acc ^= fold(v);
+		for (int y = 0; y < H; ++y)
+			if (stores) { V o = v; o.x = acc + y; o.y = acc ^ y; *reinterpret_cast<V *>(dst + dof + (size_t)y * FW) = o; }
+		return;
+	}
+#pragma unroll
+	for (int i = 0; i < D; ++i)
+	{
+		ring[i] = reinterpret_cast<const UV<LB> *>(ref + ro + (size_t)(i < rows ? i : rows - 1) * RS)->v;
+		if (REFS == 2) ring1[i] = reinterpret_cast<const UV<LB> *>(ref1 + ro1 + (size_t)(i < rows ? i : rows - 1) * RS)->v;
+	}
+	for (int r0 = 0; r0 < rows; r0 += D)
+	{
+#pragma unroll
+		for (int i = 0; i < D; ++i)
+		{
+			const int r = r0 + i;
+			const V v = ring[i];
+			const int nx = r + D < rows ? r + D : rows - 1;
+			ring[i] = reinterpret_cast<const UV<LB> *>(ref + ro + (size_t)nx * RS)->v;
+			acc = (acc << 1 | acc >> 31) ^ fold(v);
+			if (REFS == 2)
+			{
+				acc += fold(ring1[i]);
+				ring1[i] = reinterpret_cast<const UV<LB> *>(ref1 + ro1 + (size_t)nx * RS)->v;
+			}
+			if (mode == 0 && r >= 7 && r - 7 < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; *reinterpret_cast<V *>(dst + dof + (size_t)(r - 7) * FW) = o; }
+		}
+	}
+	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; *reinterpret_cast<V *>(dst + dof) = o; }
+}
+
+template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int frames, int mode, uint8_t *dst, const uint8_t *ref, int coherent = 0)
+{
+	const int per_row = FW / W, per_frame = per_row * (FH / H);
+	const uint32_t n = (uint32_t)per_frame * frames;
+	if (W % LB) return;
+	const int L = (W + 7 + LB - 1) / LB, ppw = 64 / L;
+	const uint32_t waves = (n + ppw - 1) / ppw, grid = (waves + 3) / 4;
+	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+	std::vector<float> ms;
+	for (int rep = 0; rep < 7; ++rep)
+	{
+		// a different third of the buffers each time: nothing comes from the Infinity Cache
+		const size_t shift_f = (size_t)(rep % 3) * frames;
+		hipEventRecord(e0);
+		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * FW, ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent);
+		hipEventRecord(e1); hipDeviceSynchronize();
+		float t; hipEventElapsedTime(&t, e0, e1);
+		if (rep) ms.push_back(t);
+	}
+	float best = 1e9f, sum = 0;
+	for (float t : ms) { best = t < best ? t : best; sum += t; }
+	const double ld = (double)(W + 7) * (H + 7), st = (double)W * H;
+	const double bytes = (mode == 0 ? REFS * ld + st : mode == 1 ? REFS * ld : st) * n;
+	printf("%2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
+			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
+}
+
+int main(int argc, char **)
+{
+	const int max_frames = 256;
+	uint8_t *dst, *ref;
+	if (hipMalloc(&dst, (size_t)3 * max_frames * FH * FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * RH * RS + 65536)) { printf("alloc failed\n"); return 1; }
+	hipMemset(ref, 3, (size_t)6 * max_frames * RH * RS);
+	const int sizes[][2] = { { 16, 16 }, { 32, 32 }, { 64, 64 }, { 16, 64 }, { 64, 16 }, { 8, 8 } };
+	const bool quick = argc > 1;
+	for (int frames : { 64, 256 })
+		for (auto &s : sizes)
+		{
+			if (frames == 256 && s[0] != s[1]) continue;
+			for (int mode = 0; mode < 3; ++mode)
+			{
+				run<8, 8, false>(s[0], s[1], frames, mode, dst, ref);
+				run<8, 8, true>(s[0], s[1], frames, mode, dst, ref);
+				if (quick) continue;
+				run<16, 8, false>(s[0], s[1], frames, mode, dst, ref);
+				run<8, 16, false>(s[0], s[1], frames, mode, dst, ref);
+				run<8, 16, true>(s[0], s[1], frames, mode, dst, ref);
+			}
+			// one motion vector for the whole batch: neighbouring PUs' window rows are contiguous
+			run<8, 8, false>(s[0], s[1], frames, 0, dst, ref, 1);
+			run<8, 8, false>(s[0], s[1], frames, 1, dst, ref, 1);
+			// two references (bi-prediction)
+			run<8, 8, false, 2>(s[0], s[1], frames, 0, dst, ref);
+			run<8, 8, true, 2>(s[0], s[1], frames, 0, dst, ref);
+			run<8, 8, false, 2>(s[0], s[1], frames, 1, dst, ref);
+		}
+	return 0;
+}
