@@ -16,12 +16,16 @@ template <int LB> struct Vec;
 template <> struct Vec<8> { typedef u32x2 T; };
 template <> struct Vec<16> { typedef u32x4 T; };
 template <int LB> struct __attribute__((packed, aligned(1))) UV { typename Vec<LB>::T v; };
+__device__ inline void put(uint8_t *p, u32x2 v, int) { *reinterpret_cast<u32x2 *>(p) = v; }
+__device__ inline void put(uint8_t *p, u32x4 v, int sb) { if (sb == 16) *reinterpret_cast<u32x4 *>(p) = v; else { u32x2 h; h.x = v.x; h.y = v.y; *reinterpret_cast<u32x2 *>(p) = h; } }
 __device__ inline uint32_t fold(u32x2 v) { return v.x + v.y; }
 __device__ inline uint32_t fold(u32x4 v) { return (v.x + v.y) ^ (v.z + v.w); }
 
-constexpr int FW = 1920, FH = 1080, RS = FW + 32, RH = FH + 32;
+struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes; };
+constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0 };
+constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0 };
 
-template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent)
+template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent, Geo g)
 {
 	const uint32_t nwg = gridDim.x, q = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
 	const uint32_t wg = xcd * q + (xcd < r8 ? xcd : r8) + k;
@@ -35,12 +39,13 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 	const int mvx = coherent ? 3 : (int)((h >> 8) % 17u) - 8, mvy = coherent ? -2 : (int)((h >> 17) % 17u) - 8;
 	const int mvx1 = coherent ? -5 : (int)((h >> 3) % 17u) - 8, mvy1 = coherent ? 4 : (int)((h >> 12) % 17u) - 8;
 	typedef typename Vec<LB>::T V;
-	size_t ro = ((size_t)f * RH + 16 + by * H - 3 + mvy) * RS + 16 + bx * W - 3 + mvx + LB * j;
+	const int FW = g.FW, FH = g.FH, RS = g.RS, RH = g.RH, pitch = g.pitch ? g.pitch : LB, SB = g.store_bytes ? g.store_bytes : LB;
+	size_t ro = ((size_t)f * RH + 16 + by * H - g.before + mvy) * RS + 16 + bx * W - g.before + mvx + pitch * j;
 	if (ALIGNED) ro &= ~(size_t)3;              // the aligned words around the lane's bytes (a real kernel then loads one dword more and realigns in registers)
-	const size_t dof = ((size_t)f * FH + by * H) * FW + bx * W + LB * j;
-	const bool stores = active && (int)j < W / LB;
-	const int rows = H + 7;
-	size_t ro1 = ((size_t)f * RH + 16 + by * H - 3 + mvy1) * RS + 16 + bx * W - 3 + mvx1 + LB * j;
+	const size_t dof = ((size_t)f * FH + by * H) * FW + bx * W + SB * j;
+	const bool stores = active && (int)j < W / SB;
+	const int rows = H + g.margin, first_out = g.margin;
+	size_t ro1 = ((size_t)f * RH + 16 + by * H - g.before + mvy1) * RS + 16 + bx * W - g.before + mvx1 + pitch * j;
 	if (ALIGNED) ro1 &= ~(size_t)3;
 	V ring[D], ring1[REFS == 2 ? D : 1];
 	uint32_t acc = lane;
@@ -49,7 +54,7 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 		const V v = reinterpret_cast<const UV<LB> *>(ref + ro)->v;
 		acc ^= fold(v);
 		for (int y = 0; y < H; ++y)
-			if (stores) { V o = v; o.x = acc + y; o.y = acc ^ y; *reinterpret_cast<V *>(dst + dof + (size_t)y * FW) = o; }
+			if (stores) { V o = v; o.x = acc + y; o.y = acc ^ y; put(dst + dof + (size_t)y * FW, o, SB); }
 		return;
 	}
 #pragma unroll
@@ -73,18 +78,19 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 				acc += fold(ring1[i]);
 				ring1[i] = reinterpret_cast<const UV<LB> *>(ref1 + ro1 + (size_t)nx * RS)->v;
 			}
-			if (mode == 0 && r >= 7 && r - 7 < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; *reinterpret_cast<V *>(dst + dof + (size_t)(r - 7) * FW) = o; }
+			if (mode == 0 && r >= first_out && r - first_out < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; put(dst + dof + (size_t)(r - first_out) * FW, o, SB); }
 		}
 	}
-	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; *reinterpret_cast<V *>(dst + dof) = o; }
+	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; put(dst + dof, o, SB); }
 }
 
-template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int frames, int mode, uint8_t *dst, const uint8_t *ref, int coherent = 0)
+template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int frames, int mode, uint8_t *dst, const uint8_t *ref, int coherent = 0, Geo g = kLuma)
 {
+	const int FW = g.FW, FH = g.FH, RS = g.RS, RH = g.RH, pitch = g.pitch ? g.pitch : LB, SB = g.store_bytes ? g.store_bytes : LB;
 	const int per_row = FW / W, per_frame = per_row * (FH / H);
 	const uint32_t n = (uint32_t)per_frame * frames;
-	if (W % LB) return;
-	const int L = (W + 7 + LB - 1) / LB, ppw = 64 / L;
+	if (W % SB) return;
+	const int L = g.pitch ? W / pitch : (W + g.margin + LB - 1) / LB, ppw = 64 / L;
 	const uint32_t waves = (n + ppw - 1) / ppw, grid = (waves + 3) / 4;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	std::vector<float> ms;
@@ -93,16 +99,16 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int 
 		// a different third of the buffers each time: nothing comes from the Infinity Cache
 		const size_t shift_f = (size_t)(rep % 3) * frames;
 		hipEventRecord(e0);
-		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * FW, ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent);
+		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * FW, ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent, g);
 		hipEventRecord(e1); hipDeviceSynchronize();
 		float t; hipEventElapsedTime(&t, e0, e1);
 		if (rep) ms.push_back(t);
 	}
 	float best = 1e9f, sum = 0;
 	for (float t : ms) { best = t < best ? t : best; sum += t; }
-	const double ld = (double)(W + 7) * (H + 7), st = (double)W * H;
+	const double ld = (double)(W + g.margin) * (H + g.margin), st = (double)W * H;
 	const double bytes = (mode == 0 ? REFS * ld + st : mode == 1 ? REFS * ld : st) * n;
-	printf("%2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
+	printf("%s %2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", g.margin == 7 ? "luma  " : g.pitch ? "chroma (strip deal)" : "chroma (stream deal)", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
 			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
 }
 
@@ -110,10 +116,33 @@ int main(int argc, char **)
 {
 	const int max_frames = 256;
 	uint8_t *dst, *ref;
-	if (hipMalloc(&dst, (size_t)3 * max_frames * FH * FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * RH * RS + 65536)) { printf("alloc failed\n"); return 1; }
-	hipMemset(ref, 3, (size_t)6 * max_frames * RH * RS);
+	if (hipMalloc(&dst, (size_t)3 * max_frames * kLuma.FH * kLuma.FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * kLuma.RH * kLuma.RS + 65536)) { printf("alloc failed\n"); return 1; }
+	hipMemset(ref, 3, (size_t)6 * max_frames * kLuma.RH * kLuma.RS);
 	const int sizes[][2] = { { 16, 16 }, { 32, 32 }, { 64, 64 }, { 16, 64 }, { 64, 16 }, { 8, 8 } };
-	const bool quick = argc > 1;
+	const bool chroma = argc > 1;
+	if (chroma)
+	{
+		// 960 x 540 planes, 4 taps; "frames" = planes per launch (Cb + Cr of 64 frames = 128).  Strip deal = pred_strip4_kernel's: one lane per 8-column strip,
+		// one dword-aligned 16-byte load per lane and row at an 8-byte pitch, every lane stores 8 bytes; stream deal = pred_stream_kernel's 8-byte lanes.
+		Geo strip = kChroma; strip.pitch = 8; strip.store_bytes = 8;
+		const int csizes[][2] = { { 8, 8 }, { 16, 16 }, { 8, 16 }, { 16, 8 }, { 32, 32 }, { 8, 32 } };
+		for (int planes : { 64, 128 })
+			for (auto &s : csizes)
+				for (int mode = 0; mode < 3; ++mode)
+				{
+					run<8, 16, true>(s[0], s[1], planes, mode, dst, ref, 0, strip);
+					run<4, 16, true>(s[0], s[1], planes, mode, dst, ref, 0, strip);
+					run<8, 8, false>(s[0], s[1], planes, mode, dst, ref, 0, kChroma);
+					if (mode == 0)
+					{
+						run<8, 16, true, 2>(s[0], s[1], planes, mode, dst, ref, 0, strip);
+						run<4, 16, true, 2>(s[0], s[1], planes, mode, dst, ref, 0, strip);
+						run<8, 16, true>(s[0], s[1], planes, mode, dst, ref, 1, strip);
+					}
+				}
+		return 0;
+	}
+	const bool quick = false;
 	for (int frames : { 64, 256 })
 		for (auto &s : sizes)
 		{
