@@ -21,9 +21,9 @@ __device__ inline void put(uint8_t *p, u32x4 v, int sb) { if (sb == 16) *reinter
 __device__ inline uint32_t fold(u32x2 v) { return v.x + v.y; }
 __device__ inline uint32_t fold(u32x4 v) { return (v.x + v.y) ^ (v.z + v.w); }
 
-struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes; };
-constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0 };
-constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0 };
+struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes, DS; };
+constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0, 0 };
+constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0, 0 };
 
 template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent, Geo g)
 {
@@ -42,7 +42,8 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 	const int FW = g.FW, FH = g.FH, RS = g.RS, RH = g.RH, pitch = g.pitch ? g.pitch : LB, SB = g.store_bytes ? g.store_bytes : LB;
 	size_t ro = ((size_t)f * RH + 16 + by * H - g.before + mvy) * RS + 16 + bx * W - g.before + mvx + pitch * j;
 	if (ALIGNED) ro &= ~(size_t)3;              // the aligned words around the lane's bytes (a real kernel then loads one dword more and realigns in registers)
-	const size_t dof = ((size_t)f * FH + by * H) * FW + bx * W + SB * j;
+	const int DS = g.DS ? g.DS : FW;
+	const size_t dof = ((size_t)f * FH + by * H) * DS + bx * W + SB * j;
 	const bool stores = active && (int)j < W / SB;
 	const int rows = H + g.margin, first_out = g.margin;
 	size_t ro1 = ((size_t)f * RH + 16 + by * H - g.before + mvy1) * RS + 16 + bx * W - g.before + mvx1 + pitch * j;
@@ -54,7 +55,7 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 		const V v = reinterpret_cast<const UV<LB> *>(ref + ro)->v;
 		acc ^= fold(v);
 		for (int y = 0; y < H; ++y)
-			if (stores) { V o = v; o.x = acc + y; o.y = acc ^ y; put(dst + dof + (size_t)y * FW, o, SB); }
+			if (stores) { V o = v; o.x = acc + y; o.y = acc ^ y; put(dst + dof + (size_t)y * DS, o, SB); }
 		return;
 	}
 #pragma unroll
@@ -78,7 +79,7 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 				acc += fold(ring1[i]);
 				ring1[i] = reinterpret_cast<const UV<LB> *>(ref1 + ro1 + (size_t)nx * RS)->v;
 			}
-			if (mode == 0 && r >= first_out && r - first_out < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; put(dst + dof + (size_t)(r - first_out) * FW, o, SB); }
+			if (mode == 0 && r >= first_out && r - first_out < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; put(dst + dof + (size_t)(r - first_out) * DS, o, SB); }
 		}
 	}
 	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; put(dst + dof, o, SB); }
@@ -99,7 +100,7 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int 
 		// a different third of the buffers each time: nothing comes from the Infinity Cache
 		const size_t shift_f = (size_t)(rep % 3) * frames;
 		hipEventRecord(e0);
-		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * FW, ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent, g);
+		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * (g.DS ? g.DS : FW), ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent, g);
 		hipEventRecord(e1); hipDeviceSynchronize();
 		float t; hipEventElapsedTime(&t, e0, e1);
 		if (rep) ms.push_back(t);
@@ -112,13 +113,27 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int 
 			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
 }
 
-int main(int argc, char **)
+int main(int argc, char **argv)
 {
 	const int max_frames = 256;
 	uint8_t *dst, *ref;
-	if (hipMalloc(&dst, (size_t)3 * max_frames * kLuma.FH * kLuma.FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * kLuma.RH * kLuma.RS + 65536)) { printf("alloc failed\n"); return 1; }
+	if (hipMalloc(&dst, (size_t)3 * max_frames * kLuma.FH * kLuma.FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * kLuma.RH * 2304 + 65536)) { printf("alloc failed\n"); return 1; }
 	hipMemset(ref, 3, (size_t)6 * max_frames * kLuma.RH * kLuma.RS);
 	const int sizes[][2] = { { 16, 16 }, { 32, 32 }, { 64, 64 }, { 16, 64 }, { 64, 16 }, { 8, 8 } };
+	if (argc > 1 && argv[1][0] == 's')
+	{
+		// does the reference stride matter?  (the caller chooses it: integration advice if it does)
+		for (int rs : { 1952, 1984, 2048, 2112, 2176, 2304 })
+			for (int fw : { 1920, 2048 })
+			{
+				Geo g = kLuma; g.RS = rs; g.DS = fw;
+				printf("reference stride %d, destination stride %d:\n", rs, fw);
+				run<8, 8, false>(16, 16, 64, 0, dst, ref, 0, g);
+				run<8, 8, false>(64, 64, 64, 0, dst, ref, 0, g);
+				run<8, 8, false>(16, 16, 64, 1, dst, ref, 0, g);
+			}
+		return 0;
+	}
 	const bool chroma = argc > 1;
 	if (chroma)
 	{
