@@ -147,10 +147,11 @@ def sad_case(w, h, n, seed, ways=1, max_disp=7, frame=(SMALL_W, SMALL_H), kind="
         w=w, h=h, n=n, ways=ways)
 
 
-def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noise", fracs=None, device=None, coherent_mv=False):
+def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noise", fracs=None, device=None, coherent_mv=False, mv_region=0):
     """Config #3: dst tiled by w x h PUs; reference origin = same position displaced by an integer
     motion vector in [-8, 8]^2; fractions uniform over all phases (4 luma / 8 chroma per axis)
-    unless ``fracs`` = (xFrac, yFrac) pins them."""
+    unless ``fracs`` = (xFrac, yFrac) pins them.  ``mv_region`` = R > 0: one vector and fraction pair per R x R pixel region
+    of a frame (all PUs of a CTU move together: measurement only) instead of one per PU."""
     fw, fh = frame
     frames = Plane.frames_for(n, w, h, fw, fh)
     dp = Plane(fw, fh, frames)
@@ -165,11 +166,23 @@ def pred_case(taps, w, h, n, seed, bi=False, frame=(SMALL_W, SMALL_H), kind="noi
         mv = rng.integers(-8, 9, size=(n, 2))
         if coherent_mv:               # one motion vector for the whole batch (exploration only)
             mv[:] = mv[0]
-        off = base + mv[:, 1] * rp.stride + mv[:, 0]
         if fracs is None:
             fx, fy = rng.integers(0, phases, size=n), rng.integers(0, phases, size=n)
         else:
             fx, fy = np.full(n, fracs[0]), np.full(n, fracs[1])
+        if mv_region:
+            # the region a PU's top-left pixel lies in, per frame
+            per_row, per_col = fw // w, fh // h
+            i = np.arange(n, dtype=np.int64)
+            f, rr = i // (per_row * per_col), i % (per_row * per_col)
+            ry, rx = (rr // per_row) * h // mv_region, (rr % per_row) * w // mv_region
+            regions_x, regions_y = -(-fw // mv_region), -(-fh // mv_region)
+            region = (f * regions_y + ry) * regions_x + rx
+            n_regions = int(region.max()) + 1
+            mv = rng.integers(-8, 9, size=(n_regions, 2))[region]
+            if fracs is None:
+                fx, fy = rng.integers(0, phases, size=n_regions)[region], rng.integers(0, phases, size=n_regions)[region]
+        off = base + mv[:, 1] * rp.stride + mv[:, 0]
         out["ref%d" % r] = fill_u8(rp.size, seed + 2 + r, kind, device)
         out["ref%d_off" % r] = off.astype(np.uint32)
         out["frac%d" % r] = (fx | (fy << 4)).astype(np.uint8)

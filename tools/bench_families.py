@@ -35,7 +35,7 @@ def report(name, n, bytes_per_block, ms, **kw):
         print(json.dumps(row), flush=True)
 
 
-def bench_pred(frames=64, only=None, two_planes=True, taps_only=None):
+def bench_pred(frames=64, only=None, two_planes=True, taps_only=None, mv_region=0):
     """Config #3: 1920x1080 luma tiled by each PU size (chroma planes 960x540, 4-tap), all phases,
     `frames` frames per launch so that the launch is far above the launch floor."""
     for taps, fw, fh in ((8, 1920, 1080), (4, 960, 540)):
@@ -50,7 +50,7 @@ def bench_pred(frames=64, only=None, two_planes=True, taps_only=None):
                 if bi and (w, h) in ((8, 4), (4, 8)):
                     continue
                 # distinct inputs per repetition so that nothing is served from the Infinity Cache
-                cs = [wl.pred_case(taps, pw, ph, n, 50 + i, bi=bi, frame=(fw, fh), device="cuda") for i in range(3)]
+                cs = [wl.pred_case(taps, pw, ph, n, 50 + i, bi=bi, frame=(fw, fh), device="cuda", mv_region=mv_region * taps // 8) for i in range(3)]
                 devs = []
                 for c in cs:
                     d = dict(dst=torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), dst_off=B.off32(c["dst_off"]))
@@ -365,6 +365,12 @@ if __name__ == "__main__":
     for w in what:
         if w == "pred4tap":                               # chroma only, every PU size
             bench_pred(taps_only=4)
+            continue
+        if w.startswith("pred8ctu") and w[8:].isdigit():  # the same, luma only
+            bench_pred(taps_only=8, only=((16, 16), (32, 32), (64, 64), (64, 32), (16, 64)), mv_region=int(w[8:]))
+            continue
+        if w.startswith("predctu") and w[7:].isdigit():   # one vector per N x N luma region (N / 2 chroma) instead of one per PU: what coherent motion is worth
+            bench_pred(only=((8, 8), (16, 16), (32, 32), (16, 32), (32, 16)), mv_region=int(w[7:]))
             continue
         if w == "pred8tap":                               # luma only, every PU size
             bench_pred(taps_only=8)
