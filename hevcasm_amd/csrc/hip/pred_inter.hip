@@ -896,6 +896,205 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 // loads per lane instead of one of 16): the same vector-L1 accesses (an unaligned lane load is charged by the bytes asked for), a third more HBM traffic, more
 // time waiting.  The stream kernel is not bound by its instruction count.  profiles/r04_pred_hfirst_ab.txt; source: commit cf83a19.
 
+// ---- 8-tap bi-prediction, horizontal pass first, one lane per (8-column strip, reference) (round 4: 16- and 32-wide PUs) ------------------
+//
+// Luma bi-prediction is the one prediction kernel that the VALU bounds (74-83 % busy, 1.15-1.35 x the time of its access pattern alone,
+// profiles/r04_pred_access_mix.txt).  This form spends fewer vector instructions: a lane owns a strip of 8 output columns OF ONE REFERENCE, loads the strip's
+// 16 window bytes itself (one load per row), filters horizontally in the byte domain (v_dot4_i32_i8 on pixel - 128), keeps the 14-bit sums as int16 row
+// pairs and filters vertically with v_dot2_i32_i16 over the pairs; the two lanes of a strip (neighbours) then swap halves of their 14-bit intermediates
+// (quad_perm DPP) and each rounds, clips and stores 4 pixels.  Arithmetic = the reference's (pred_inter.c:490-530): per reference (sum >> 6) stored as
+// int16 (it wraps: trunc16_shr6), then (a + b + 64) >> 7 clipped.  Footprints = the reference's, as in pred_stream_kernel (window rows and bytes clamped).
+__device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
+__device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
+{
+	int r;
+	asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(k));
+	return r;
+}
+__device__ __forceinline__ int swap_pair_lane(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false); }
+
+template <int AHEAD>
+__global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
+	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
+	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
+	int W, int H, int S /* strips per PU = W / 8 */, int PPW /* PUs per wave */, uint32_t n_blocks, ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
+{
+	static_assert(AHEAD == 8, "the ring turns once per unrolled group of 8 rows");
+	if (blockIdx.y)
+	{
+		dst += plane2_dst;
+		ref0 += plane2_ref0;
+		ref1 += plane2_ref1;
+	}
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
+	const int lane = threadIdx.x & 63;
+	const int which = lane & 1;                   // the reference this lane filters; it stores columns 4 which .. 4 which + 3 of the strip
+	int sub = (lane >> 1) / S;
+	int j = (lane >> 1) - sub * S;
+	const bool spare = sub >= PPW;
+	if (spare) { sub = PPW - 1; j = 0; }
+	uint32_t pu = wave * (uint32_t)PPW + (uint32_t)sub;
+	const bool in_batch = pu < n_blocks;
+	if (!in_batch) pu = n_blocks - 1;
+	const bool stores = in_batch && !spare;
+	const uint8_t *__restrict__ ref = which ? ref1 : ref0;
+
+	const int fr = which ? frac1[pu] : frac0[pu];
+	const int xf = fr & 15, yf = fr >> 4;
+	const int bx = xf ? 3 : 0, ax = xf ? 4 : 0, by = yf ? 3 : 0, ay = yf ? 4 : 0;
+	const uint32_t step_ref = (uint32_t)stride_ref, step_dst = (uint32_t)stride_dst;
+
+	// taps.  Horizontal: signed bytes, taps 0..3 and 4..7 of phase xf.  Vertical: int16 pairs for the two row parities.
+	uint32_t cA = 0, cB = 0;
+	int v[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+	{
+		const uint32_t tb = (kTaps.luma[k] >> (8 * (xf & 3))) & 0xffu;
+		if (k < 4) cA |= tb << (8 * k); else cB |= tb << (8 * (k - 4));
+		v[k] = __builtin_amdgcn_sbfe((int)kTaps.luma[k], (uint32_t)(8 * (yf & 3)), 8u);
+	}
+	auto pair16 = [](int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); };
+	const uint32_t E0 = pair16(v[0], v[1]), E1 = pair16(v[2], v[3]), E2 = pair16(v[4], v[5]), E3 = pair16(v[6], v[7]);
+	const uint32_t O0 = pair16(0, v[0]), O1 = pair16(v[1], v[2]), O2 = pair16(v[3], v[4]), O3 = pair16(v[5], v[6]), O4 = pair16(v[7], 0);
+
+	// the strip's 16 window bytes as ONE load, moved left where it would pass the window's end (the PU's last strip: by one byte where xFrac filters,
+	// by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide)
+	const int col_nat = 8 * j - bx;
+	const int col0 = min(col_nat, W + ax - 16);
+	const uint32_t sh_bytes = (uint32_t)(col_nat - col0);                       // 0, 1 or 8
+	const bool sh8 = sh_bytes >= 8u;
+	const uint32_t hsh = sh_bytes & 3u;
+	const int last_row = H + ay + by - 1;                                       // last stream row the reference reads (stream row 0 = PU row -by)
+	const uint32_t first_lo = (which ? ref1_off[pu] : ref0_off[pu]) + (uint32_t)(-by) * step_ref + (uint32_t)col0;
+	const uint32_t end_lo = first_lo + (uint32_t)last_row * step_ref;
+	const uint32_t lo_b = min(first_lo, end_lo), hi_b = max(first_lo, end_lo);
+	uint32_t off = first_lo;
+	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * j + 4 * which);
+
+	auto issue = [&](uint32_t (&d)[4])
+	{
+		const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
+		d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
+		off = med3_u32(off + step_ref, lo_b, hi_b);
+	};
+	// 8 horizontal sums of one window row
+	auto hrow = [&](const uint32_t (&d)[4], int (&h)[8])
+	{
+		// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
+		const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
+		const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
+		const uint32_t x0 = __builtin_amdgcn_alignbyte(e1, e0, hsh), x1 = __builtin_amdgcn_alignbyte(e2, e1, hsh);
+		const uint32_t x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh), x3 = __builtin_amdgcn_alignbyte(0x80808080u, e3, hsh);
+		uint32_t g[12];
+		g[0] = x0; g[4] = x1; g[8] = x2;
+#pragma unroll
+		for (int q = 1; q < 4; ++q)
+		{
+			g[q] = __builtin_amdgcn_alignbyte(x1, x0, q);
+			g[4 + q] = __builtin_amdgcn_alignbyte(x2, x1, q);
+			g[8 + q] = __builtin_amdgcn_alignbyte(x3, x2, q);
+		}
+#pragma unroll
+		for (int x = 0; x < 8; ++x) h[x] = sdot4(g[x + 4], cB, sdot4_first(g[x], cA, 8192));     // sum c (p - 128) + 128 * 64
+	};
+
+	uint32_t P[4][8];             // P[m][c]: sums of (row 2 (i + m'), row 2 (i + m') + 1), column c
+	uint32_t ring[AHEAD][4];      // window rows 8 + ... in flight
+	{
+		uint32_t first8[8][4];
+#pragma unroll
+		for (int r = 0; r < 8; ++r) issue(first8[r]);
+#pragma unroll
+		for (int a = 0; a < AHEAD; ++a) issue(ring[a]);
+#pragma unroll
+		for (int m = 0; m < 4; ++m)
+		{
+			int h0[8], h1[8];
+			hrow(first8[2 * m], h0);
+			hrow(first8[2 * m + 1], h1);
+#pragma unroll
+			for (int c = 0; c < 8; ++c) P[m][c] = __builtin_amdgcn_perm((uint32_t)h1[c], (uint32_t)h0[c], 0x05040100);
+		}
+	}
+
+	// t: this reference's second-pass sums of one row; the partner lane holds the other reference's
+	auto store_row = [&](const int (&t)[8])
+	{
+		int mine[4];
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+		{
+			const int lo = trunc16_shr6(t[k]), hi = trunc16_shr6(t[4 + k]);
+			const int keep = which ? hi : lo, send = which ? lo : hi;          // the partner stores the other four columns
+			mine[k] = keep + swap_pair_lane(send) + 64;
+		}
+		const uint32_t a0 = __builtin_amdgcn_ashr_pk_u8_i32(mine[0], mine[1], 7), a1 = __builtin_amdgcn_ashr_pk_u8_i32(mine[2], mine[3], 7);
+		const uint32_t px = __builtin_amdgcn_perm(a1, a0, 0x05040100);
+		if (stores) reinterpret_cast<U1 *>(dst + (size_t)out_off)->v = px;
+		out_off += step_dst;
+	};
+	// output rows 2 i and 2 i + 1; the pair whose rows they start on is slot i % 4, the pair that arrives (rows 2 i + 8, 2 i + 9) replaces it
+	auto two_rows = [&](auto loads_tag, const int ii)
+	{
+		constexpr bool LOADS = decltype(loads_tag)::value;
+		const int s0 = ii % 4, s1 = (ii + 1) % 4, s2 = (ii + 2) % 4, s3 = (ii + 3) % 4;
+		int odd[8], even[8];
+#pragma unroll
+		for (int c = 0; c < 8; ++c)
+		{
+			odd[c] = dot2_first(P[s0][c], O0);
+			even[c] = dot2(P[s3][c], E3, dot2(P[s2][c], E2, dot2(P[s1][c], E1, dot2_first(P[s0][c], E0))));
+		}
+		store_row(even);
+		int h0[8], h1[8];
+		hrow(ring[(2 * ii) % AHEAD], h0);
+		hrow(ring[(2 * ii + 1) % AHEAD], h1);
+		if (LOADS)
+		{
+			issue(ring[(2 * ii) % AHEAD]);
+			issue(ring[(2 * ii + 1) % AHEAD]);
+		}
+#pragma unroll
+		for (int c = 0; c < 8; ++c)
+		{
+			P[s0][c] = __builtin_amdgcn_perm((uint32_t)h1[c], (uint32_t)h0[c], 0x05040100);
+			odd[c] = dot2(P[s0][c], O4, dot2(P[s3][c], O3, dot2(P[s2][c], O2, dot2(P[s1][c], O1, odd[c]))));
+		}
+		store_row(odd);
+	};
+	const int groups = H / 8;
+	for (int g = 0; g < groups - 1; ++g)
+	{
+#pragma unroll
+		for (int ii = 0; ii < 4; ++ii) two_rows(Flag<true>(), ii);
+	}
+#pragma unroll
+	for (int ii = 0; ii < 4; ++ii) two_rows(Flag<false>(), ii);
+}
+
+// Where it pays (same binary, 64 frames of 1080p per launch, profiles/r04_pred_hfirst_bi_ab.txt): 16-wide PUs of 16 rows and more -5 ... -9 %, 32-wide of 24 and
+// more -3 ... -7 %.  Short PUs lose (the first 8 rows are filtered before the first output row: 32x8 +19 %, 16x8 +5 %, 32x16 +4 %), 64-wide lose
+// +4 ... +18 % (16 lanes to a PU row and 2 bytes loaded per pixel where the stream kernel's 9 lanes load 1.1), 24- / 48-wide +9 % / -1 %.
+static bool hfirst_bi_applies(int W, int H)
+{
+	static const bool off = getenv("HEVCASM_PRED_NOHFIRST_BI") != nullptr;      // measurement switches, read once per process
+	static const bool all = getenv("HEVCASM_PRED_HFIRST_BI_ALL") != nullptr;    // every size the kernel can take
+	if (off || W % 8 || H % 8 || W < 16 || W > 64) return false;
+	return all || (W == 16 && H >= 16) || (W == 32 && H >= 24);
+}
+
+static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr, const uint32_t *dof, const uint32_t *r0, const uint32_t *r1,
+		const uint8_t *f0, const uint8_t *f1, int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
+{
+	const int strips = W / 8, ppw = kWave / (2 * strips);
+	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
+	hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
+	return launch_status("pred_hfirst_bi8_kernel");
+}
+
 template <int TAPS, bool BI>
 static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
 		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1,
@@ -912,6 +1111,7 @@ static int launch_pred(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const ui
 	// 24- / 32-wide +-0 ... +20 % (the stream kernel's lanes share the vertical pass there).
 	const bool strip_pays = (W <= 8 && !(BI && W == 4)) || W == 16;
 	if (TAPS == 4 && strip_pays && H >= 2 && (sr >= 16 || sr <= -16) && !no_strip) return launch_pred_strip4<BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
+	if constexpr (TAPS == 8 && BI) { if (hfirst_bi_applies(W, H)) return launch_pred_hfirst_bi8(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2); }
 	if (W >= 8) return launch_pred_ndw<TAPS, 2, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 	return launch_pred_ndw<TAPS, 1, BI>(dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, n, st, p2);
 }

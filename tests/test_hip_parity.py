@@ -898,3 +898,26 @@ def test_pred_strip_segments_keep_every_row():
                 c = wl.pred_case(4, w, h, 9, 8800 + 40 * w + h, bi=bi, frame=(2 * w, 2 * h))
                 fam = "pred_bi" if bi else "pred_uni"
                 cases.assert_same("strip segments %s %dx%d" % (fam, w, h), cases.run_hip(fam, c), cases.run_oracle(fam, c))
+
+
+def test_pred_bi_hfirst_kernel_sizes_and_edges():
+    """Round 4: luma bi-prediction of 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (a lane per strip and reference, horizontal pass first).  Every
+    height it takes (standard and not), batches that leave spare lanes and a partial last wave, bottom-up planes, the rails (all-0 / all-255 planes: the
+    14-bit intermediates wrap) and every fraction pair including zero fractions on either reference."""
+    from hevcasm_amd import workload as wl
+    for w in (16, 32):
+        for h in (16, 24, 32, 40, 48, 64):
+            for n in (1, 37):
+                c = wl.pred_case(8, w, h, n, 9100 + w + h + n, bi=True, frame=(4 * w, 2 * h))
+                cases.assert_same("hfirst bi %dx%d n=%d" % (w, h, n), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    for kind in ("zeros", "max"):
+        c = wl.pred_case(8, 16, 16, 50, 9300, bi=True, frame=(64, 32), kind=kind)
+        cases.assert_same("hfirst bi rails " + kind, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    c = cases._wrap14(wl.pred_case(8, 32, 32, 7, 9350, bi=True, frame=(64, 64), fracs=(2, 2)))
+    cases.assert_same("hfirst bi wrap 32x32", cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    for fx0 in range(4):
+        for fy0 in range(4):
+            c = wl.pred_case(8, 32, 24, 21, 9400 + 4 * fx0 + fy0, bi=True, frame=(96, 48), fracs=(fx0, fy0))
+            c["frac1"] = ((3 - fx0) | ((fy0 ^ 1) << 4)) * np.ones_like(c["frac1"])
+            cases.assert_same("hfirst bi fractions %d %d" % (fx0, fy0), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+
