@@ -915,6 +915,19 @@ def test_pred_bi_hfirst_kernel_sizes_and_edges():
         cases.assert_same("hfirst bi rails " + kind, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
     c = cases._wrap14(wl.pred_case(8, 32, 32, 7, 9350, bi=True, frame=(64, 64), fracs=(2, 2)))
     cases.assert_same("hfirst bi wrap 32x32", cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    # plane strides that are not a multiple of 4 (the byte-aligned form of the kernel) and plane bases at every byte alignment (the word-aligned form's shifts)
+    c = wl.pred_case(8, 16, 32, 23, 9360, bi=True, frame=(66, 64))
+    assert c["stride_ref"] % 4 == 2
+    cases.assert_same("hfirst bi odd stride", cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    import torch
+    from hevcasm_amd import batch as B
+    for k in (1, 2, 3):
+        c = wl.pred_case(8, 16 * (1 + k % 2), 16, 29, 9370 + k, bi=True, frame=(128, 32))
+        shifted = [torch.from_numpy(np.concatenate([np.zeros(s, np.uint8), c["ref%d" % r]])).cuda()[s:] for r, s in ((0, k), (1, (k + 1) % 4))]
+        d = B.pred_bi(torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), c["stride_dst"], shifted[0], shifted[1], c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]),
+                      B.off32(c["ref1_off"]), B.u8(c["frac0"]), B.u8(c["frac1"]), 8, c["w"], c["h"])
+        got = cases._only_blocks(d.cpu().numpy(), c["stride_dst"], c["dst_off"], c["w"], c["h"])
+        cases.assert_same("hfirst bi plane base + %d" % k, got, cases.run_oracle("pred_bi", c))
     for fx0 in range(4):
         for fy0 in range(4):
             c = wl.pred_case(8, 32, 24, 21, 9400 + 4 * fx0 + fy0, bi=True, frame=(96, 48), fracs=(fx0, fy0))
