@@ -237,10 +237,11 @@ for _n in (8, 16, 32):
 
 # Integer VALU roof of the part: 256 CUs x 4 SIMDs x 16 lanes per clock at 2.4 GHz (tools/ubench/valu_rates.hip measures one full-rate wave-instruction
 # per ~4 cycles per SIMD: profiles/r01_valu_issue_rates.txt), and the vector lane-operations the luma prediction kernels issue per output pixel of a
-# 16x16 PU (SQ_INSTS_VALU x 64 / pixels, rocprofv3 --pmc: profiles/r04_pred_transform_counters.txt).  Prediction is bound by this roof, not by HBM
-# (DESIGN.md 4.2): <key>_valu_frac says how much of it a row uses, next to the HBM fraction the metric asks for.
+# 16x16 PU (SQ_INSTS_VALU x 64 / pixels, rocprofv3 --pmc: uni = pred_stream_kernel, profiles/r04_pred_transform_counters.txt; bi = pred_hfirst_bi8_kernel,
+# profiles/r04_pred_hfirst_bi_ab.txt -- the stream kernel it replaced at this size issued 43.7).  <key>_valu_frac says how much of that roof a row uses, next
+# to the HBM fraction the metric asks for; what bounds these kernels is their access pattern (profiles/r04_pred_access_mix.txt).
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9
-PRED_LANE_OPS_PER_PIXEL = {"pred_uni_luma16": 20.1, "pred_bi_luma16": 43.7, "pred_uni_luma16_256f": 20.1, "pred_bi_luma16_256f": 43.7}
+PRED_LANE_OPS_PER_PIXEL = {"pred_uni_luma16": 20.1, "pred_bi_luma16": 34.1, "pred_uni_luma16_256f": 20.1, "pred_bi_luma16_256f": 34.1}
 
 
 def flatten_families(rows):

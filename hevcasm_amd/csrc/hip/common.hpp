@@ -31,7 +31,6 @@ typedef uint32_t u32x1_u __attribute__((aligned(1)));
 typedef u32x2 u32x2_u __attribute__((aligned(1)));
 typedef u32x3 u32x3_u __attribute__((aligned(1)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));
-typedef u32x4 u32x4_w __attribute__((aligned(4)));      // 16 bytes at word alignment
 
 template <int BYTES> struct Chunk;
 template <> struct Chunk<4>

@@ -913,8 +913,8 @@ __device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
 }
 __device__ __forceinline__ int swap_pair_lane(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false); }
 
-template <int AHEAD, bool ALIGNED>
-__global__ __launch_bounds__(kThreads, 4) void pred_hfirst_bi8_kernel(
+template <int AHEAD>
+__global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
@@ -960,50 +960,34 @@ __global__ __launch_bounds__(kThreads, 4) void pred_hfirst_bi8_kernel(
 	const uint32_t E0 = pair16(v[0], v[1]), E1 = pair16(v[2], v[3]), E2 = pair16(v[4], v[5]), E3 = pair16(v[6], v[7]);
 	const uint32_t O0 = pair16(0, v[0]), O1 = pair16(v[1], v[2]), O2 = pair16(v[3], v[4]), O3 = pair16(v[5], v[6]), O4 = pair16(v[7], 0);
 
-	// The strip's window bytes.  !ALIGNED: ONE byte-aligned 16-byte load, moved left where it would pass the window's end (the PU's last strip: by one byte where
-	// xFrac filters, by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide).
-	// ALIGNED (stride_ref % 4 == 0, so a lane's alignment is the same on every row): the aligned words that hold the strip's 15 bytes -- a 16-byte load plus the
-	// word behind it where the bytes reach into it (else the last of the four again) -- realigned by v_alignbyte with the lane's own shift.  A word that holds a
-	// byte of the window never crosses into a page the window does not touch.  Only the unfiltered last strip still moves left by eight.
+	// the strip's 16 window bytes as ONE load, moved left where it would pass the window's end (the PU's last strip: by one byte where xFrac filters,
+	// by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide)
 	const int col_nat = 8 * j - bx;
-	const int col0 = ALIGNED ? ((xf == 0 && j == S - 1) ? col_nat - 8 : col_nat) : min(col_nat, W + ax - 16);
+	const int col0 = min(col_nat, W + ax - 16);
 	const uint32_t sh_bytes = (uint32_t)(col_nat - col0);                       // 0, 1 or 8
 	const bool sh8 = sh_bytes >= 8u;
+	const uint32_t hsh = sh_bytes & 3u;
 	const int last_row = H + ay + by - 1;                                       // last stream row the reference reads (stream row 0 = PU row -by)
-	const uint32_t first_byte = (which ? ref1_off[pu] : ref0_off[pu]) + (uint32_t)(-by) * step_ref + (uint32_t)col0;
-	const uint32_t mis = ALIGNED ? ((uint32_t)reinterpret_cast<uintptr_t>(ref) + first_byte) & 3u : 0u;
-	const uint32_t hsh = ALIGNED ? mis : sh_bytes & 3u;
-	const uint32_t fifth = (mis >= (sh8 ? 1u : 2u)) ? 16u : 12u;              // ALIGNED: where the fifth word comes from
-	const uint32_t first_lo = first_byte - mis;
+	const uint32_t first_lo = (which ? ref1_off[pu] : ref0_off[pu]) + (uint32_t)(-by) * step_ref + (uint32_t)col0;
 	const uint32_t end_lo = first_lo + (uint32_t)last_row * step_ref;
 	const uint32_t lo_b = min(first_lo, end_lo), hi_b = max(first_lo, end_lo);
 	uint32_t off = first_lo;
 	uint32_t out_off = dst_off[pu] + (uint32_t)(8 * j + 4 * which);
 
-	constexpr int NW = ALIGNED ? 5 : 4;
-	auto issue = [&](uint32_t (&d)[NW])
+	auto issue = [&](uint32_t (&d)[4])
 	{
-		if constexpr (ALIGNED)
-		{
-			const u32x4 a = *reinterpret_cast<const u32x4_w *>(ref + (size_t)off);
-			d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-			d[4] = *reinterpret_cast<const uint32_t *>(ref + (size_t)(off + fifth));
-		}
-		else
-		{
-			const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
-			d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-		}
+		const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
+		d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
 		off = med3_u32(off + step_ref, lo_b, hi_b);
 	};
 	// 8 horizontal sums of one window row
-	auto hrow = [&](const uint32_t (&d)[NW], int (&h)[8])
+	auto hrow = [&](const uint32_t (&d)[4], int (&h)[8])
 	{
+		// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
 		const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
-		const uint32_t e2 = ((ALIGNED && sh8) ? d[NW - 1] : d[2]) ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
-		const uint32_t e4 = ALIGNED ? d[NW - 1] ^ 0x80808080u : 0x80808080u;
+		const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
 		const uint32_t x0 = __builtin_amdgcn_alignbyte(e1, e0, hsh), x1 = __builtin_amdgcn_alignbyte(e2, e1, hsh);
-		const uint32_t x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh), x3 = __builtin_amdgcn_alignbyte(e4, e3, hsh);
+		const uint32_t x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh), x3 = __builtin_amdgcn_alignbyte(0x80808080u, e3, hsh);
 		uint32_t g[12];
 		g[0] = x0; g[4] = x1; g[8] = x2;
 #pragma unroll
@@ -1018,9 +1002,9 @@ __global__ __launch_bounds__(kThreads, 4) void pred_hfirst_bi8_kernel(
 	};
 
 	uint32_t P[4][8];             // P[m][c]: sums of (row 2 (i + m'), row 2 (i + m') + 1), column c
-	uint32_t ring[AHEAD][NW];     // window rows 8 + ... in flight
+	uint32_t ring[AHEAD][4];      // window rows 8 + ... in flight
 	{
-		uint32_t first8[8][NW];
+		uint32_t first8[8][4];
 #pragma unroll
 		for (int r = 0; r < 8; ++r) issue(first8[r]);
 #pragma unroll
@@ -1105,12 +1089,9 @@ static bool hfirst_bi_applies(int W, int H)
 static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr, const uint32_t *dof, const uint32_t *r0, const uint32_t *r1,
 		const uint8_t *f0, const uint8_t *f1, int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
 {
-	static const bool want_aligned = getenv("HEVCASM_PRED_HFIRST_ALIGNED") != nullptr;      // measurement switch (the word-aligned form lost: profiles/r04_pred_hfirst_bi_ab.txt)
 	const int strips = W / 8, ppw = kWave / (2 * strips);
 	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
-	const bool aligned = want_aligned && sr % 4 == 0;          // a lane's alignment must be the same on every row
-	if (aligned) hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, true>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
-	else hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, false>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
+	hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
 	return launch_status("pred_hfirst_bi8_kernel");
 }
 
