@@ -901,11 +901,11 @@ def test_pred_strip_segments_keep_every_row():
 
 
 def test_pred_bi_hfirst_kernel_sizes_and_edges():
-    """Round 4: luma bi-prediction of 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (a lane per strip and reference, horizontal pass first).  Every
+    """Round 4: luma bi-prediction of 8-, 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (a lane per strip and reference, horizontal pass first).  Every
     height it takes (standard and not), batches that leave spare lanes and a partial last wave, bottom-up planes, the rails (all-0 / all-255 planes: the
     14-bit intermediates wrap) and every fraction pair including zero fractions on either reference."""
     from hevcasm_amd import workload as wl
-    for w in (16, 32):
+    for w in (8, 16, 32):
         for h in (16, 24, 32, 40, 48, 64):
             for n in (1, 37):
                 c = wl.pred_case(8, w, h, n, 9100 + w + h + n, bi=True, frame=(4 * w, 2 * h))
@@ -916,13 +916,18 @@ def test_pred_bi_hfirst_kernel_sizes_and_edges():
     c = cases._wrap14(wl.pred_case(8, 32, 32, 7, 9350, bi=True, frame=(64, 64), fracs=(2, 2)))
     cases.assert_same("hfirst bi wrap 32x32", cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
     # plane strides that are not a multiple of 4 (the byte-aligned form of the kernel) and plane bases at every byte alignment (the word-aligned form's shifts)
-    c = wl.pred_case(8, 16, 32, 23, 9360, bi=True, frame=(66, 64))
-    assert c["stride_ref"] % 4 == 2
-    cases.assert_same("hfirst bi odd stride", cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    for w in (8, 16):
+        c = wl.pred_case(8, w, 32, 23, 9360 + w, bi=True, frame=(66, 64))
+        assert c["stride_ref"] % 4 == 2
+        cases.assert_same("hfirst bi odd stride %d" % w, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    for fx in (0, 1):            # 8-wide: the second load of a row ends with the window (filtered) or repeats the first (not filtered)
+        for fy in (0, 2):
+            c = wl.pred_case(8, 8, 16, 45, 9380 + 2 * fx + fy, bi=True, frame=(32, 32), fracs=(fx, fy))
+            cases.assert_same("hfirst bi 8-wide fractions %d %d" % (fx, fy), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
     import torch
     from hevcasm_amd import batch as B
     for k in (1, 2, 3):
-        c = wl.pred_case(8, 16 * (1 + k % 2), 16, 29, 9370 + k, bi=True, frame=(128, 32))
+        c = wl.pred_case(8, (8, 16, 32)[k - 1], 16, 29, 9370 + k, bi=True, frame=(128, 32))
         shifted = [torch.from_numpy(np.concatenate([np.zeros(s, np.uint8), c["ref%d" % r]])).cuda()[s:] for r, s in ((0, k), (1, (k + 1) % 4))]
         d = B.pred_bi(torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda"), c["stride_dst"], shifted[0], shifted[1], c["stride_ref"], B.off32(c["dst_off"]), B.off32(c["ref0_off"]),
                       B.off32(c["ref1_off"]), B.u8(c["frac0"]), B.u8(c["frac1"]), 8, c["w"], c["h"])
