@@ -913,7 +913,7 @@ __device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
 }
 __device__ __forceinline__ int swap_pair_lane(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false); }
 
-template <int AHEAD, bool W8>
+template <int AHEAD>
 __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
@@ -961,15 +961,12 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	const uint32_t O0 = pair16(0, v[0]), O1 = pair16(v[1], v[2]), O2 = pair16(v[3], v[4]), O3 = pair16(v[5], v[6]), O4 = pair16(v[7], 0);
 
 	// the strip's 16 window bytes as ONE load, moved left where it would pass the window's end (the PU's last strip: by one byte where xFrac filters,
-	// by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide).  W8: an 8-wide PU's window is 15 (or 8)
-	// bytes, one short of the load: two 8-byte loads instead, the second one ending with the window (one byte back where xFrac filters -- shifted back
-	// in registers -- and the first one again where it does not: those bytes only meet zero taps)
+	// by eight where it does not) and shifted back in registers (W >= 16: the window is at least 16 bytes wide)
 	const int col_nat = 8 * j - bx;
-	const int col0 = W8 ? col_nat : min(col_nat, W + ax - 16);
-	const uint32_t sh_bytes = W8 ? (uint32_t)(col_nat + 8 - min(col_nat + 8, W + ax - 8)) : (uint32_t)(col_nat - col0);      // W8: how far the second load moves left: 1 or 8
-	const bool sh8 = !W8 && sh_bytes >= 8u;
+	const int col0 = min(col_nat, W + ax - 16);
+	const uint32_t sh_bytes = (uint32_t)(col_nat - col0);                       // 0, 1 or 8
+	const bool sh8 = sh_bytes >= 8u;
 	const uint32_t hsh = sh_bytes & 3u;
-	const uint32_t d_hi = 8u - sh_bytes;                                        // W8: the second load's distance from the first
 	const int last_row = H + ay + by - 1;                                       // last stream row the reference reads (stream row 0 = PU row -by)
 	const uint32_t first_lo = (which ? ref1_off[pu] : ref0_off[pu]) + (uint32_t)(-by) * step_ref + (uint32_t)col0;
 	const uint32_t end_lo = first_lo + (uint32_t)last_row * step_ref;
@@ -979,38 +976,18 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 
 	auto issue = [&](uint32_t (&d)[4])
 	{
-		if constexpr (W8)
-		{
-			const u32x2 a = reinterpret_cast<const U2 *>(ref + (size_t)off)->v;
-			const u32x2 b = reinterpret_cast<const U2 *>(ref + (size_t)(off + d_hi))->v;
-			d[0] = a.x; d[1] = a.y; d[2] = b.x; d[3] = b.y;
-		}
-		else
-		{
-			const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
-			d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
-		}
+		const u32x4 a = reinterpret_cast<const U4 *>(ref + (size_t)off)->v;
+		d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w;
 		off = med3_u32(off + step_ref, lo_b, hi_b);
 	};
 	// 8 horizontal sums of one window row
 	auto hrow = [&](const uint32_t (&d)[4], int (&h)[8])
 	{
-		uint32_t x0, x1, x2, x3;
-		if constexpr (W8)
-		{
-			// the second load's bytes shifted back to where they belong
-			x0 = d[0] ^ 0x80808080u; x1 = d[1] ^ 0x80808080u;
-			const uint32_t y2 = d[2] ^ 0x80808080u, y3 = d[3] ^ 0x80808080u;
-			x2 = __builtin_amdgcn_alignbyte(y3, y2, hsh); x3 = __builtin_amdgcn_alignbyte(0x80808080u, y3, hsh);
-		}
-		else
-		{
-			// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
-			const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
-			const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
-			x0 = __builtin_amdgcn_alignbyte(e1, e0, hsh); x1 = __builtin_amdgcn_alignbyte(e2, e1, hsh);
-			x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh); x3 = __builtin_amdgcn_alignbyte(0x80808080u, e3, hsh);
-		}
+		// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
+		const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
+		const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
+		const uint32_t x0 = __builtin_amdgcn_alignbyte(e1, e0, hsh), x1 = __builtin_amdgcn_alignbyte(e2, e1, hsh);
+		const uint32_t x2 = __builtin_amdgcn_alignbyte(e3, e2, hsh), x3 = __builtin_amdgcn_alignbyte(0x80808080u, e3, hsh);
 		uint32_t g[12];
 		g[0] = x0; g[4] = x1; g[8] = x2;
 #pragma unroll
@@ -1105,9 +1082,8 @@ static bool hfirst_bi_applies(int W, int H)
 {
 	static const bool off = getenv("HEVCASM_PRED_NOHFIRST_BI") != nullptr;      // measurement switches, read once per process
 	static const bool all = getenv("HEVCASM_PRED_HFIRST_BI_ALL") != nullptr;    // every size the kernel can take
-	static const bool no8 = getenv("HEVCASM_PRED_HFIRST_BI_NO8") != nullptr;
-	if (off || W % 8 || H % 8 || W > 64) return false;
-	return all || (W == 8 && H >= 16 && !no8) || (W == 16 && H >= 16) || (W == 32 && H >= 24);
+	if (off || W % 8 || H % 8 || W < 16 || W > 64) return false;
+	return all || (W == 16 && H >= 16) || (W == 32 && H >= 24);
 }
 
 static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr, const uint32_t *dof, const uint32_t *r0, const uint32_t *r1,
@@ -1115,8 +1091,7 @@ static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref
 {
 	const int strips = W / 8, ppw = kWave / (2 * strips);
 	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
-	if (W == 8) hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, true>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
-	else hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, false>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
+	hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
 	return launch_status("pred_hfirst_bi8_kernel");
 }
 

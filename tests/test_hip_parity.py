@@ -901,7 +901,8 @@ def test_pred_strip_segments_keep_every_row():
 
 
 def test_pred_bi_hfirst_kernel_sizes_and_edges():
-    """Round 4: luma bi-prediction of 8-, 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (a lane per strip and reference, horizontal pass first).  Every
+    """Round 4: luma bi-prediction of 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (8-wide ones stay on the stream kernel: an 8-wide form was measured and lost;
+    its cases stay here) (a lane per strip and reference, horizontal pass first).  Every
     height it takes (standard and not), batches that leave spare lanes and a partial last wave, bottom-up planes, the rails (all-0 / all-255 planes: the
     14-bit intermediates wrap) and every fraction pair including zero fractions on either reference."""
     from hevcasm_amd import workload as wl
@@ -920,7 +921,7 @@ def test_pred_bi_hfirst_kernel_sizes_and_edges():
         c = wl.pred_case(8, w, 32, 23, 9360 + w, bi=True, frame=(66, 64))
         assert c["stride_ref"] % 4 == 2
         cases.assert_same("hfirst bi odd stride %d" % w, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
-    for fx in (0, 1):            # 8-wide: the second load of a row ends with the window (filtered) or repeats the first (not filtered)
+    for fx in (0, 1):            # 8-wide PUs, filtered and unfiltered columns
         for fy in (0, 2):
             c = wl.pred_case(8, 8, 16, 45, 9380 + 2 * fx + fy, bi=True, frame=(32, 32), fracs=(fx, fy))
             cases.assert_same("hfirst bi 8-wide fractions %d %d" % (fx, fy), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
