@@ -901,8 +901,9 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 // Luma bi-prediction is the one prediction kernel that the VALU bounds (74-83 % busy, 1.15-1.35 x the time of its access pattern alone,
 // profiles/r04_pred_access_mix.txt).  This form spends fewer vector instructions: a lane owns a strip of 8 output columns OF ONE REFERENCE, loads the strip's
 // 16 window bytes itself (one load per row), filters horizontally in the byte domain (v_dot4_i32_i8 on pixel - 128), keeps the 14-bit sums as int16 row
-// pairs and filters vertically with v_dot2_i32_i16 over the pairs; the two lanes of a strip (neighbours) then swap halves of their 14-bit intermediates
-// (quad_perm DPP) and each rounds, clips and stores 4 pixels.  Arithmetic = the reference's (pred_inter.c:490-530): per reference (sum >> 6) stored as
+// pairs and filters vertically with v_dot2_i32_i16 over the pairs; the two lanes of a strip then swap halves of their 14-bit intermediates (quad_perm DPP or
+// ds_swizzle: a PU's lanes are its strips of reference 0, then those of reference 1 -- neighbouring lanes read neighbouring bytes; 32-wide -3 % against the
+// interleaved deal) and each rounds, clips and stores 4 pixels.  Arithmetic = the reference's (pred_inter.c:490-530): per reference (sum >> 6) stored as
 // int16 (it wraps: trunc16_shr6), then (a + b + 64) >> 7 clipped.  Footprints = the reference's, as in pred_stream_kernel (window rows and bytes clamped).
 __device__ __forceinline__ int sdot4(uint32_t a, uint32_t b, int c) { return __builtin_amdgcn_sdot4((int)a, (int)b, c, false); }
 __device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
@@ -912,8 +913,15 @@ __device__ __forceinline__ int sdot4_first(uint32_t a, uint32_t b, int k)
 	return r;
 }
 __device__ __forceinline__ int swap_pair_lane(int v) { return __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false); }
+// the value of the lane that filters the same strip of the other reference: lane ^ 1 (interleaved deal) or lane ^ S (blocked deal)
+template <int BLOCKED> __device__ __forceinline__ int partner_lane(int v)
+{
+	if constexpr (BLOCKED == 0) return swap_pair_lane(v);
+	else if constexpr (BLOCKED == 2) return __builtin_amdgcn_mov_dpp(v, 0x4e /* quad_perm [2, 3, 0, 1] */, 0xf, 0xf, false);
+	else return __builtin_amdgcn_ds_swizzle(v, 0x1f | (BLOCKED << 10) /* bit-mask mode: lane ^ BLOCKED */);
+}
 
-template <int AHEAD>
+template <int AHEAD, int BLOCKED /* 0: the two references of a strip in neighbouring lanes; else S: a PU's strips of reference 0, then those of reference 1 */>
 __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst, const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
@@ -930,9 +938,21 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63;
-	const int which = lane & 1;                   // the reference this lane filters; it stores columns 4 which .. 4 which + 3 of the strip
-	int sub = (lane >> 1) / S;
-	int j = (lane >> 1) - sub * S;
+	// which: the reference this lane filters; it stores columns 4 which .. 4 which + 3 of the strip
+	int which, sub, j;
+	if constexpr (BLOCKED)
+	{
+		sub = lane / (2 * BLOCKED);
+		const int q = lane - sub * (2 * BLOCKED);
+		which = q / BLOCKED;
+		j = q - which * BLOCKED;
+	}
+	else
+	{
+		which = lane & 1;
+		sub = (lane >> 1) / S;
+		j = (lane >> 1) - sub * S;
+	}
 	const bool spare = sub >= PPW;
 	if (spare) { sub = PPW - 1; j = 0; }
 	uint32_t pu = wave * (uint32_t)PPW + (uint32_t)sub;
@@ -1029,7 +1049,7 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 		{
 			const int lo = trunc16_shr6(t[k]), hi = trunc16_shr6(t[4 + k]);
 			const int keep = which ? hi : lo, send = which ? lo : hi;          // the partner stores the other four columns
-			mine[k] = keep + swap_pair_lane(send) + 64;
+			mine[k] = keep + partner_lane<BLOCKED>(send) + 64;
 		}
 		const uint32_t a0 = __builtin_amdgcn_ashr_pk_u8_i32(mine[0], mine[1], 7), a1 = __builtin_amdgcn_ashr_pk_u8_i32(mine[2], mine[3], 7);
 		const uint32_t px = __builtin_amdgcn_perm(a1, a0, 0x05040100);
@@ -1089,9 +1109,15 @@ static bool hfirst_bi_applies(int W, int H)
 static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr, const uint32_t *dof, const uint32_t *r0, const uint32_t *r1,
 		const uint8_t *f0, const uint8_t *f1, int W, int H, size_t n, hipStream_t st, const Planes2 &p2)
 {
+	static const bool interleaved = getenv("HEVCASM_PRED_HFIRST_INTERLEAVED") != nullptr;      // measurement switch, read once per process
 	const int strips = W / 8, ppw = kWave / (2 * strips);
 	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
-	hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1);
+#define HFIRST_BI(B) hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, B>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
+	if (interleaved || (strips != 2 && strips != 4 && strips != 8)) HFIRST_BI(0);
+	else if (strips == 2) HFIRST_BI(2);
+	else if (strips == 4) HFIRST_BI(4);
+	else HFIRST_BI(8);
+#undef HFIRST_BI
 	return launch_status("pred_hfirst_bi8_kernel");
 }
 
