@@ -928,7 +928,7 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
 	int W, int H, int S /* strips per PU = W / 8 */, int PPW /* PUs per wave */, uint32_t n_blocks, ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
 {
-	static_assert(AHEAD == 8, "the ring turns once per unrolled group of 8 rows");
+	static_assert(AHEAD == 8 || AHEAD == 4, "the ring turns a whole number of times per unrolled group of 8 rows");
 	if (blockIdx.y)
 	{
 		dst += plane2_dst;
@@ -1091,13 +1091,19 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 #pragma unroll
 		for (int ii = 0; ii < 4; ++ii) two_rows(Flag<true>(), ii);
 	}
-#pragma unroll
-	for (int ii = 0; ii < 4; ++ii) two_rows(Flag<false>(), ii);
+	// the last group: the rows the ring does not hold yet (none with 8 rows ahead)
+	two_rows(Flag<(AHEAD < 8)>(), 0);
+	two_rows(Flag<(AHEAD < 6)>(), 1);
+	two_rows(Flag<false>(), 2);
+	two_rows(Flag<false>(), 3);
 }
 
 // Where it pays (same binary, 64 frames of 1080p per launch, profiles/r04_pred_hfirst_bi_ab.txt): 16-wide PUs of 16 rows and more -5 ... -9 %, 32-wide of 24 and
 // more -3 ... -7 %.  Short PUs lose (the first 8 rows are filtered before the first output row: 32x8 +19 %, 16x8 +5 %, 32x16 +4 %), 64-wide lose
 // +4 ... +18 % (16 lanes to a PU row and 2 bytes loaded per pixel where the stream kernel's 9 lanes load 1.1), 24- / 48-wide +9 % / -1 %.
+#ifndef HEVCASM_HFIRST_AHEAD
+#define HEVCASM_HFIRST_AHEAD 8
+#endif
 static bool hfirst_bi_applies(int W, int H)
 {
 	static const bool off = getenv("HEVCASM_PRED_NOHFIRST_BI") != nullptr;      // measurement switches, read once per process
@@ -1112,7 +1118,7 @@ static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref
 	static const bool interleaved = getenv("HEVCASM_PRED_HFIRST_INTERLEAVED") != nullptr;      // measurement switch, read once per process
 	const int strips = W / 8, ppw = kWave / (2 * strips);
 	const uint32_t grid = ceil_div(ceil_div(n, (size_t)ppw), (size_t)(kThreads / kWave));
-#define HFIRST_BI(B) hipLaunchKernelGGL((pred_hfirst_bi8_kernel<8, B>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
+#define HFIRST_BI(B) hipLaunchKernelGGL((pred_hfirst_bi8_kernel<HEVCASM_HFIRST_AHEAD, B>), dim3(grid, p2.count), dim3(kThreads), 0, st, dst, sd, ref0, ref1, sr, dof, r0, r1, f0, f1, W, H, strips, ppw, (uint32_t)n, p2.dst, p2.ref0, p2.ref1)
 	if (interleaved || (strips != 2 && strips != 4 && strips != 8)) HFIRST_BI(0);
 	else if (strips == 2) HFIRST_BI(2);
 	else if (strips == 4) HFIRST_BI(4);
