@@ -1099,8 +1099,9 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 }
 
 // Where it pays (same binary, 64 frames of 1080p per launch, profiles/r04_pred_hfirst_bi_ab.txt): 16-wide PUs of 16 rows and more -5 ... -9 %, 32-wide of 24 and
-// more -3 ... -7 %.  Short PUs lose (the first 8 rows are filtered before the first output row: 32x8 +19 %, 16x8 +5 %, 32x16 +4 %), 64-wide lose
-// +4 ... +18 % (16 lanes to a PU row and 2 bytes loaded per pixel where the stream kernel's 9 lanes load 1.1), 24- / 48-wide +9 % / -1 %.
+// more -3 ... -7 %, 64x64 -2 % (-7 % at 256 frames per launch).  Short PUs lose (the first 8 rows are filtered before the first output row: 32x8 +19 %,
+// 16x8 +5 %, 32x16 +4 %), 64-wide ones of fewer than 64 rows +5 ... +14 % (16 lanes to a PU row and 2 bytes loaded per pixel where the stream kernel's 9 lanes
+// load 1.1), 24- / 48-wide +9 % / +-0.
 #ifndef HEVCASM_HFIRST_AHEAD
 #define HEVCASM_HFIRST_AHEAD 8
 #endif
@@ -1109,7 +1110,7 @@ static bool hfirst_bi_applies(int W, int H)
 	static const bool off = getenv("HEVCASM_PRED_NOHFIRST_BI") != nullptr;      // measurement switches, read once per process
 	static const bool all = getenv("HEVCASM_PRED_HFIRST_BI_ALL") != nullptr;    // every size the kernel can take
 	if (off || W % 8 || H % 8 || W < 16 || W > 64) return false;
-	return all || (W == 16 && H >= 16) || (W == 32 && H >= 24);
+	return all || (W == 16 && H >= 16) || (W == 32 && H >= 24) || (W == 64 && H >= 64);
 }
 
 static int launch_pred_hfirst_bi8(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr, const uint32_t *dof, const uint32_t *r0, const uint32_t *r1,

@@ -901,7 +901,7 @@ def test_pred_strip_segments_keep_every_row():
 
 
 def test_pred_bi_hfirst_kernel_sizes_and_edges():
-    """Round 4: luma bi-prediction of 16- and 32-wide PUs runs pred_hfirst_bi8_kernel (8-wide ones stay on the stream kernel: an 8-wide form was measured and lost;
+    """Round 4: luma bi-prediction of 16- and 32-wide PUs and of 64x64 runs pred_hfirst_bi8_kernel (8-wide ones stay on the stream kernel: an 8-wide form was measured and lost;
     its cases stay here) (a lane per strip and reference, horizontal pass first).  Every
     height it takes (standard and not), batches that leave spare lanes and a partial last wave, bottom-up planes, the rails (all-0 / all-255 planes: the
     14-bit intermediates wrap) and every fraction pair including zero fractions on either reference."""
@@ -911,6 +911,9 @@ def test_pred_bi_hfirst_kernel_sizes_and_edges():
             for n in (1, 37):
                 c = wl.pred_case(8, w, h, n, 9100 + w + h + n, bi=True, frame=(4 * w, 2 * h))
                 cases.assert_same("hfirst bi %dx%d n=%d" % (w, h, n), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
+    for n in (1, 9):                 # 64x64: 16 lanes to a PU, 4 PUs to a wave
+        c = wl.pred_case(8, 64, 64, n, 9250 + n, bi=True, frame=(192, 128))
+        cases.assert_same("hfirst bi 64x64 n=%d" % n, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
     for kind in ("zeros", "max"):
         c = wl.pred_case(8, 16, 16, 50, 9300, bi=True, frame=(64, 32), kind=kind)
         cases.assert_same("hfirst bi rails " + kind, cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
