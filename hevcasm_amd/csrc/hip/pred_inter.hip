@@ -894,9 +894,10 @@ static int launch_pred_strip4(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, c
 // pass on v_dot2_i32_i16 over the pairs; no cross-lane traffic, no idle lane.  Bit-exact (every GPU prediction test, footprints included), 22 % fewer vector
 // instructions at 64x64 (11.2 lane-operations per pixel against 14.4) -- and 4 % SLOWER (geometric mean over the PU sizes it serves; 14 % with two 8-byte
 // loads per lane instead of one of 16): the same vector-L1 accesses (an unaligned lane load is charged by the bytes asked for), a third more HBM traffic, more
-// time waiting.  The stream kernel is not bound by its instruction count.  profiles/r04_pred_hfirst_ab.txt; source: commit cf83a19.
+// time waiting.  The stream kernel is not bound by its instruction count but by its access pattern (profiles/r04_pred_access_mix.txt: its loads and stores
+// alone take the kernel's time).  profiles/r04_pred_hfirst_ab.txt; source: commit cf83a19.
 
-// ---- 8-tap bi-prediction, horizontal pass first, one lane per (8-column strip, reference) (round 4: 16- and 32-wide PUs) ------------------
+// ---- 8-tap bi-prediction, horizontal pass first, one lane per (8-column strip, reference) (round 4: 16- / 32-wide PUs, 64x64) --------------
 //
 // Luma bi-prediction is the one prediction kernel that the VALU bounds (74-83 % busy, 1.15-1.35 x the time of its access pattern alone,
 // profiles/r04_pred_access_mix.txt).  This form spends fewer vector instructions: a lane owns a strip of 8 output columns OF ONE REFERENCE, loads the strip's
