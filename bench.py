@@ -520,6 +520,11 @@ def main():
             per_family.insert(0, dict(family="sad", kernel="sad 16x16 single-ref", config="#2, inside the timed region", ms=head["ms_per_pass"], mblocks_per_s=head["mblocks_per_s"],
                                       gbs=head["algorithmic_gb_per_s"], frac=head["frac_of_hbm_peak"], bytes_per_block=head["bytes_per_block"]))
         flat = flatten_families(per_family)
+        if per_family is not None:
+            for key, ms in pred_pattern_ms().items():     # the prediction rows against their access pattern alone, same box, same run
+                if flat.get(key + "_ms"):
+                    flat[key + "_pattern_ms"] = round(ms, 4)
+                    flat[key + "_vs_pattern"] = round(flat[key + "_ms"] / ms, 3)
         if cpu:   # GPU rate over the CPU legs of the same family (Mblocks/s both)
             for key, _ in CPU_FAMILY_CASES:
                 g = flat.get(key + "_mblocks")
@@ -589,6 +594,31 @@ def qsad_peak():
             return float(json.load(f)["v_qsad_pk_u16_u8_tera_byte_differences_per_s"]), "measured: tools/ubench/qsad_rate.hip, profiles/r03_qsad_rate.txt"
     except (OSError, ValueError, KeyError):
         return NOMINAL_QSAD_TBYTEDIFFS, "nominal quarter rate: 16 byte differences per lane per 16 cycles, 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz"
+
+
+PATTERN_KEYS = {"luma16_uni": "pred_uni_luma16", "luma16_bi": "pred_bi_luma16", "chroma8_uni": "pred_uni_chroma8", "chroma8_bi": "pred_bi_chroma8"}
+
+
+def pred_pattern_ms():
+    """{family key: ms} -- the loads and stores of the four 64-frame prediction rows WITHOUT arithmetic (hevcasm_amd/lib/ubench_pred_mix live =
+    tools/ubench/pred_mix.hip: same PU tiling, one motion vector per PU, cold buffers), run NOW on this box.  The prediction kernels take about the time
+    of their access pattern alone (profiles/r04_pred_access_mix.txt): <key>_pattern_ms / <key>_vs_pattern put that next to every HBM fraction.
+    {} when the probe is absent or fails (the figures are a comment on the measurement, never part of it)."""
+    import subprocess
+    try:
+        from hevcasm_amd import capi
+        exe = os.path.join(os.path.dirname(capi.LIB_PATH), "ubench_pred_mix")
+        out = subprocess.run([exe, "live"], capture_output=True, text=True, timeout=120)
+        if out.returncode != 0:
+            return {}
+        got = {}
+        for l in out.stdout.splitlines():
+            name, _, v = l.partition(" ")
+            if name in PATTERN_KEYS and 0.0 < float(v) < 100.0:
+                got[PATTERN_KEYS[name]] = float(v)
+        return got
+    except Exception:   # noqa: BLE001 -- no probe, no GPU, nonsense output
+        return {}
 
 
 def measure_families():

@@ -45,6 +45,15 @@ def test_qsad_roof_is_the_measured_one():
     assert 0.75 < peak / bench.NOMINAL_QSAD_TBYTEDIFFS < 1.05      # 17.2 cycles per instruction against the nominal 16, at the box's clock
 
 
+def test_pattern_probe_is_a_comment_on_the_measurement():
+    """bench.pred_pattern_ms(): the prediction rows' access patterns without arithmetic, measured by a child process on a GPU box; without a GPU (here) or
+    without the probe it is empty and the line goes out without those keys.  Its keys name rows the flattened record has."""
+    got = bench.pred_pattern_ms()
+    assert isinstance(got, dict) and all(isinstance(v, float) and v > 0 for v in got.values())
+    assert set(bench.PATTERN_KEYS.values()) <= set(bench.FAMILY_KEYS.values())
+    assert os.path.exists(os.path.join(ROOT, "hevcasm_amd", "lib", "ubench_pred_mix")), "built by hevcasm_amd/csrc/Makefile (__graft_entry__.build())"
+
+
 def test_gather_without_a_process_group_is_the_identity():
     res = np.arange(3 * 6, dtype=np.int32).reshape(6, 3)
     table = bench.gather_me_results((0, 2, res), 3 * 64, 2 * 64, 64)

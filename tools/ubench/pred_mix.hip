@@ -85,12 +85,14 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; put(dst + dof, o, SB); }
 }
 
-template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int frames, int mode, uint8_t *dst, const uint8_t *ref, int coherent = 0, Geo g = kLuma)
+static bool g_quiet = false;
+static int g_max_frames = 256;
+template <int D, int LB, bool ALIGNED, int REFS = 1> float run(int W, int H, int frames, int mode, uint8_t *dst, const uint8_t *ref, int coherent = 0, Geo g = kLuma)
 {
 	const int FW = g.FW, FH = g.FH, RS = g.RS, RH = g.RH, pitch = g.pitch ? g.pitch : LB, SB = g.store_bytes ? g.store_bytes : LB;
 	const int per_row = FW / W, per_frame = per_row * (FH / H);
 	const uint32_t n = (uint32_t)per_frame * frames;
-	if (W % SB) return;
+	if (W % SB) return 0.f;
 	const int L = g.pitch ? W / pitch : (W + g.margin + LB - 1) / LB, ppw = 64 / L;
 	const uint32_t waves = (n + ppw - 1) / ppw, grid = (waves + 3) / 4;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -100,7 +102,7 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int 
 		// a different third of the buffers each time: nothing comes from the Infinity Cache
 		const size_t shift_f = (size_t)(rep % 3) * frames;
 		hipEventRecord(e0);
-		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * (g.DS ? g.DS : FW), ref + shift_f * RH * RS, ref + (shift_f + 3 * 256) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent, g);
+		mix<D, LB, ALIGNED, REFS><<<grid, 256>>>(dst + shift_f * FH * (g.DS ? g.DS : FW), ref + shift_f * RH * RS, ref + (shift_f + 3 * (size_t)g_max_frames) * RH * RS, W, H, L, ppw, n, per_row, per_frame, mode, coherent, g);
 		hipEventRecord(e1); hipDeviceSynchronize();
 		float t; hipEventElapsedTime(&t, e0, e1);
 		if (rep) ms.push_back(t);
@@ -109,17 +111,32 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> void run(int W, int H, int 
 	for (float t : ms) { best = t < best ? t : best; sum += t; }
 	const double ld = (double)(W + g.margin) * (H + g.margin), st = (double)W * H;
 	const double bytes = (mode == 0 ? REFS * ld + st : mode == 1 ? REFS * ld : st) * n;
+	if (!g_quiet)
 	printf("%s %2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", g.margin == 7 ? "luma  " : g.pitch ? "chroma (strip deal)" : "chroma (stream deal)", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
 			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
+	return sum / ms.size();
 }
 
 int main(int argc, char **argv)
 {
-	const int max_frames = 256;
+	const int max_frames = (argc > 1 && argv[1][0] == 'l') ? 64 : 256;
+	g_max_frames = max_frames;
 	uint8_t *dst, *ref;
 	if (hipMalloc(&dst, (size_t)3 * max_frames * kLuma.FH * kLuma.FW + 4096) || hipMalloc(&ref, (size_t)6 * max_frames * kLuma.RH * 2304 + 65536)) { printf("alloc failed\n"); return 1; }
 	hipMemset(ref, 3, (size_t)6 * max_frames * kLuma.RH * kLuma.RS);
 	const int sizes[][2] = { { 16, 16 }, { 32, 32 }, { 64, 64 }, { 16, 64 }, { 64, 16 }, { 8, 8 } };
+	if (argc > 1 && argv[1][0] == 'l')
+	{
+		// bench.py's figures: the access patterns of its four 64-frame prediction rows WITHOUT arithmetic, on the box and in the run that measures the kernels
+		// (luma 16x16 uni / bi: the stream kernel's 8-byte byte-aligned lanes; chroma 8x8 Cb + Cr uni / bi: the strip kernel's word-aligned 16-byte lanes)
+		g_quiet = true;
+		Geo strip = kChroma; strip.pitch = 8; strip.store_bytes = 8;
+		printf("luma16_uni %.4f\n", run<8, 8, false>(16, 16, 64, 0, dst, ref));
+		printf("luma16_bi %.4f\n", run<8, 8, false, 2>(16, 16, 64, 0, dst, ref));
+		printf("chroma8_uni %.4f\n", run<4, 16, true>(8, 8, 128, 0, dst, ref, 0, strip));
+		printf("chroma8_bi %.4f\n", run<4, 16, true, 2>(8, 8, 128, 0, dst, ref, 0, strip));
+		return 0;
+	}
 	if (argc > 1 && argv[1][0] == 's')
 	{
 		// does the reference stride matter?  (the caller chooses it: integration advice if it does)
