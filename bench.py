@@ -596,26 +596,29 @@ def qsad_peak():
         return NOMINAL_QSAD_TBYTEDIFFS, "nominal quarter rate: 16 byte differences per lane per 16 cycles, 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz"
 
 
-PATTERN_KEYS = {"luma16_uni": "pred_uni_luma16", "luma16_bi": "pred_bi_luma16", "chroma8_uni": "pred_uni_chroma8", "chroma8_bi": "pred_bi_chroma8"}
+PATTERN_KEYS = {"luma16_uni": "pred_uni_luma16", "luma16_bi": "pred_bi_luma16", "chroma8_uni": "pred_uni_chroma8", "chroma8_bi": "pred_bi_chroma8",
+                "idct16_2p28": "idct16_2p28", "idct32_2p28": "idct32_2p28"}
+PATTERN_PROBES = ("ubench_pred_mix", "ubench_transform_mix")
 
 
 def pred_pattern_ms():
-    """{family key: ms} -- the loads and stores of the four 64-frame prediction rows WITHOUT arithmetic (hevcasm_amd/lib/ubench_pred_mix live =
-    tools/ubench/pred_mix.hip: same PU tiling, one motion vector per PU, cold buffers), run NOW on this box.  The prediction kernels take about the time
+    """{family key: ms} -- the loads and stores of the four 64-frame prediction rows and of the two 2^28-coefficient inverse-transform rows WITHOUT
+    arithmetic (hevcasm_amd/lib/ubench_pred_mix live, ubench_transform_mix live = tools/ubench/pred_mix.hip, transform_mix.hip: same tilings, one motion
+    vector per PU, cold buffers), run NOW on this box.  The prediction kernels take about the time
     of their access pattern alone (profiles/r04_pred_access_mix.txt): <key>_pattern_ms / <key>_vs_pattern put that next to every HBM fraction.
     {} when the probe is absent or fails (the figures are a comment on the measurement, never part of it)."""
     import subprocess
     try:
         from hevcasm_amd import capi
-        exe = os.path.join(os.path.dirname(capi.LIB_PATH), "ubench_pred_mix")
-        out = subprocess.run([exe, "live"], capture_output=True, text=True, timeout=120)
-        if out.returncode != 0:
-            return {}
         got = {}
-        for l in out.stdout.splitlines():
-            name, _, v = l.partition(" ")
-            if name in PATTERN_KEYS and 0.0 < float(v) < 100.0:
-                got[PATTERN_KEYS[name]] = float(v)
+        for probe in PATTERN_PROBES:
+            out = subprocess.run([os.path.join(os.path.dirname(capi.LIB_PATH), probe), "live"], capture_output=True, text=True, timeout=120)
+            if out.returncode != 0:
+                continue
+            for l in out.stdout.splitlines():
+                name, _, v = l.partition(" ")
+                if name in PATTERN_KEYS and 0.0 < float(v) < 100.0:
+                    got[PATTERN_KEYS[name]] = float(v)
         return got
     except Exception:   # noqa: BLE001 -- no probe, no GPU, nonsense output
         return {}

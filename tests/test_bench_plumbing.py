@@ -51,7 +51,8 @@ def test_pattern_probe_is_a_comment_on_the_measurement():
     got = bench.pred_pattern_ms()
     assert isinstance(got, dict) and all(isinstance(v, float) and v > 0 for v in got.values())
     assert set(bench.PATTERN_KEYS.values()) <= set(bench.FAMILY_KEYS.values())
-    assert os.path.exists(os.path.join(ROOT, "hevcasm_amd", "lib", "ubench_pred_mix")), "built by hevcasm_amd/csrc/Makefile (__graft_entry__.build())"
+    for probe in bench.PATTERN_PROBES:
+        assert os.path.exists(os.path.join(ROOT, "hevcasm_amd", "lib", probe)), "built by hevcasm_amd/csrc/Makefile (__graft_entry__.build())"
 
 
 def test_gather_without_a_process_group_is_the_identity():
