@@ -375,6 +375,9 @@ if __name__ == "__main__":
         if w.startswith("pred8wide") and w[9:].isdigit():  # luma, the 64- and 48-wide PU sizes, N frames per launch
             bench_pred(frames=int(w[9:]), taps_only=8, only=((64, 16), (64, 32), (64, 48), (64, 64), (48, 64)))
             continue
+        if w == "pred8odd":                               # luma, the 24- and 48-wide PU sizes (+ 32x32 as a yardstick)
+            bench_pred(taps_only=8, only=((24, 32), (48, 64), (32, 32)))
+            continue
         if w == "pred8w8":                                # luma, the 8-wide PU sizes
             bench_pred(taps_only=8, only=((8, 8), (8, 16), (8, 32), (8, 4)))
             continue
