@@ -352,6 +352,152 @@ def cpu_family_legs(budget_s, max_procs=16, sample_pus=8100):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------
+# The ONE line on stdout (a 26 kB line did not parse).  The line the driver reads is compact() of the full
+# record: < 4 kB, strict JSON, printed last and alone on the real stdout; the full record (detail, per_family, every flattened
+# key) goes to profiles/bench_last.json and nothing else may reach stdout (main() points fd 1 at stderr while it runs).
+
+HEADLINE_FAMILIES = ("sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "idct16", "idct32", "fused_idct32", "fdct32")
+PATTERN_HEADLINES = ("pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8")
+LINE_LIMIT = 4096
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "bytes_per_block",
+                 "me_valu_frac", "me_frame_ms", "frac_nominal", "hbm_frac", "per_family_error")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "simd_value", "simd_cores", "gpu_multiple", "checked_ctus", "mismatches", "simd_error", "family_error")
+CONFIG_KEYS = ("workload", "blocks_per_step_per_gpu", "launches_per_step", "parallelism", "frame", "step_ms_median", "step_ms_min", "library",
+               "me_split", "ctus_per_rank", "slowest_rank_ms", "rank0_kernel_ms", "frames_per_s", "gsad_evals_per_s")
+
+
+def _finite(v):
+    """Strict JSON has no NaN / Infinity: a non-finite number becomes null (recursively)."""
+    if isinstance(v, float):
+        return v if v == v and v not in (float("inf"), float("-inf")) else None
+    if isinstance(v, dict):
+        return {k: _finite(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_finite(x) for x in v]
+    if isinstance(v, (np.floating,)):
+        return _finite(float(v))
+    if isinstance(v, (np.integer,)):
+        return int(v)
+    return v
+
+
+def compact(full):
+    """The driver's line: the contract's top-level keys; config / roofline / cpu_baseline cut down to the scalars the record needs
+    (one _frac + _ms per headline family, the four _vs_pattern keys, one ref_ / simd_ pair per CPU family leg); strings <= 120."""
+    cut = lambda v: v[:120] if isinstance(v, str) else v
+    line = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                                 "dtype", "data", "valid") if k in full}
+    cfg = full.get("config") or {}
+    line["config"] = {k: cut(cfg[k]) for k in CONFIG_KEYS if k in cfg}
+    if cfg.get("env_switches"):
+        line["config"]["env_switches"] = ",".join(sorted(cfg["env_switches"]))[:120]
+    rf = full.get("roofline") or {}
+    out = {k: cut(rf[k]) for k in ROOFLINE_KEYS if k in rf and (rf[k] is not None or k in ("achieved", "peak", "frac", "traffic"))}
+    for fam in HEADLINE_FAMILIES:
+        for sfx in ("_frac", "_ms"):
+            if fam + sfx in rf:
+                out[fam + sfx] = rf[fam + sfx]
+    for fam in PATTERN_HEADLINES:
+        if fam + "_vs_pattern" in rf:
+            out[fam + "_vs_pattern"] = rf[fam + "_vs_pattern"]
+    line["roofline"] = out
+    cpu = full.get("cpu_baseline")
+    if cpu is None:
+        line["cpu_baseline"] = None
+    else:
+        c = {k: cut(cpu[k]) for k in CPU_KEYS if k in cpu and cpu[k] is not None or k in ("value", "unit", "cores", "kind") and k in cpu}
+        for key, _ in CPU_FAMILY_CASES:
+            for col in ("ref", "simd"):
+                k = "%s_%s_mblocks" % (col, key)
+                if k in cpu:
+                    c[k] = cpu[k]
+        line["cpu_baseline"] = c
+    line["full_record"] = full.get("full_record", "profiles/bench_last.json")
+    return _finite(line)
+
+
+def emit(full, out_fd=None, full_path=None):
+    """Write the full record beside the profiles and the compact line -- alone, last, newline-terminated -- to the real stdout."""
+    full = _finite(full)
+    full_path = full_path or os.path.join(ROOT, "profiles", "bench_last.json")
+    try:
+        with open(full_path, "w") as f:
+            json.dump(full, f, indent=1, allow_nan=False)
+            f.write("\n")
+        full["full_record"] = os.path.relpath(full_path, ROOT)
+    except OSError as e:       # a read-only tree must not cost the line
+        full["full_record"] = "not written: %s" % repr(e)[:80]
+    text = json.dumps(compact(full), allow_nan=False, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:      # never again a line the driver cannot read: drop the optional keys, keep the contract's
+        slim = compact(full)
+        slim["roofline"] = {k: v for k, v in slim["roofline"].items() if k in ROOFLINE_KEYS}
+        if slim.get("cpu_baseline"):
+            slim["cpu_baseline"] = {k: v for k, v in slim["cpu_baseline"].items() if k in CPU_KEYS}
+        text = json.dumps(slim, allow_nan=False, separators=(",", ":"))
+    assert len(text) < LINE_LIMIT and "\n" not in text
+    data = (text + "\n").encode()
+    if out_fd is None:
+        sys.stdout.flush()
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
+    else:
+        os.write(out_fd, data)
+    return text
+
+
+def plumbing_run(args):
+    """--plumbing: what a rank does around the measurement, without the measurement (no GPU is touched): join the gloo group, meet at the barrier,
+    take the max over ranks, and let rank 0 emit the record it was handed.  The record's numbers are the test's, never a measurement."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        dist.barrier()
+    slowest = max_over_ranks(1e-3 * (rank + 1), device="cpu")
+    if rank == 0:
+        with open(args.plumbing) as f:
+            full = json.load(f)
+        full.update(n_gpus=world, steps=args.steps, warmup=args.warmup, data="canned record (--plumbing): not a measurement")
+        full.setdefault("config", {})["slowest_rank_ms"] = round(slowest * 1e3, 3)
+        emit(full, args.out_fd, args.full_out or os.devnull)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def quiet_stdout():
+    """Point fd 1 at stderr for the rest of the process and return a descriptor of the REAL stdout: library printf()s, child probes and stray
+    print()s (tools/bench_families.py printed a JSON row of its own ahead of round 4's line) can then never precede or follow the result line."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+    return real
+
+
+def relaunch_as_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
+    (never exec: nothing here has touched the GPU, and a child is always safe), relay rank 0's one line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in p.stdout.splitlines():
+        if not lines or l != lines[-1]:
+            print(l, file=sys.stderr)
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return p.returncode if p.returncode or lines else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -365,10 +511,19 @@ def main():
     ap.add_argument("--no-families", action="store_true", help="skip the per-family measurements (inter prediction, transforms, full search) after the timed region")
     ap.add_argument("--me-split", default="ctus", choices=("rows", "ctus"), help="me5: ranks own raster runs of CTUs balanced to one CTU (default; each still holds whole CTU rows + halo), or whole CTU rows")
     ap.add_argument("--workload", default="sad", choices=("sad", "me5"), help="sad = BASELINE.json configs[1] (the metric's configuration); me5 = configs[4], full search sharded by CTU rows")
+    ap.add_argument("--plumbing", default=None, metavar="RECORD.json", help="TEST ONLY (tests/test_bench_plumbing.py): no GPU, no measurement -- the launcher / rank / "
+                    "barrier / emit path alone, emitting the given full record with n_gpus = the ranks that met")
+    ap.add_argument("--full-out", default=None, help="where the full record goes (default profiles/bench_last.json)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch_as_ranks(args, sys.argv[1:]))
+    args.out_fd = quiet_stdout()
     stale = sorted(k for k in os.environ if k.startswith("HEVCASM_") and k not in ("HEVCASM_BENCH_ONE_DEVICE", "HEVCASM_DIST_BACKEND"))
     if stale:
         print("bench.py: WARNING: %s set in the environment -- the measurement is not of the default library configuration (recorded in config.env_switches)" % ", ".join(stale), file=sys.stderr)
+        print("bench.py: (printed with a bare print(): fd 1 is stderr until the result line)")
+    if args.plumbing:
+        return plumbing_run(args)
 
     import torch
     import torch.distributed as dist
@@ -378,8 +533,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: measuring the %d ranks the launcher started" % (args.gpus, world, world), file=sys.stderr)
     # one process per GPU.  HEVCASM_BENCH_ONE_DEVICE=1 + HEVCASM_DIST_BACKEND=gloo is a rehearsal mode for
     # boxes with a single GPU (all ranks share cuda:0); the real multi-GPU run uses RCCL ("nccl").
     if os.environ.get("HEVCASM_BENCH_ONE_DEVICE"):
@@ -559,7 +713,7 @@ def main():
             "cpu_baseline": cpu,
             "detail": detail, "per_family": per_family,
         }
-        print(json.dumps(line))
+        emit(line, args.out_fd, args.full_out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -652,8 +806,8 @@ def measure_families():
     collect("#4, 2^26 coefficients per launch", lambda r: "idct" if "inverse" in r["kernel"] else "fdct")
     fam.bench_transform(1 << 28, only=((0, 4), (0, 5)))       # the same kernels nearer their steady state: a 60 us launch pays 10-13 us of ramp-up and tail
     collect("#4, 2^28 coefficients per launch", lambda r: "idct_large_launch" if "inverse" in r["kernel"] else "fdct_large_launch")
+    me = fam.bench_me_frame(quiet=True)
     fam.SINK = None
-    me = fam.bench_me_frame()
     peak, src = qsad_peak()
     rows.append(dict(family="full_search", kernel="me_full_search 64x64 (+ 64x48 row) +-64", config="#5, one 3840x2160 frame = 2040 CTUs, one launch",
                      ms=round(me["ms"], 4), mblocks_per_s=round(me["ctus"] / me["ms"] / 1e3, 3), frames_per_s=round(1e3 / me["ms"], 1),
@@ -791,7 +945,7 @@ def bench_me5(args, rank, world, device):
                          "note": "bound by the v_qsad_pk_u16_u8 issue rate, not HBM (1.7 k byte differences per byte fetched); rank 0's launches"},
             "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        emit(line, args.out_fd, args.full_out)
         if mismatches:
             print("bench.py: %d of %d CTUs differ from the reference's hevcasm_sad composition" % (mismatches, checked), file=sys.stderr)
             exit_code = 1

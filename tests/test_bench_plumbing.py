@@ -122,3 +122,172 @@ def test_cpu_family_legs_run_beside_prediction_and_idct():
             assert out["ref_%s_mblocks" % key] > 0, key
         assert out["simd_%s_mblocks" % key] > 0, key
     assert bench.scalars_only(out) == out           # nothing nested: the record keeps all of it
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The one line the driver reads (a 26 kB line preceded by a stray JSON row did not parse).
+
+def _canned_full_record(nan=False):
+    """A full record shaped as bench.main() builds it: 40 detail rows, the per-family rows, ~170 flattened roofline keys, both CPU columns."""
+    rows = _canned_family_rows()
+    flat = bench.flatten_families(rows)
+    for k in bench.PATTERN_KEYS.values():
+        flat[k + "_pattern_ms"] = 0.09
+        flat[k + "_vs_pattern"] = 0.93
+    detail = [dict(kernel="sad_multiref_4" if ways == 4 else "sad", size="%dx%d" % (w, h), ms_per_pass=0.7561, launches_per_pass=1, mblocks_per_s=1386.7,
+                   algorithmic_gb_per_s=5793.1, frac_of_hbm_peak=0.7241, launch_ms_median=0.7551, launch_ms_min=0.7432, bytes_per_block=bench.algorithmic_bytes(w, h, ways))
+              for (w, h) in wl.SAD_BENCH_SIZES for ways in (1, 4)]
+    roofline = dict(bound="hbm", kernel="sad_multiref_4 64x64", achieved=float("nan") if nan else 5793.1, peak=8000.0, unit="GB/s", frac=0.7241, traffic=4512000000,
+                    algorithmic_bytes_per_launch=4379901952, avg_launch_ms=0.7561, launch_ms_median=0.7551, launch_ms_min=0.7432, bytes_per_block=8354,
+                    measured_read_stream_gbs=7043.6, traffic_over_stream=0.85, survey_5wh16_gbs=13970.2, note="n" * 118, per_family_error=None, **flat)
+    cpu = dict(value=18.5, unit="Mblocks/s", cores=16, kind="reference", value_per_core=1.16, sample="s" * 150, sad16x16_single_ref_mblocks_per_s=50.0, host_cpus=256,
+               usable_cpus=16, note="16 procs", gpu_multiple=137.2, sample_blocks=8192, simd_value=140.1, simd_cores=16, simd_gpu_multiple=18.1, simd_sad16_mblocks=400.0,
+               simd_sample="t" * 150, family_cores=16, family_sample_pus=8100, family_sample_coeffs=1 << 19, simd_mask="0x1ff")
+    for key, _ in bench.CPU_FAMILY_CASES:
+        cpu.update({"ref_%s_mblocks" % key: 12.3456, "simd_%s_mblocks" % key: 123.4567, "ref_%s_gpu_multiple" % key: 400.1, "simd_%s_gpu_multiple" % key: 40.1})
+    return {"metric": "Mblocks/s (SAD-16x16, inter-pred, IDCT) batched; achieved HBM GB/s vs peak", "value": float("inf") if nan else 2538.7, "unit": "Mblocks/s",
+            "n_gpus": 1, "steps": 10, "warmup": 2, "ms_per_step": 16.522, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: SAD + 4-way SAD, 20 sizes 8x8..64x64, 1048576 blocks/size/GPU, ref +-7 px, frames in HBM", "blocks_per_step_per_gpu": 41943040,
+                       "launches_per_step": 44, "parallelism": "batch split x1, no collectives", "frame": "1920x1080", "input_generation_s": 31.2, "step_ms_median": 16.4,
+                       "step_ms_min": 16.3, "library": "hevcasm_amd/lib/libhevcasm_hip.so", "env_switches": {}},
+            "roofline": roofline, "cpu_baseline": cpu, "detail": detail, "per_family": rows}
+
+
+def _strict_loads(text):
+    def refuse(name):
+        raise ValueError("non-finite constant in the line: " + name)
+    return json.loads(text, parse_constant=refuse)
+
+
+REQUIRED_TOP = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "scaling", "higher_is_better", "vs_baseline", "data", "config",
+                "roofline", "cpu_baseline")
+REQUIRED_ROOFLINE = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "me_valu_frac", "me_frame_ms")
+REQUIRED_CPU = ("value", "unit", "cores", "kind", "sample", "simd_value")
+
+
+def _check_line(text, n_gpus=1):
+    assert "\n" not in text and len(text) < 4096, len(text)
+    line = _strict_loads(text)
+    for k in REQUIRED_TOP:
+        assert k in line, k
+    assert line["n_gpus"] == n_gpus and len(line["config"]["workload"]) <= 120
+    for k in REQUIRED_ROOFLINE:
+        assert k in line["roofline"], k
+    for fam in bench.HEADLINE_FAMILIES:
+        for sfx in ("_frac", "_ms"):
+            assert isinstance(line["roofline"][fam + sfx], float), fam + sfx
+    for fam in bench.PATTERN_HEADLINES:
+        assert isinstance(line["roofline"][fam + "_vs_pattern"], float), fam
+    for k in REQUIRED_CPU:
+        assert k in line["cpu_baseline"], k
+    for key, _ in bench.CPU_FAMILY_CASES:
+        for col in ("ref", "simd"):
+            assert line["cpu_baseline"]["%s_%s_mblocks" % (col, key)] > 0
+    for obj in (line["config"], line["roofline"], line["cpu_baseline"]):
+        for v in obj.values():
+            assert not isinstance(v, (dict, list)) and (not isinstance(v, str) or len(v) <= 120)
+    return line
+
+
+def test_the_line_is_compact_strict_json(tmp_path):
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 20000                     # the record that did not parse in round 4 was this size
+    path = str(tmp_path / "full.json")
+    r, w = os.pipe()
+    text = bench.emit(full, w, path)
+    os.close(w)
+    got = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert got == text + "\n"                                  # exactly one line reaches the descriptor
+    line = _check_line(text)
+    assert line["value"] == 2538.7 and line["roofline"]["frac"] == 0.7241 and line["cpu_baseline"]["value"] == 18.5
+    with open(path) as f:                                     # everything else is in the side file
+        side = json.load(f)
+    assert len(side["detail"]) == 40 and side["per_family"] and "idct16_2p28_frac" in side["roofline"]
+    assert line["full_record"].endswith("full.json")
+
+
+def test_the_line_never_carries_nan_or_infinity(tmp_path):
+    text = bench.emit(_canned_full_record(nan=True), os.open(os.devnull, os.O_WRONLY), str(tmp_path / "f.json"))
+    line = _strict_loads(text)
+    assert line["value"] is None and line["roofline"]["achieved"] is None
+    import pytest
+    with pytest.raises(ValueError):
+        _strict_loads('{"value": NaN}')
+
+
+def test_an_oversized_record_still_gives_a_line(tmp_path):
+    full = _canned_full_record()
+    for i in range(300):
+        full["roofline"]["sad16_extra%d_frac" % i] = 0.5       # not headline keys: must not reach the line
+    full["roofline"]["note"] = "x" * 5000
+    text = bench.emit(full, os.open(os.devnull, os.O_WRONLY), str(tmp_path / "f.json"))
+    assert len(text) < 4096 and "extra" not in text
+
+
+def _run_bench(argv, tmp_path, env=None):
+    import subprocess, sys
+    rec = str(tmp_path / "record.json")
+    with open(rec, "w") as f:
+        json.dump(_canned_full_record(), f)
+    e = dict(os.environ, **(env or {}))
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--plumbing", rec], capture_output=True, text=True, timeout=300, env=e)
+
+
+def test_bench_main_prints_one_line_last_and_alone(tmp_path):
+    """bench.py's process: whatever anything prints on the way (here: the stale-switch warning path and a library banner), stdout holds one line."""
+    out = _run_bench(["--steps", "3", "--warmup", "1"], tmp_path, env={"HEVCASM_SOMETHING_STALE": "1"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and out.stdout.endswith("\n")
+    line = _check_line(lines[0])
+    assert line["steps"] == 3 and line["warmup"] == 1 and "not a measurement" in line["data"]
+    assert "WARNING" in out.stderr and "bare print()" in out.stderr          # a print() to sys.stdout lands on stderr
+
+
+def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` as the driver's BENCH command shapes it (no torch.distributed.run around it): bench.py starts the two ranks as a
+    child process, they meet over gloo, and rank 0's one line -- n_gpus 2 -- is relayed alone on stdout with the child's exit code."""
+    out = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "0"], tmp_path)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1, out.stdout[-2000:]
+    line = _check_line(lines[0], n_gpus=2)
+    assert line["config"]["slowest_rank_ms"] == 2.0            # the MAX over the two ranks' (rank + 1) ms
+
+
+def test_bench_under_the_launcher_prints_one_line(tmp_path):
+    """The contract's N > 1 launch: python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 ..."""
+    import subprocess, sys, socket
+    rec = str(tmp_path / "record.json")
+    with open(rec, "w") as f:
+        json.dump(_canned_full_record(), f)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--plumbing", rec], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, out.stdout[-2000:]
+    _check_line(lines[0], n_gpus=2)
+
+
+def test_me5_line_is_compact(tmp_path):
+    """The configs[4] line (strong scaling) through the same emit: me_split, ctus_per_rank, slowest_rank_ms survive."""
+    full = {"metric": "m", "value": 1.77, "unit": "Mblocks/s", "n_gpus": 8, "steps": 50, "warmup": 5, "ms_per_step": 0.19, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "valid": True,
+            "config": {"workload": "w" * 119, "parallelism": "CTU runs split x8", "me_split": "ctus", "ctus_per_rank": 255, "rank0_first_ctu": 0, "rank0_rows": "0..5",
+                       "slowest_rank_ms": 0.19, "rank0_kernel_ms": 0.18, "frames_per_s": 5200.0, "gsad_evals_per_s": 176.0, "library": "hevcasm_amd/lib/libhevcasm_hip.so", "env_switches": {}},
+            "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": 120.0, "peak": 147.8, "unit": "T byte differences/s", "frac": 0.81, "traffic": None,
+                         "frac_nominal": 0.76, "avg_launch_ms": 0.18, "hbm_frac": 0.001, "note": "n" * 118},
+            "cpu_baseline": {"value": 1e-5, "unit": "Mblocks/s", "cores": 16, "kind": "reference", "sample": "s" * 118, "checked_ctus": 40, "mismatches": 0}}
+    text = bench.emit(full, os.open(os.devnull, os.O_WRONLY), str(tmp_path / "f.json"))
+    line = _strict_loads(text)
+    assert len(text) < 4096 and line["valid"] is True and line["scaling"] == "strong"
+    for k in ("me_split", "ctus_per_rank", "slowest_rank_ms"):
+        assert k in line["config"]
+    assert line["roofline"]["traffic"] is None and line["cpu_baseline"]["mismatches"] == 0

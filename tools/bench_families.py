@@ -253,7 +253,7 @@ def bench_me():
                           frames_per_s=round(1e3 / ms2, 1), gsad_evals_per_s=round(total_sads / ms2 / 1e6, 2))), flush=True)
 
 
-def bench_me_frame(reps=5):
+def bench_me_frame(reps=5, quiet=False):
     """Config #5 through the frame-rows entry point: the whole 3840x2160 frame (33 rows of 64x64 CTUs + one of 64x48) in ONE launch."""
     from hevcasm_amd import me_frame
     fw, fh, ctu, r = 3840, 2160, 64, 64
@@ -275,7 +275,7 @@ def bench_me_frame(reps=5):
     side = (2 * r + 1) ** 2
     res = dict(ms=ms, ctus=rows * cols, sad_evals=rows * cols * side, byte_diffs=sum(cols * ctu * h for h in heights) * side,
                bytes=sum(cols * (ctu * h + (ctu + 2 * r) * (h + 2 * r) + 12) for h in heights))
-    if SINK is None:
+    if SINK is None and not quiet:
         print(json.dumps(dict(kernel="me_full_search_frame_rows, whole 4K frame in one launch", ms=round(ms, 4), ctus=res["ctus"], frames_per_s=round(1e3 / ms, 1),
                               gsad_evals_per_s=round(res["sad_evals"] / ms / 1e6, 2), tera_byte_diffs_per_s=round(res["byte_diffs"] / ms / 1e9, 2))), flush=True)
     return res
