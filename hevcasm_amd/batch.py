@@ -227,3 +227,14 @@ def ssd_linear(src0, src1, off0, off1, size, out=None):
     check(lib().hevcasm_hip_ssd_linear_batch(src0.data_ptr(), src1.data_ptr(), off0.data_ptr(), off1.data_ptr(), out.data_ptr(), size, n, _stream()),
           "ssd_linear_batch")
     return out
+
+
+def frame_sse(a, stride_a, b, stride_b, a_off, b_off, width, height, out=None):
+    """Whole-frame SSE, 64-bit: out[i] = sum over rows of hevcasm_ssd_linear(row) for frame i (int64 tensor; the values are < 2^63)."""
+    n = a_off.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.int64, device=a.device)
+    assert out.dtype == torch.int64 and out.is_contiguous() and out.numel() >= n and out.device == a.device
+    check(lib().hevcasm_hip_frame_sse_batch(a.data_ptr(), stride_a, b.data_ptr(), stride_b, a_off.data_ptr(), b_off.data_ptr(), out.data_ptr(),
+                                            width, height, n, _stream()), "frame_sse_batch")
+    return out

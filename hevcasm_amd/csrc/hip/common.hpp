@@ -135,26 +135,6 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
 	return v;
 }
 
-// the same reductions with DPP moves only (no LDS crossbar, no lgkmcnt waits): quad, row of 16, then the row broadcasts put the result in lane 63,
-// v_readlane hands it out as a wave-uniform SCALAR.  Lanes a DPP step does not write keep their own value (old = v: the identity of min / max).
-#define HEVC_DPP_REDUCE(OP, v) \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xb1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false)); \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4e /* quad_perm [2,3,0,1] */, 0xf, 0xf, false)); \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xe, false)); \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xc, false)); \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false)); \
-	v = OP(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false));
-__device__ __forceinline__ uint32_t wave_min_u32_scalar(uint32_t v)
-{
-	HEVC_DPP_REDUCE(min, v)
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ uint32_t wave_max_u32_scalar(uint32_t v)
-{
-	HEVC_DPP_REDUCE(max, v)
-	return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
 // v[idx] for a per-lane idx < N out of N wave-uniform values (SGPRs): a binary tree of v_cndmask on the bits of idx when N is a power of two
 // (N - 1 selects; the bit tests are shared by every array picked with the same idx), a chain of compares otherwise
 template <int N> __device__ __forceinline__ uint32_t pick_by_index(const uint32_t (&v)[N], uint32_t idx)

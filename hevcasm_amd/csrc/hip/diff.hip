@@ -9,6 +9,8 @@
 
 #include "common.hpp"
 
+#include <algorithm>
+
 namespace hevc {
 
 template <int LPS>
@@ -51,6 +53,65 @@ __global__ __launch_bounds__(kThreads) void ssd_linear_kernel(
 	if (live && j == 0) ssd[run] = (int)v;
 }
 
+// Whole-frame SSE (second half): frame i = `width` x `height` bytes, rows `stride` apart, at
+// a + a_off[i] against b + b_off[i]; sse[i] = sum over the rows of hevcasm_ssd_linear(row a, row b, width) (reference
+// diff.c:45-54), accumulated in 64 bits -- a row is at most 32 768 bytes here so every row sum is exact in the reference's
+// int, and a 3840 x 2160 frame of 0 against 255 (5.4e11) needs the wide sum.
+//
+// A workgroup owns kThreads / LPR row slots and walks `rows_per_wg` rows of one frame; LPR lanes share a row, 16 bytes each
+// and LPR * 16 bytes apart, tail bytes one per lane.  Per chunk sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab <= 16 * 255^2
+// (three v_dot4_u32_u8 per dword), added to a 64-bit lane total; wave total by __shfl_xor, one 64-bit atomic add per wave
+// into sse[i] (integer: the order does not matter).  HBM-bound: algorithmic bytes per frame = 2 * width * height + 8 + 8.
+template <int LPR>
+__global__ __launch_bounds__(kThreads) void frame_sse_kernel(
+	const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ b_off,
+	unsigned long long *__restrict__ sse, int64_t stride_a, int64_t stride_b, uint32_t width, uint32_t height, uint32_t rows_per_wg, uint32_t wgs_per_frame)
+{
+	constexpr uint32_t kSlots = kThreads / LPR;
+	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
+	const uint32_t frame = wg / wgs_per_frame;
+	const uint32_t row0 = (wg % wgs_per_frame) * rows_per_wg;
+	const uint32_t row1 = min(row0 + rows_per_wg, height);
+	const uint32_t lane = threadIdx.x % LPR, slot = threadIdx.x / LPR;
+	const uint8_t *pa = a + a_off[frame], *pb = b + b_off[frame];
+	const uint32_t whole = width & ~15u;
+
+	unsigned long long total = 0;
+	for (uint32_t y = row0 + slot; y < row1; y += kSlots)
+	{
+		const uint8_t *ra = pa + (int64_t)y * stride_a, *rb = pb + (int64_t)y * stride_b;
+		for (uint32_t o = 16 * lane; o < whole; o += 16 * LPR)
+		{
+			Chunk<16> x, z;
+			x.load_stream(ra + o);   // both frames are read exactly once
+			z.load_stream(rb + o);
+			uint32_t sq = 0, ab = 0;
+#pragma unroll
+			for (int k = 0; k < 4; ++k)
+			{
+				sq = __builtin_amdgcn_udot4(x.d[k], x.d[k], sq, false);
+				sq = __builtin_amdgcn_udot4(z.d[k], z.d[k], sq, false);
+				ab = __builtin_amdgcn_udot4(x.d[k], z.d[k], ab, false);
+			}
+			total += sq - 2u * ab;
+		}
+		if (whole + lane < width)    // LPR >= 16: one tail byte per lane
+		{
+			const int d = (int)ra[whole + lane] - (int)rb[whole + lane];
+			total += (uint32_t)(d * d);
+		}
+	}
+	uint32_t lo = (uint32_t)total, hi = (uint32_t)(total >> 32);
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1)
+	{
+		const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)hi, d, kWave) << 32) | (uint32_t)__shfl_xor((int)lo, d, kWave);
+		total += other;
+		lo = (uint32_t)total; hi = (uint32_t)(total >> 32);
+	}
+	if (threadIdx.x % kWave == 0 && total) atomicAdd(&sse[frame], total);
+}
+
 }  // namespace hevc
 
 using namespace hevc;
@@ -72,4 +133,37 @@ extern "C" int hevcasm_hip_ssd_linear_batch(
 	else
 		hipLaunchKernelGGL(ssd_linear_kernel<4>, dim3(ceil_div(n_blocks * 4, kThreads)), dim3(kThreads), 0, st, src0, src1, off0, off1, ssd, (uint32_t)size, (uint32_t)n_blocks);
 	return launch_status("ssd_linear_kernel");
+}
+
+extern "C" int hevcasm_hip_frame_sse_batch(
+	const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b, const uint32_t *a_off, const uint32_t *b_off,
+	uint64_t *sse, int width, int height, size_t n_frames, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (width < 0 || height < 0 || width > 32768 || height > 65536) return set_error(HEVCASM_HIP_EINVAL, "width must be 0..32768, height 0..65536");
+	if (n_frames == 0) return 0;
+	if (n_frames > 0xfffffull) return set_error(HEVCASM_HIP_EINVAL, "n_frames too large");
+	if (!a || !b || !a_off || !b_off || !sse) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	hipStream_t st = as_stream(stream);
+	HEVC_HIP_TRY(hipMemsetAsync(sse, 0, 8 * n_frames, st));
+	if (width == 0 || height == 0) return 0;
+	// lanes per row: the smallest of 16 / 64 / 256 that covers the row's 16-byte chunks (a 4K row: 240 chunks on 256 lanes; 1080p: 120 on 2 x 64)
+	const uint32_t chunks = ((uint32_t)width + 15) / 16;
+	const uint32_t lpr = chunks <= 16 ? 16 : chunks <= 128 ? 64 : 256;
+	const uint32_t slots = kThreads / lpr;
+	// rows per workgroup: whole rounds of the slots, few enough rounds that about 16 workgroups per CU share the frames
+	const size_t total_rounds = n_frames * (size_t)ceil_div((size_t)height, slots);
+	uint32_t rounds = (uint32_t)std::min<size_t>(64, std::max<size_t>(2, total_rounds / ((size_t)device_cus() * 16)));
+	const uint32_t rows_per_wg = rounds * slots;
+	const uint32_t wgs_per_frame = ceil_div((size_t)height, rows_per_wg);
+	const size_t grid = n_frames * (size_t)wgs_per_frame;
+	if (grid > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "batch too large for one launch");
+	unsigned long long *out = reinterpret_cast<unsigned long long *>(sse);
+#define HEVC_LAUNCH_SSE(L) hipLaunchKernelGGL(frame_sse_kernel<L>, dim3((uint32_t)grid), dim3(kThreads), 0, st, a, b, a_off, b_off, out, \
+	(int64_t)stride_a, (int64_t)stride_b, (uint32_t)width, (uint32_t)height, rows_per_wg, wgs_per_frame)
+	if (lpr == 16) HEVC_LAUNCH_SSE(16);
+	else if (lpr == 64) HEVC_LAUNCH_SSE(64);
+	else HEVC_LAUNCH_SSE(256);
+#undef HEVC_LAUNCH_SSE
+	return launch_status("frame_sse_kernel");
 }

@@ -117,6 +117,18 @@ int hevcasm_hip_ssd_linear_batch(
 	const uint8_t *src0, const uint8_t *src1, const uint32_t *off0, const uint32_t *off1, int *ssd,
 	int size, size_t n_blocks, void *stream);
 
+/* Whole-frame sum of squared errors with 64-bit accumulation ("linear SSD / PSNR over whole frames"):
+ * frame i is width x height bytes, rows stride_a / stride_b apart, at a + a_off[i] against b + b_off[i];
+ * sse[i] = the sum over its rows of hevcasm_ssd_linear(row of a, row of b, width) (reference diff.h:52; C body diff.c:45-54) -- each
+ * row sum is exact in the reference's int (width <= 32 768 < 33 025), the sum over rows is kept in 64 bits (a 3840 x 2160 frame of
+ * 0 against 255 is 5.4e11).  width 0..32768, height 0..65536, any strides (negative = bottom-up), any alignment.  PSNR is a host
+ * one-liner on top: 10 log10(255^2 * width * height / sse).  sse must be 8-byte aligned; the call zeroes it first
+ * (hipMemsetAsync on `stream`) and then accumulates into it, so it belongs to the call until `stream` has passed the launch. */
+int hevcasm_hip_frame_sse_batch(
+	const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b,
+	const uint32_t *a_off, const uint32_t *b_off, uint64_t *sse,
+	int width, int height, size_t n_frames, void *stream);
+
 /* ---- intra prediction ----------------------------------------------------------------- */
 
 /* Batched hevcasm_pred_intra (reference pred_intra.h:55; C body pred_intra.c:61-101).  Block i

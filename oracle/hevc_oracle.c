@@ -624,3 +624,17 @@ void orc_ssd_linear_batch(const uint8_t *src0, const uint8_t *src1, const uint32
 {
 	for (size_t i = 0; i < n; ++i) ssd[i] = orc_ssd_linear(src0 + off0[i], src1 + off1[i], size);
 }
+
+/* Whole-frame SSE: the reference has no such function; the pin is the composition of hevcasm_ssd_linear (diff.c:45-54) over the rows
+ * of a frame, each row exact in int (width < 33 025), summed in 64 bits. */
+void orc_frame_sse_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b, const uint32_t *a_off, const uint32_t *b_off,
+                         uint64_t *sse, int width, int height, size_t n)
+{
+	for (size_t i = 0; i < n; ++i)
+	{
+		uint64_t sum = 0;
+		for (int y = 0; y < height; ++y)
+			sum += (uint64_t)(unsigned)orc_ssd_linear(a + a_off[i] + (ptrdiff_t)y * stride_a, b + b_off[i] + (ptrdiff_t)y * stride_b, width);
+		sse[i] = sum;
+	}
+}

@@ -118,6 +118,8 @@ void orc_pred_intra_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t nei
 /* diff.h:52; diff.c:45-54 */
 int orc_ssd_linear(const uint8_t *p1, const uint8_t *p2, int n);
 void orc_ssd_linear_batch(const uint8_t *src0, const uint8_t *src1, const uint32_t *off0, const uint32_t *off1, int *ssd, int size, size_t n);
+void orc_frame_sse_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b, const uint32_t *a_off, const uint32_t *b_off,
+                         uint64_t *sse, int width, int height, size_t n);
 
 #ifdef __cplusplus
 }

@@ -199,6 +199,14 @@ def ssd_linear_batch(src0, src1, off0, off1, size):
     return out
 
 
+def frame_sse_batch(a, stride_a, b, stride_b, a_off, b_off, width, height):
+    a, b, a_off, b_off = _u8(a), _u8(b), _u32(a_off), _u32(b_off)
+    out = np.empty(a_off.size, dtype=np.uint64)
+    lib().orc_frame_sse_batch(_p(a), C.c_ssize_t(stride_a), _p(b), C.c_ssize_t(stride_b), _p(a_off), _p(b_off), _p(out), C.c_int(width), C.c_int(height),
+                              C.c_size_t(a_off.size))
+    return out.astype(np.int64)
+
+
 def dct_matrix(n):
     f = lib().orc_dct_matrix
     return np.array([[f(n, k, i) for i in range(n)] for k in range(n)], dtype=np.int32)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
-OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL, OP_INTRA, OP_SSD_LINEAR = 8, 9, 10, 11, 12, 13, 14, 15, 16
+OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL, OP_INTRA, OP_SSD_LINEAR, OP_FRAME_SSE = 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
 OP_SELFTEST, OP_BENCH_SAD, OP_BENCH_PRED, OP_BENCH_INV = 20, 30, 31, 32
 
 
@@ -151,6 +151,10 @@ class RefProc:
     def ssd_linear_batch(self, src0, src1, off0, off1, size):
         o = self.call(OP_SSD_LINEAR, [size, len(off0)], [_u8(src0), _u8(src1), _u32(off0), _u32(off1)])
         return np.frombuffer(o[0], dtype=np.int32).copy()
+
+    def frame_sse_batch(self, a, stride_a, b, stride_b, a_off, b_off, width, height):
+        o = self.call(OP_FRAME_SSE, [stride_a, stride_b, width, height, len(a_off)], [_u8(a), _u8(b), _u32(a_off), _u32(b_off)])
+        return np.frombuffer(o[0], dtype=np.uint64).astype(np.int64)
 
     def selftest(self, family_mask, out_path):
         o = self.call(OP_SELFTEST, [family_mask], [out_path.encode()])

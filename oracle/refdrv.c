@@ -82,7 +82,7 @@ static double now_s(void)
 
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
-	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14, OP_INTRA = 15, OP_SSD_LINEAR = 16,
+	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14, OP_INTRA = 15, OP_SSD_LINEAR = 16, OP_FRAME_SSE = 17,
 	OP_SELFTEST = 20, OP_BENCH_SAD = 30, OP_BENCH_PRED = 31, OP_BENCH_INV = 32
 };
 
@@ -336,6 +336,21 @@ int main(void)
 			int *r = (int *)malloc(4 * n + 4);
 			for (size_t i = 0; i < n; ++i) r[i] = f(in[0].p + o0[i], in[1].p + o1[i], (int)par[0]);
 			out[0].p = (uint8_t *)r; out[0].bytes = 4 * n; nout = 1;
+			break;
+		}
+		case OP_FRAME_SSE: /* par: stride_a, stride_b, width, height, n; bufs: a, b, a_off, b_off -> u64[n]: the reference's hevcasm_ssd_linear per row, summed in 64 bits */
+		{
+			const size_t n = (size_t)par[4];
+			const uint32_t *o0 = (const uint32_t *)in[2].p, *o1 = (const uint32_t *)in[3].p;
+			hevcasm_ssd_linear *f = hevcasm_get_ssd_linear((int)par[2], HEVCASM_C_REF);
+			uint64_t *r = (uint64_t *)malloc(8 * n + 8);
+			for (size_t i = 0; i < n; ++i)
+			{
+				uint64_t sum = 0;
+				for (int64_t y = 0; y < par[3]; ++y) sum += (uint64_t)(unsigned)f(in[0].p + o0[i] + y * par[0], in[1].p + o1[i] + y * par[1], (int)par[2]);
+				r[i] = sum;
+			}
+			out[0].p = (uint8_t *)r; out[0].bytes = 8 * n; nout = 1;
 			break;
 		}
 		case OP_SELFTEST: /* par[0] = bit mask of families; runs the reference's own self-tests on its C path. Output on stderr-free stdout is

@@ -380,9 +380,41 @@ def ssd_linear_cases(seed=1200):
     return out
 
 
+def frame_sse_cases(seed=1300):
+    """Whole-frame SSE, 64-bit: widths on both sides of every lane deal (16 / 64 / 256 lanes per row; a row longer than 256 chunks), tails that are
+    not multiples of 16, padded / bottom-up / byte-misaligned planes, empty frames, several frames per call, and the 4K frame of 0 against 255
+    whose sum (5.4e11) is past 32 bits -- each ROW of it is still exact in the reference's int."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for (w, h, n, pad) in ((1, 1, 3, 0), (15, 7, 4, 5), (16, 9, 3, 0), (17, 33, 2, 3), (100, 21, 5, 28), (256, 64, 2, 0), (257, 5, 2, 7), (1920, 30, 2, 64),
+                           (2048, 3, 1, 0), (2049, 67, 1, 1), (3840, 17, 2, 0), (4100, 6, 1, 4), (5000, 2, 2, 0)):
+        stride = w + pad
+        span = stride * h + 5
+        a = wl.fill_u8(span * n + 16, seed + w)
+        b = wl.fill_u8(span * n + 16, seed + w + 1)
+        a_off = (np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32)
+        b_off = (np.arange(n) * span + rng.integers(0, 4, n)).astype(np.uint32)
+        out.append(("fsse_%dx%d" % (w, h), "frame_sse", dict(a=a, stride_a=stride, b=b, stride_b=stride, a_off=a_off, b_off=b_off, width=w, height=h)))
+    # different strides per plane, and a bottom-up plane (negative stride: the offset names the LAST row in memory)
+    a = wl.fill_u8(200 * 50 + 16, seed + 90)
+    b = wl.fill_u8(300 * 50 + 16, seed + 91)
+    out.append(("fsse_strides", "frame_sse", dict(a=a, stride_a=200, b=b, stride_b=300, a_off=np.array([1, 0], dtype=np.uint32), b_off=np.array([0, 37], dtype=np.uint32),
+                                                  width=163, height=50)))
+    out.append(("fsse_bottom_up", "frame_sse", dict(a=a, stride_a=-200, b=b, stride_b=300, a_off=np.array([49 * 200 + 3], dtype=np.uint32), b_off=np.array([2], dtype=np.uint32),
+                                                    width=190, height=50)))
+    for tag, (w, h) in (("w0", (0, 8)), ("h0", (8, 0))):
+        out.append(("fsse_" + tag, "frame_sse", dict(a=a, stride_a=200, b=b, stride_b=300, a_off=np.zeros(3, dtype=np.uint32), b_off=np.zeros(3, dtype=np.uint32), width=w, height=h)))
+    fw, fh = 3840, 2160
+    out.append(("fsse_4k_extremes", "frame_sse", dict(a=np.zeros(fw * fh, dtype=np.uint8), stride_a=fw, b=np.full(fw * fh, 255, dtype=np.uint8), stride_b=fw,
+                                                      a_off=np.zeros(1, dtype=np.uint32), b_off=np.zeros(1, dtype=np.uint32), width=fw, height=fh)))
+    out.append(("fsse_widest_row", "frame_sse", dict(a=np.zeros(32768 * 2, dtype=np.uint8), stride_a=32768, b=np.full(32768 * 2, 255, dtype=np.uint8), stride_b=32768,
+                                                     a_off=np.zeros(1, dtype=np.uint32), b_off=np.zeros(1, dtype=np.uint32), width=32768, height=2)))
+    return out
+
+
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
-                      intra=intra_cases, ssd_linear=ssd_linear_cases)
+                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases)
 
 
 # ------------------------------------------------------------------------------------- runners
@@ -431,6 +463,8 @@ def _run_cpu(api, family, c):
         return (api.pred_intra_batch(c["neighbours"], c["neighbour_stride"], c["mode"], c["packed"], c["n"]),)
     if family == "ssd_linear":
         return (api.ssd_linear_batch(c["src0"], c["src1"], c["off0"], c["off1"], c["size"]),)
+    if family == "frame_sse":
+        return (api.frame_sse_batch(c["a"], c["stride_a"], c["b"], c["stride_b"], c["a_off"], c["b_off"], c["width"], c["height"]),)
     raise ValueError(family)
 
 
@@ -499,6 +533,8 @@ def run_hip(family, c):
         return (cpu(B.pred_intra(plane(c["n"] * size * size), u8(c["neighbours"]), c["neighbour_stride"], c["mode"], c["packed"], c["n"])),)
     if family == "ssd_linear":
         return (cpu(B.ssd_linear(u8(c["src0"]), u8(c["src1"]), off(c["off0"]), off(c["off1"]), c["size"])),)
+    if family == "frame_sse":
+        return (cpu(B.frame_sse(u8(c["a"]), c["stride_a"], u8(c["b"]), c["stride_b"], off(c["a_off"]), off(c["b_off"]), c["width"], c["height"])),)
     raise ValueError(family)
 
 

@@ -68,6 +68,7 @@ def small_cases():
     out += [x for x in cases.subpel_cases() if x[0] in ("subpel_8x8", "subpel_smooth_16x16", "subpel_ties", "subpel_satd_16x16", "subpel_satd_12x16")]
     out += [x for x in cases.intra_cases() if x[0].endswith("_s160")]
     out += [x for x in cases.ssd_linear_cases() if x[0] in ("ssdlin_17", "ssdlin_512", "ssdlin_1023", "ssdlin_4099")]
+    out += [x for x in cases.frame_sse_cases() if x[0] in ("fsse_17x33", "fsse_257x5", "fsse_bottom_up")]
     return out
 
 

@@ -943,3 +943,102 @@ def test_pred_bi_hfirst_kernel_sizes_and_edges():
             c["frac1"] = ((3 - fx0) | ((fy0 ^ 1) << 4)) * np.ones_like(c["frac1"])
             cases.assert_same("hfirst bi fractions %d %d" % (fx0, fy0), cases.run_hip("pred_bi", c), cases.run_oracle("pred_bi", c))
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tr,lg", [(1, 2), (0, 2), (0, 3), (0, 4), (0, 5)])
+def test_config4_fused_pipeline_at_its_own_size(tr, lg):
+    """BASELINE.json configs[3] at SURVEY 8(d)'s size -- 2^24 coefficients per transform size -- through hevcasm_hip_dequant_inverse_transform_add_batch
+    (full workgroups with scalar offsets, then the partial tail: launch shapes the 24..130-block oracle cases never reach).  Composition to match:
+    hevcasm_quantize_inverse (reference quantize.c:53-62) followed by hevcasm_inverse_transform_add (residual_decode.c:371-413).
+      whole output == quantize_inverse -> inverse_transform_add as two HIP launches (each oracle-tested on its own);
+      first and last 200 blocks == the oracle's composition."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    size = 1 << lg
+    n = (1 << 24) >> (2 * lg)
+    n += 3                       # not a multiple of any workgroup's block count: the tail launch runs too
+    for kind, (scale, shift) in (("natural", (51, 14)), ("full", (51, 14)), ("natural", (57 << 8, lg + 3)), ("full", (40 << 3, max(1, lg + 3)))):
+        c = wl.inverse_case(tr, lg, n, 4400 + lg + shift, kind, frame=(wl.FRAME_W, wl.FRAME_H))
+        pred, levels = B.u8(c["pred"]), B.i16(c["coeffs"])
+        doff, poff = B.off32(c["dst_off"]), B.off32(c["pred_off"])
+        fused = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.dequant_inverse_transform_add(fused, c["stride_dst"], pred, c["stride_pred"], doff, poff, levels, scale, shift, tr, lg)
+        two = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.inverse_transform_add(two, c["stride_dst"], pred, c["stride_pred"], doff, poff, B.quantize_inverse(levels, scale, shift), tr, lg)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, two), (tr, lg, kind, scale, shift, int((fused != two).sum()))
+        assert int(fused.count_nonzero()) > fused.numel() // 4          # something was written
+        got = fused.cpu().numpy()
+        for sl in (slice(0, 200), slice(n - 200, n)):
+            want = pyoracle.dequant_inverse_transform_add_batch(tr, lg, c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"][sl], c["pred_off"][sl],
+                                                                c["coeffs"][sl.start * size * size: sl.stop * size * size], scale, shift)
+            cases.assert_same("config4 %s %d/%d blocks %d.." % (kind, scale, shift, sl.start),
+                              (cases._dst_rows(got, c["stride_dst"], c["dst_off"][sl], size, size),), (cases._dst_rows(want, c["stride_dst"], c["dst_off"][sl], size, size),))
+        del fused, two, pred, levels
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lg", [2, 3, 4, 5])
+def test_config4_reconstruct_at_its_own_size(lg):
+    """hevcasm_hip_quantize_reconstruct_batch (reference quantize.c:292-302) over 2^24 residuals: the whole output against the definition
+    clip8(pred + res) computed by torch on the same device arrays (gather / scatter by the same offsets), first and last 200 blocks against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    size = 1 << lg
+    n = ((1 << 24) >> (2 * lg)) + 5
+    for kind in ("residual9", "full"):
+        c = wl.inverse_case(0, lg, n, 4500 + lg, kind, frame=(wl.FRAME_W, wl.FRAME_H))
+        pred, res = B.u8(c["pred"]), B.i16(c["coeffs"])
+        rec = torch.zeros(c["dst_bytes"], dtype=torch.uint8, device="cuda")
+        B.quantize_reconstruct(rec, c["stride_dst"], pred, c["stride_pred"], B.off32(c["dst_off"]), B.off32(c["pred_off"]), res, size)
+        torch.cuda.synchronize()
+        rows = torch.arange(size, device="cuda", dtype=torch.int64)
+        pidx = (torch.from_numpy(c["pred_off"].astype(np.int64)).cuda()[:, None, None] + rows[None, :, None] * c["stride_pred"] + rows[None, None, :])
+        didx = (torch.from_numpy(c["dst_off"].astype(np.int64)).cuda()[:, None, None] + rows[None, :, None] * c["stride_dst"] + rows[None, None, :])
+        want = (pred[pidx].to(torch.int32) + res.view(n, size, size).to(torch.int32)).clamp_(0, 255).to(torch.uint8)
+        assert torch.equal(rec[didx], want), (lg, kind)
+        del pidx, didx, want
+        got = rec.cpu().numpy()
+        for sl in (slice(0, 200), slice(n - 200, n)):
+            o = pyoracle.quantize_reconstruct_batch(c["dst_bytes"], c["stride_dst"], c["pred"], c["stride_pred"], c["dst_off"][sl], c["pred_off"][sl],
+                                                    c["coeffs"][sl.start * size * size: sl.stop * size * size], size)
+            cases.assert_same("recon %d %s" % (size, kind), (cases._dst_rows(got, c["stride_dst"], c["dst_off"][sl], size, size),),
+                              (cases._dst_rows(o, c["stride_dst"], c["dst_off"][sl], size, size),))
+        del rec, pred, res
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_frame_sse_full_size():
+    """hevcasm_hip_frame_sse_batch on 64 frames of 3840 x 2160 inside padded planes: equals the per-row hevcasm_hip_ssd_linear_batch sums (each row exact
+    in 32 bits) added up in 64 bits by torch, equals the oracle on the first and last frame, and PSNR of a known offset comes out as the formula says."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    fw, fh, pad, frames = 3840, 2160, 64, 24
+    stride = fw + 2 * pad
+    span = stride * (fh + 2)
+    a = wl.fill_u8(span * frames + 64, 31, device="cuda")
+    b = wl.fill_u8(span * frames + 64, 32, device="cuda")
+    a_off = (np.arange(frames, dtype=np.int64) * span + pad + 1).astype(np.uint32)
+    b_off = (np.arange(frames, dtype=np.int64) * span + stride + 3).astype(np.uint32)
+    got = B.frame_sse(a, stride, b, stride, B.off32(a_off), B.off32(b_off), fw, fh)
+    ro_a = (a_off.astype(np.int64)[:, None] + np.arange(fh)[None, :] * stride).reshape(-1).astype(np.uint32)
+    ro_b = (b_off.astype(np.int64)[:, None] + np.arange(fh)[None, :] * stride).reshape(-1).astype(np.uint32)
+    rows = B.ssd_linear(a, b, B.off32(ro_a), B.off32(ro_b), fw)
+    torch.cuda.synchronize()
+    assert torch.equal(got, rows.to(torch.int64).view(frames, fh).sum(dim=1))
+    host_a, host_b = a.cpu().numpy(), b.cpu().numpy()
+    for f in (0, frames - 1):
+        want = pyoracle.frame_sse_batch(host_a, stride, host_b, stride, a_off[f:f + 1], b_off[f:f + 1], fw, fh)
+        assert int(got[f]) == int(want[0]) > 2 ** 32
+    # a plane against itself + 3 (no wrap: values capped at 252): SSE = 9 W H, PSNR = 10 log10(255^2 / 9)
+    c = a.clamp(max=252)
+    d = c + 3
+    s = B.frame_sse(c, stride, d, stride, B.off32(a_off), B.off32(a_off), fw, fh)
+    torch.cuda.synchronize()
+    assert bool((s == 9 * fw * fh).all())
