@@ -280,28 +280,6 @@ __global__ __launch_bounds__(kThreads) void me_decode_kernel(int *result, uint32
 
 using namespace hevc;
 
-// Workgroups per block.  One when the launch fills the device's workgroup slots by itself; a launch too small for that (one rank's share of a
-// frame split over 8 GPUs) cuts every block's candidate ROWS into 2 or 4 parts.  Slots = compute units of the CURRENT device (a CPX / DPX
-// partition has 32 / 128) x the workgroups a CU holds at this launch's LDS footprint (160 KiB of LDS, 8 workgroups of 256 threads: four at
-// 64x64 / +-64).  Splitting costs a memset, a decode launch and re-staged window rows, so it is only done where a block is a large piece of
-// work -- W H (2 range + 1)^2 of at least 2^23 byte differences (32x32 / +-64 upwards; a list of 16x16 / +-16 blocks never splits) -- and while
-// the part-workgroups stay within 1.5 rounds of the slots (on 256 CUs at 64x64 / +-64: up to 384 blocks in 4 parts, up to 768 in 2; the only
-// geometry measured, profiles/r03_me_shard_launches.txt).
-static int me_parts(size_t n_blocks, int W, int H, int range, size_t lds_whole)
-{
-	static const int forced = getenv("HEVCASM_ME_PARTS") ? atoi(getenv("HEVCASM_ME_PARTS")) : 0;    // measurement switch, read once per process
-	int parts = 1;
-	if (forced >= 1 && forced <= 8) parts = forced;
-	else if ((size_t)W * H * (2 * range + 1) * (2 * range + 1) >= ((size_t)1 << 23))
-	{
-		const size_t per_cu = lds_whole ? (160 * 1024) / ((lds_whole + 1023) & ~(size_t)1023) : 8;
-		const size_t slots = (size_t)device_cus() * (per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu);
-		parts = 2 * n_blocks * 4 <= 3 * slots ? 4 : 2 * n_blocks * 2 <= 3 * slots ? 2 : 1;
-	}
-	while (parts > 1 && 2 * range + 1 < 8 * parts) --parts;              // every part gets candidate rows
-	return parts;
-}
-
 // LDS bytes of one workgroup: `win_rows` window rows of win_stride bytes (H + 2 range of them when one workgroup takes all of a block's
 // candidate rows), then the source tile, which also absorbs what the last dx group reads past the last window row (see the kernel's layout note)
 static size_t me_lds_bytes(int W, int H, int range, int win_rows, int *win_stride)
@@ -313,6 +291,35 @@ static size_t me_lds_bytes(int W, int H, int range, int win_rows, int *win_strid
 	return (size_t)*win_stride * win_rows + (size_t)((tail + 15) & ~15);
 }
 
+// Workgroups per block.  One when the launch fills the device's workgroup slots by itself; a launch too small for that (one rank's share of a
+// frame split over 8 GPUs) cuts every block's candidate ROWS into 2 or 4 parts.  Slots = compute units of the CURRENT device (a CPX / DPX
+// partition has 32 / 128) x the workgroups a CU holds at the LDS footprint of the launch that would actually be issued -- the PART's window
+// (H + rows-per-part - 1 rows), not the whole one: 160 KiB of LDS, at most 8 workgroups of 256 threads; at 64x64 / +-64 that is 6 per CU in 4 parts
+// (23 KiB each), 5 in 2 parts (29 KiB), 3 whole (41 KiB).  Splitting costs a memset, a decode launch and re-staged window rows, so it is only done
+// where a block is a large piece of work -- W H (2 range + 1)^2 of at least 2^23 byte differences (32x32 / +-64 upwards; smaller blocks were
+// measured in round 5, profiles/r05_me_small_parts_ab.txt) -- and while the part-workgroups fit one round of those slots (4 parts) or 1.25 rounds
+// (2 parts): on 256 CUs at 64x64 / +-64 up to 384 blocks in 4 parts, up to 800 in 2 (measured: profiles/r03_me_shard_launches.txt, 255 / 510 / 1020 CTUs).
+static int me_parts(size_t n_blocks, int W, int H, int range)
+{
+	static const int forced = getenv("HEVCASM_ME_PARTS") ? atoi(getenv("HEVCASM_ME_PARTS")) : 0;    // measurement switch, read once per process
+	const int side = 2 * range + 1;
+	int parts = 1;
+	if (forced >= 1 && forced <= 8) parts = forced;
+	else if ((size_t)W * H * side * side >= ((size_t)1 << 23))
+	{
+		for (int p = 4; p >= 2 && parts == 1; p >>= 1)
+		{
+			int ws;
+			const size_t lds = me_lds_bytes(W, H, range, H + (side + p - 1) / p - 1, &ws);
+			const size_t per_cu = (160 * 1024) / ((lds + 1023) & ~(size_t)1023);
+			const size_t slots = (size_t)device_cus() * (per_cu < 1 ? 1 : per_cu > 8 ? 8 : per_cu);
+			if (p == 4 ? n_blocks * 4 <= slots : n_blocks * 2 * 4 <= slots * 5) parts = p;
+		}
+	}
+	while (parts > 1 && side < 8 * parts) --parts;              // every part gets candidate rows
+	return parts;
+}
+
 // launches the search (and, with several workgroups per block, the preset of the key slots before it and their decoding after it)
 template <bool FRAME>
 static int me_launch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, const uint32_t *src_off, const uint32_t *ref_off,
@@ -322,7 +329,7 @@ static int me_launch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *re
 	// the domain does not depend on the batch: a window must fit LDS whole, whether or not this launch cuts it into parts
 	const size_t lds_whole = me_lds_bytes(W, H, range, H + 2 * range, &win_stride);
 	if (lds_whole > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	const int parts = me_parts(n_blocks, W, H, range, lds_whole);
+	const int parts = me_parts(n_blocks, W, H, range);
 	const int per = (2 * range + 1 + parts - 1) / parts;             // candidate rows per workgroup
 	const size_t shmem = me_lds_bytes(W, H, range, H + per - 1, &win_stride);
 	if (parts > 1) HEVC_HIP_TRY(hipMemsetAsync(result, 0xff, 12 * n_blocks, st));

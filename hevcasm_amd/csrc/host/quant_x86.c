@@ -44,9 +44,12 @@ TARGET_SSE41 int hevcasm_sse4_quantize(int16_t *dst, const int16_t *src, int sca
 	{
 		const __m128i v = _mm_loadu_si128((const __m128i *)(src + i));
 		const __m128i a = _mm_cvtepi16_epi32(v), b = _mm_cvtepi16_epi32(_mm_srli_si128(v, 8));
-		/* |x| in 32 bits (32768 for -32768), (|x| scale + round) >> shift, sign restored */
-		const __m128i qa = _mm_sign_epi32(_mm_srai_epi32(_mm_add_epi32(_mm_mullo_epi32(_mm_abs_epi32(a), vs), vr), shift), a);
-		const __m128i qb = _mm_sign_epi32(_mm_srai_epi32(_mm_add_epi32(_mm_mullo_epi32(_mm_abs_epi32(b), vs), vr), shift), b);
+		/* |x| in 32 bits (32768 for -32768), (|x| scale + round) >> shift, then the sign by mask: (q ^ m) - m with m = x >> 31.  Not _mm_sign_epi32,
+		 * which returns 0 for x == 0 where the C path keeps +round >> shift (non-zero once offset >= 0x10000: outside the reference's asserted
+		 * domain, quantize.c:163, but this entry has no assert and must still equal the C path there) */
+		const __m128i ma = _mm_srai_epi32(a, 31), mb = _mm_srai_epi32(b, 31);
+		const __m128i qa = _mm_sub_epi32(_mm_xor_si128(_mm_srai_epi32(_mm_add_epi32(_mm_mullo_epi32(_mm_abs_epi32(a), vs), vr), shift), ma), ma);
+		const __m128i qb = _mm_sub_epi32(_mm_xor_si128(_mm_srai_epi32(_mm_add_epi32(_mm_mullo_epi32(_mm_abs_epi32(b), vs), vr), shift), mb), mb);
 		const __m128i q = _mm_packs_epi32(qa, qb);
 		any = _mm_or_si128(any, q);
 		_mm_storeu_si128((__m128i *)(dst + i), q);

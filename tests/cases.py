@@ -120,18 +120,54 @@ def pred_bi_cases(n=16, seed=400, sizes=None):
     return out
 
 
-def _wrap14(c):
+def _wrap14(c, positive=(1, 3, 4, 6), period=8):
     """Reference planes on which the 14-bit intermediate of bi-prediction leaves int16: 255 under the positive taps of the half-pel filter and 0
     under the negative ones in BOTH directions (and the complement in the negative rows), so that the second-pass sum >> 6 reaches 33 150.  The
-    reference stores it into an int16_t (pred_inter.c:125), i.e. it WRAPS; an implementation that saturates, or keeps 32 bits, differs here."""
-    positive = (1, 3, 4, 6)
+    reference stores it into an int16_t (pred_inter.c:125), i.e. it WRAPS; an implementation that saturates, or keeps 32 bits, differs here.
+    positive / period: which sample positions (mod period) sit under positive taps -- (1, 3, 4, 6) mod 8 for the luma half-pel filter
+    {-1, 4, -11, 40, 40, -11, 4, -1}; (1, 2) mod 4 for the chroma one {-4, 36, 36, -4}."""
     stride = c["stride_ref"]
     for r in (0, 1):
+        if "ref%d" % r not in c:
+            continue
         plane = c["ref%d" % r]
         idx = np.arange(plane.size)
         y, x = idx // stride, idx % stride
-        plane[:] = np.where(np.isin((x + 5 * r) % 8, positive) == np.isin((y + 3 * r) % 8, positive), 255, 0).astype(np.uint8)
+        plane[:] = np.where(np.isin((x + 5 * r) % period, positive) == np.isin((y + 3 * r) % period, positive), 255, 0).astype(np.uint8)
     return c
+
+
+def narrowing_cases(seed=1400):
+    """every place the reference's C path narrows a value (DESIGN.md section 2 has the table), driven past the narrow type
+    where that is reachable and to the extreme of its range where it is not.
+      pred_inter.c:125  `dst16[x] = a` (int -> int16_t): bi-prediction's second pass, luma: (88 * 22440 + 24 * 6120) >> 6 = 33150 > 32767 -- REACHABLE, wraps.
+                        Every luma bi PU size (each goes to one of four kernel variants), half-pel in both directions, on the planes that reach it.
+                        chroma: at most (74 * 18870 + 10 * 2550) >> 6 = 22216 -- unreachable; the same planes for the 4-tap filter reach that maximum.
+                        uni HV first pass (shift 0): at most 88 * 255 = 22440 (luma), 74 * 255 = 18870 (chroma) -- unreachable; same planes, extreme reached.
+      residual_decode.c:350 hevcasm_clip(int16_t x): pred + residual narrowed to int16_t before the clip.  |residual| <= (1862 * 32768 + 2048) >> 12 = 14896
+                        after the int16-clamped first pass (1862 = the largest column sum of |coefficients| of the 32-point matrix), so pred + residual
+                        <= 15151 -- unreachable; the all-+32767 / all--32768 / alternating coefficient blocks of inverse_cases() are the extremes.
+      residual_decode.c:631-634 (and the other sizes) forward passes store (sum + add) >> shift into int16_t without a clip -- REACHABLE: fwd_*_full / _max / _min.
+      quantize.c:176-183 abs(-32768) = 32768 in int (no narrowing), x * scale <= 32768 * 32767 fits int, Clip3 after the sign is dead code for shift >= 16
+                        ((32768 * 32767 + 2^26) >> 16 = 17407): q_*_min covers the extreme.
+      quantize.c:53-62  dequantisation clips to int16 -- REACHABLE: deq_*_full (32767 * 40 >> 5 = 40958).
+      ssd.c:43-55 / sad.c:47-60 / hadamard.c:76-111: int accumulators, maxima 266 M / 1.04 M / 8x8 SATD 130 560: no narrowing.
+      diff.c:45-54      int sum wraps past 33 024 bytes -- REACHABLE: ssdlin_wrap; frame_sse keeps rows below that and sums them in 64 bits."""
+    out = []
+    for i, (w, h) in enumerate(wl.PU_SIZES_BI):
+        if (w, h) != (16, 16):      # 16x16 is pred_bi_cases()'s bi8_wrap
+            out.append(("bi8_wrap_%dx%d" % (w, h), "pred_bi", _wrap14(wl.pred_case(8, w, h, 3, seed + i, bi=True, fracs=(2, 2), frame=(2 * max(w, 32), 2 * max(h, 32))))))
+    # half-pel on one reference only, and quarter-pel pairs: the wrap must come from the one reference that reaches it, whatever the other does
+    for j, (fa, fb) in enumerate((((2, 2), (0, 0)), ((2, 2), (1, 3)), ((3, 2), (2, 1)))):
+        c = wl.pred_case(8, 16, 8, 4, seed + 40 + j, bi=True, fracs=fa)
+        c["frac1"][:] = fb[0] | (fb[1] << 4)
+        out.append(("bi8_wrap_mixed_%d" % j, "pred_bi", _wrap14(c)))
+    for i, (w, h) in enumerate(((8, 8), (4, 16), (32, 32), (2, 4), (16, 4))):
+        out.append(("bi4_extreme_%dx%d" % (w, h), "pred_bi", _wrap14(wl.pred_case(4, w, h, 3, seed + 50 + i, bi=True, fracs=(4, 4)), positive=(1, 2), period=4)))
+        out.append(("uni4_extreme_%dx%d" % (w, h), "pred_uni", _wrap14(wl.pred_case(4, w, h, 3, seed + 60 + i, fracs=(4, 4)), positive=(1, 2), period=4)))
+    for i, (w, h) in enumerate(((8, 8), (16, 16), (64, 64), (12, 16), (4, 8))):
+        out.append(("uni8_extreme_%dx%d" % (w, h), "pred_uni", _wrap14(wl.pred_case(8, w, h, 3, seed + 70 + i, fracs=(2, 2), frame=(2 * max(w, 32), 2 * max(h, 32))))))
+    return out
 
 
 def inverse_cases(n=40, seed=500):
@@ -414,7 +450,7 @@ def frame_sse_cases(seed=1300):
 
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
-                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases)
+                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases)
 
 
 # ------------------------------------------------------------------------------------- runners

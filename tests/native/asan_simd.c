@@ -133,6 +133,11 @@ static void test_quant_and_costs(void)
 			const int qshift = 16 + (int)(rnd() % 12), off = (int)(rnd() % 0x8000);
 			const int ca = hevcasm_c_quantize(a, s, scale, qshift, off, n), cb = hevcasm_sse4_quantize(b, s, scale, qshift, off, n);
 			CHECK(!memcmp(a, b, 2 * (size_t)n) && ca == cb, "quant n %d kind %d cbf %d %d", n, kind, ca, cb);
+			/* zero coefficients under a rounding offset of 1.0 and more (outside the reference's asserted domain): the C path keeps
+			 * +((offset << (shift - 16)) >> shift) for x == 0, and so must the SIMD entry (a sign restored with _mm_sign_epi32 gave 0) */
+			for (int i = 0; i < n; i += 3) s[i] = 0;
+			const int ca2 = hevcasm_c_quantize(a, s, 16384, 20, 70000, n), cb2 = hevcasm_sse4_quantize(b, s, 16384, 20, 70000, n);
+			CHECK(!memcmp(a, b, 2 * (size_t)n) && ca2 == cb2 && a[0] == 1, "quant zero inputs, offset 70000: n %d kind %d first %d %d", n, kind, a[0], b[0]);
 			free(s); free(a); free(b);
 		}
 	for (int size = 4; size <= 64; size *= 2)

@@ -272,6 +272,16 @@ def test_quant_and_ssd_x86_simd_entries(oracle_lib):
     HEVC-style sweeps, src = -32768 (where the reference's own pabsw assembly differs from its C: SURVEY appendix A), full-range residuals."""
     _x86(capi.SSE41 | capi.AVX)
     _check_quant(capi.SSE41)
+    # zero inputs under a rounding offset >= 1.0 (ADVICE round 4): C path and SSE4.1 entry agree (both give +1 for x == 0 at offset 70000, shift 20)
+    src = np.zeros(64, dtype=np.int16)
+    src[1::2] = np.arange(-16, 16, dtype=np.int16)
+    outs = []
+    for mask in (capi.C_REF, capi.SSE41):
+        f = C.CFUNCTYPE(C.c_int, VP, VP, C.c_int, C.c_int, C.c_int, C.c_int)(_slot("hevcasm_populate_quantize", 1, 0, mask))
+        out = np.zeros_like(src)
+        cbf = f(_ptr(out), _ptr(src), 16384, 20, 70000, 64)
+        outs.append((out, cbf))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][0][0] == 1
     buf = (C.c_void_p * 5)()
     capi.lib().hevcasm_populate_ssd(buf, capi.AVX)
     assert [bool(v) for v in buf] == [False, False, True, True, True]        # reference ssd.c:80-85
