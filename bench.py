@@ -259,7 +259,9 @@ def flatten_families(rows):
         out[key + "_gbs"] = r["gbs"]
         out[key + "_ms"] = r["ms"]
         out[key + "_mblocks"] = r["mblocks_per_s"]
-        if key in PRED_LANE_OPS_PER_PIXEL:
+        # the lane-operation counts are counter readings of the kernels the DEFAULT launcher picks: with any prediction switch (or another build of the
+        # library) in the environment a different kernel may run, and the figure would be silently wrong -- it is then left out
+        if key in PRED_LANE_OPS_PER_PIXEL and not any(k.startswith("HEVCASM_PRED_") or k in ("HEVCASM_HIP_LIB", "HEVCASM_HFIRST_AHEAD") for k in os.environ):
             out[key + "_valu_frac"] = round(r["mblocks_per_s"] * 1e6 * 256 * PRED_LANE_OPS_PER_PIXEL[key] / VALU_PEAK_LANE_OPS, 4)
     return out
 

@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 import bench
 from hevcasm_amd import workload as wl
@@ -291,3 +292,26 @@ def test_me5_line_is_compact(tmp_path):
     for k in ("me_split", "ctus_per_rank", "slowest_rank_ms"):
         assert k in line["config"]
     assert line["roofline"]["traffic"] is None and line["cpu_baseline"]["mismatches"] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["sad", "me5"])
+def test_bench_gpus_2_end_to_end_on_one_device(workload):
+    """`python bench.py --gpus 2` with no launcher around it, on the one GPU of the test box (both ranks on cuda:0, gloo for the barrier / max: the rehearsal
+    mode): the real measurement path of both workloads -- ranks started as a child, barrier + synchronize brackets, max over ranks, rank 0's one compact line."""
+    import subprocess, sys
+    env = dict(os.environ, HEVCASM_BENCH_ONE_DEVICE="1", HEVCASM_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--cpu-seconds", "2", "--cpu-procs", "2"]
+    argv += ["--blocks", "16384", "--sizes", "16x16,64x64", "--no-families"] if workload == "sad" else ["--workload", "me5"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv + ["--full-out", os.devnull], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096, out.stdout[-2000:]
+    line = _strict_loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0 and line["roofline"]["frac"] > 0
+    if workload == "me5":
+        assert line["scaling"] == "strong" and line["config"]["ctus_per_rank"] == 1020 and line["config"]["me_split"] == "ctus"
+        assert line["valid"] in (True, None) and (line["cpu_baseline"] is None or line["cpu_baseline"]["mismatches"] == 0)
+    else:
+        assert line["scaling"] == "weak" and line["config"]["blocks_per_step_per_gpu"] == 4 * 16384

@@ -324,6 +324,19 @@ def bench_ssd_linear():
         out = torch.empty(n, dtype=torch.int32, device="cuda")
         ms = timed(lambda i: B.ssd_linear(a, b, off, off, size, out=out))
         report("ssd_linear", n, 2 * size + 12, ms, size="%d bytes" % size)
+    del a, b
+    torch.cuda.empty_cache()
+    # whole-frame SSE, 64-bit sums (hevcasm_hip_frame_sse_batch): frames inside planes with a 64-byte border, cold (two sets of planes alternate)
+    for (fw, fh, frames) in ((3840, 2160, 32), (1920, 1080, 128), (1920, 1080, 1), (3840, 2160, 1)):
+        stride = fw + 128
+        span = stride * fh
+        planes = [(wl.fill_u8(span * frames + 64, 510 + k, device="cuda"), wl.fill_u8(span * frames + 64, 520 + k, device="cuda")) for k in range(2)]
+        off = B.off32((np.arange(frames, dtype=np.int64) * span + 64).astype(np.uint32))
+        out = torch.empty(frames, dtype=torch.int64, device="cuda")
+        ms = timed(lambda i: B.frame_sse(planes[i % 2][0], stride, planes[i % 2][1], stride, off, off, fw, fh, out=out))
+        report("frame_sse", frames, 2 * fw * fh + 16, ms, size="%dx%d x%d" % (fw, fh, frames))
+        del planes
+        torch.cuda.empty_cache()
 
 
 def bench_subpel():

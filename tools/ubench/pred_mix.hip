@@ -17,20 +17,25 @@ template <> struct Vec<8> { typedef u32x2 T; };
 template <> struct Vec<16> { typedef u32x4 T; };
 template <int LB> struct __attribute__((packed, aligned(1))) UV { typename Vec<LB>::T v; };
 __device__ inline void put(uint8_t *p, u32x2 v, int) { *reinterpret_cast<u32x2 *>(p) = v; }
-__device__ inline void put(uint8_t *p, u32x4 v, int sb) { if (sb == 16) *reinterpret_cast<u32x4 *>(p) = v; else { u32x2 h; h.x = v.x; h.y = v.y; *reinterpret_cast<u32x2 *>(p) = h; } }
+__device__ inline void put(uint8_t *p, u32x4 v, int sb) { if (sb == 16) *reinterpret_cast<u32x4 *>(p) = v; else if (sb == 4) *reinterpret_cast<uint32_t *>(p) = v.x; else { u32x2 h; h.x = v.x; h.y = v.y; *reinterpret_cast<u32x2 *>(p) = h; } }
 __device__ inline uint32_t fold(u32x2 v) { return v.x + v.y; }
 __device__ inline uint32_t fold(u32x4 v) { return (v.x + v.y) ^ (v.z + v.w); }
 
-struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes, DS; };
-constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0, 0 };
-constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0, 0 };
+struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes, DS, split; };
+constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0, 0, 0 };
+constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0, 0, 0 };
 
 template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent, Geo g)
 {
 	const uint32_t nwg = gridDim.x, q = nwg / 8, r8 = nwg % 8, xcd = blockIdx.x % 8, k = blockIdx.x / 8;
 	const uint32_t wg = xcd * q + (xcd < r8 ? xcd : r8) + k;
 	const uint32_t wave = wg * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-	const uint32_t local = lane / L, j = lane % L;
+	const uint32_t local = lane / L;
+	uint32_t j = lane % L;
+	// split deal (pred_hfirst_bi8_kernel's): a PU's lanes are its 8-column strips of reference 0, then those of reference 1; each loads ITS reference's
+	// 16 window bytes per row and stores 4 of the strip's 8 output bytes
+	const uint32_t which = g.split ? j / (L / 2) : 0;
+	if (g.split) j %= L / 2;
 	uint32_t pu = wave * ppw + local;
 	const bool active = local < (uint32_t)ppw && pu < n;
 	if (pu >= n) pu = n - 1;
@@ -40,11 +45,12 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 	const int mvx1 = coherent ? -5 : (int)((h >> 3) % 17u) - 8, mvy1 = coherent ? 4 : (int)((h >> 12) % 17u) - 8;
 	typedef typename Vec<LB>::T V;
 	const int FW = g.FW, FH = g.FH, RS = g.RS, RH = g.RH, pitch = g.pitch ? g.pitch : LB, SB = g.store_bytes ? g.store_bytes : LB;
-	size_t ro = ((size_t)f * RH + 16 + by * H - g.before + mvy) * RS + 16 + bx * W - g.before + mvx + pitch * j;
+	size_t ro = ((size_t)f * RH + 16 + by * H - g.before + (which ? mvy1 : mvy)) * RS + 16 + bx * W - g.before + (which ? mvx1 : mvx) + pitch * j;
+	if (which) ref = ref1;
 	if (ALIGNED) ro &= ~(size_t)3;              // the aligned words around the lane's bytes (a real kernel then loads one dword more and realigns in registers)
 	const int DS = g.DS ? g.DS : FW;
-	const size_t dof = ((size_t)f * FH + by * H) * DS + bx * W + SB * j;
-	const bool stores = active && (int)j < W / SB;
+	const size_t dof = ((size_t)f * FH + by * H) * DS + bx * W + (g.split ? 8 * j + 4 * which : SB * j);
+	const bool stores = active && (g.split || (int)j < W / SB);
 	const int rows = H + g.margin, first_out = g.margin;
 	size_t ro1 = ((size_t)f * RH + 16 + by * H - g.before + mvy1) * RS + 16 + bx * W - g.before + mvx1 + pitch * j;
 	if (ALIGNED) ro1 &= ~(size_t)3;
@@ -93,7 +99,7 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> float run(int W, int H, int
 	const int per_row = FW / W, per_frame = per_row * (FH / H);
 	const uint32_t n = (uint32_t)per_frame * frames;
 	if (W % SB) return 0.f;
-	const int L = g.pitch ? W / pitch : (W + g.margin + LB - 1) / LB, ppw = 64 / L;
+	const int L = g.split ? 2 * (W / 8) : g.pitch ? W / pitch : (W + g.margin + LB - 1) / LB, ppw = 64 / L;
 	const uint32_t waves = (n + ppw - 1) / ppw, grid = (waves + 3) / 4;
 	hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
 	std::vector<float> ms;
@@ -110,7 +116,8 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> float run(int W, int H, int
 	float best = 1e9f, sum = 0;
 	for (float t : ms) { best = t < best ? t : best; sum += t; }
 	const double ld = (double)(W + g.margin) * (H + g.margin), st = (double)W * H;
-	const double bytes = (mode == 0 ? REFS * ld + st : mode == 1 ? REFS * ld : st) * n;
+	const int refs = g.split ? 2 : REFS;
+	const double bytes = (mode == 0 ? refs * ld + st : mode == 1 ? refs * ld : st) * n;
 	if (!g_quiet)
 	printf("%s %2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", g.margin == 7 ? "luma  " : g.pitch ? "chroma (strip deal)" : "chroma (stream deal)", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
 			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
@@ -128,11 +135,15 @@ int main(int argc, char **argv)
 	if (argc > 1 && argv[1][0] == 'l')
 	{
 		// bench.py's figures: the access patterns of its four 64-frame prediction rows WITHOUT arithmetic, on the box and in the run that measures the kernels
-		// (luma 16x16 uni / bi: the stream kernel's 8-byte byte-aligned lanes; chroma 8x8 Cb + Cr uni / bi: the strip kernel's word-aligned 16-byte lanes)
+		// (luma 16x16 uni: the stream kernel's 8-byte byte-aligned lanes; luma 16x16 bi: pred_hfirst_bi8_kernel's deal -- a lane per 8-column strip and reference,
+		// one 16-byte load per row at an 8-byte pitch, 16 rows in flight, 4-byte stores (the stream deal it was measured against until then no
+		// longer runs at that size; that one stays as luma16_bi_stream); chroma 8x8 Cb + Cr uni / bi: the strip kernel's word-aligned 16-byte lanes)
 		g_quiet = true;
 		Geo strip = kChroma; strip.pitch = 8; strip.store_bytes = 8;
+		Geo hfirst = kLuma; hfirst.pitch = 8; hfirst.store_bytes = 4; hfirst.split = 1;
 		printf("luma16_uni %.4f\n", run<8, 8, false>(16, 16, 64, 0, dst, ref));
-		printf("luma16_bi %.4f\n", run<8, 8, false, 2>(16, 16, 64, 0, dst, ref));
+		printf("luma16_bi %.4f\n", run<16, 16, false>(16, 16, 64, 0, dst, ref, 0, hfirst));
+		printf("luma16_bi_stream %.4f\n", run<8, 8, false, 2>(16, 16, 64, 0, dst, ref));
 		printf("chroma8_uni %.4f\n", run<4, 16, true>(8, 8, 128, 0, dst, ref, 0, strip));
 		printf("chroma8_bi %.4f\n", run<4, 16, true, 2>(8, 8, 128, 0, dst, ref, 0, strip));
 		return 0;
