@@ -60,14 +60,17 @@ __global__ __launch_bounds__(kThreads) void ssd_linear_kernel(
 //
 // A workgroup owns kThreads / LPR row slots and walks `rows_per_wg` rows of one frame; LPR lanes share a row, 16 bytes each
 // and LPR * 16 bytes apart, tail bytes one per lane.  Per chunk sum (a-b)^2 = sum a^2 + sum b^2 - 2 sum ab <= 16 * 255^2
-// (three v_dot4_u32_u8 per dword), added to a 64-bit lane total; wave total by __shfl_xor, one 64-bit atomic add per wave
-// into sse[i] (integer: the order does not matter).  HBM-bound: algorithmic bytes per frame = 2 * width * height + 8 + 8.
-template <int LPR>
+// (three v_dot4_u32_u8 per dword), added to a 64-bit lane total; wave totals by __shfl_xor, the four waves' through LDS, then ONE
+// 64-bit atomic add per workgroup into sse[i] (integer: the order does not matter).  The launcher keeps a frame to at most 128
+// workgroups: adds to one address are serialised at the memory side (4 320 of them -- a wave each, two rows a workgroup -- made a
+// single 4K frame take 64 us, profiles/r05_frame_sse.txt).  HBM-bound: algorithmic bytes per frame = 2 * width * height + 8 + 8.
+template <int LPR, bool SINGLE /* a row is at most LPR chunks: one per lane, so that the unrolled rows' loads are all issued before the first is used */>
 __global__ __launch_bounds__(kThreads) void frame_sse_kernel(
 	const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, const uint32_t *__restrict__ a_off, const uint32_t *__restrict__ b_off,
 	unsigned long long *__restrict__ sse, int64_t stride_a, int64_t stride_b, uint32_t width, uint32_t height, uint32_t rows_per_wg, uint32_t wgs_per_frame)
 {
 	constexpr uint32_t kSlots = kThreads / LPR;
+	__shared__ unsigned long long wave_total[kThreads / kWave];
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t frame = wg / wgs_per_frame;
 	const uint32_t row0 = (wg % wgs_per_frame) * rows_per_wg;
@@ -77,10 +80,11 @@ __global__ __launch_bounds__(kThreads) void frame_sse_kernel(
 	const uint32_t whole = width & ~15u;
 
 	unsigned long long total = 0;
+#pragma unroll 4
 	for (uint32_t y = row0 + slot; y < row1; y += kSlots)
 	{
 		const uint8_t *ra = pa + (int64_t)y * stride_a, *rb = pb + (int64_t)y * stride_b;
-		for (uint32_t o = 16 * lane; o < whole; o += 16 * LPR)
+		auto chunk = [&](uint32_t o)
 		{
 			Chunk<16> x, z;
 			x.load_stream(ra + o);   // both frames are read exactly once
@@ -94,7 +98,9 @@ __global__ __launch_bounds__(kThreads) void frame_sse_kernel(
 				ab = __builtin_amdgcn_udot4(x.d[k], z.d[k], ab, false);
 			}
 			total += sq - 2u * ab;
-		}
+		};
+		if constexpr (SINGLE) { if (16 * lane < whole) chunk(16 * lane); }
+		else for (uint32_t o = 16 * lane; o < whole; o += 16 * LPR) chunk(o);
 		if (whole + lane < width)    // LPR >= 16: one tail byte per lane
 		{
 			const int d = (int)ra[whole + lane] - (int)rb[whole + lane];
@@ -109,7 +115,15 @@ __global__ __launch_bounds__(kThreads) void frame_sse_kernel(
 		total += other;
 		lo = (uint32_t)total; hi = (uint32_t)(total >> 32);
 	}
-	if (threadIdx.x % kWave == 0 && total) atomicAdd(&sse[frame], total);
+	if (threadIdx.x % kWave == 0) wave_total[threadIdx.x / kWave] = total;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		unsigned long long t = 0;
+#pragma unroll
+		for (int w = 0; w < kThreads / kWave; ++w) t += wave_total[w];
+		if (t) atomicAdd(&sse[frame], t);
+	}
 }
 
 }  // namespace hevc
@@ -147,23 +161,26 @@ extern "C" int hevcasm_hip_frame_sse_batch(
 	hipStream_t st = as_stream(stream);
 	HEVC_HIP_TRY(hipMemsetAsync(sse, 0, 8 * n_frames, st));
 	if (width == 0 || height == 0) return 0;
-	// lanes per row: the smallest of 16 / 64 / 256 that covers the row's 16-byte chunks (a 4K row: 240 chunks on 256 lanes; 1080p: 120 on 2 x 64)
+	// lanes per row: the smallest of 16 / 64 / 128 / 256 that covers the row's 16-byte chunks (a 4K row: 240 chunks on 256 lanes; 1080p: 120 on 128)
 	const uint32_t chunks = ((uint32_t)width + 15) / 16;
-	const uint32_t lpr = chunks <= 16 ? 16 : chunks <= 128 ? 64 : 256;
+	const uint32_t lpr = chunks <= 16 ? 16 : chunks <= 64 ? 64 : chunks <= 128 ? 128 : 256;
 	const uint32_t slots = kThreads / lpr;
-	// rows per workgroup: whole rounds of the slots, few enough rounds that about 16 workgroups per CU share the frames
-	const size_t total_rounds = n_frames * (size_t)ceil_div((size_t)height, slots);
-	uint32_t rounds = (uint32_t)std::min<size_t>(64, std::max<size_t>(2, total_rounds / ((size_t)device_cus() * 16)));
+	// workgroups per frame: about 8 per CU over the whole batch (one resident generation), never more than 128 for one frame (one atomic add each, all to sse[i]) nor
+	// fewer rows than one round of the slots; a workgroup's rows are whole rounds of its slots
+	const size_t want = std::max<size_t>(1, std::min<size_t>(128, ((size_t)device_cus() * 8 + n_frames - 1) / n_frames));
+	const uint32_t rounds = std::max<uint32_t>(1, ceil_div(ceil_div((size_t)height, slots), want));
 	const uint32_t rows_per_wg = rounds * slots;
 	const uint32_t wgs_per_frame = ceil_div((size_t)height, rows_per_wg);
 	const size_t grid = n_frames * (size_t)wgs_per_frame;
 	if (grid > 0x7fffffffull) return set_error(HEVCASM_HIP_EINVAL, "batch too large for one launch");
 	unsigned long long *out = reinterpret_cast<unsigned long long *>(sse);
-#define HEVC_LAUNCH_SSE(L) hipLaunchKernelGGL(frame_sse_kernel<L>, dim3((uint32_t)grid), dim3(kThreads), 0, st, a, b, a_off, b_off, out, \
+#define HEVC_LAUNCH_SSE(L, S) hipLaunchKernelGGL((frame_sse_kernel<L, S>), dim3((uint32_t)grid), dim3(kThreads), 0, st, a, b, a_off, b_off, out, \
 	(int64_t)stride_a, (int64_t)stride_b, (uint32_t)width, (uint32_t)height, rows_per_wg, wgs_per_frame)
-	if (lpr == 16) HEVC_LAUNCH_SSE(16);
-	else if (lpr == 64) HEVC_LAUNCH_SSE(64);
-	else HEVC_LAUNCH_SSE(256);
+	if (lpr == 16) HEVC_LAUNCH_SSE(16, true);
+	else if (lpr == 64) HEVC_LAUNCH_SSE(64, true);
+	else if (lpr == 128) HEVC_LAUNCH_SSE(128, true);
+	else if (chunks <= 256) HEVC_LAUNCH_SSE(256, true);
+	else HEVC_LAUNCH_SSE(256, false);
 #undef HEVC_LAUNCH_SSE
 	return launch_status("frame_sse_kernel");
 }

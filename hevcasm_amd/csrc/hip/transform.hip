@@ -222,13 +222,8 @@ template <int N, bool DST> __device__ __forceinline__ void forward_1d(const int 
 
 template <int N> struct Tile
 {
-#ifdef HEVCASM_FWD_TILE_PAD      // round-5 A/B: row and tile strides chosen by a bank model so that two blocks of a 32-lane group never meet in a bank
-	static constexpr int S = N == 8 ? 16 : N == 16 ? 24 : N + 4;
-	static constexpr int HALFWORDS = N == 8 ? 140 : N == 16 ? 404 : N * S;
-#else
 	static constexpr int S = N + 4;             // row stride in halfwords
 	static constexpr int HALFWORDS = N * S;
-#endif
 };
 
 // lane-private row <-> registers, 8 bytes at a time (rows start 8-byte aligned: S is a multiple of 4)
@@ -317,12 +312,6 @@ template <int N> struct InverseTiles
 	static constexpr int DWORDS = ((P1_DWORDS > P2_DWORDS ? P1_DWORDS : P2_DWORDS) + 3) & ~3;
 };
 
-#ifdef HEVCASM_INV32_WIDE
-constexpr bool kInv32Wide = true;
-#else
-constexpr bool kInv32Wide = false;
-#endif
-
 template <int N, bool DST, bool DEQUANT>
 __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,   // dst may alias pred (in-place reconstruction): no __restrict__
@@ -349,21 +338,15 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// The add stage's lane deal (below: consecutive lanes hold the SAME row of consecutive blocks) is known now, so its
 	// offsets and prediction bytes are fetched now, behind the coefficients: where the add stage uses them they would be
 	// two more memory round trips at the very end of every workgroup.
-	// WIDE (round 5, N = 32, A/B): 16 lanes cover the 256 contiguous bytes of one prediction / destination row of the workgroup's 8 blocks (a lane: 16 bytes of
-	// rows rp and rp + 16) instead of 8 lanes of 32 bytes in two half-line instructions; the lane still TRANSFORMS one whole row (rp + 16 h, h = its half), so
-	// lane pairs swap half rows of prediction before the add and of result after it (quad_perm DPP).  Coefficients: the workgroup's 16 KiB run in
-	// (q * 256 + tid) * 16-byte pieces, every wave instruction 1 KiB of consecutive bytes.  tools/ubench/transform_mix.hip deal 2: -10 % on the pattern alone.
-	constexpr bool WIDE = kInv32Wide && N == 32;
-	const uint32_t hbit = WIDE ? threadIdx.x & 1 : 0, rp = threadIdx.x >> 4;
-	const uint32_t local2 = WIDE ? (threadIdx.x & 15) >> 1 : threadIdx.x % BPWG, t2 = WIDE ? rp + 16 * hbit : threadIdx.x / BPWG;
+	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
 	uint32_t blk2 = wg * BPWG + local2;
 	const bool live2 = blk2 < n_blocks;
 	if (!live2) blk2 = n_blocks - 1;
 	// (round 4: the workgroup's offsets by scalar loads + v_cndmask, as the SAD kernels fetch their descriptors, measured -5 ... +6 % by kernel and
 	// size, nothing on balance: profiles/r04_scalar_offsets_elsewhere_ab.txt -- these kernels run at the rate of their access mix)
 	const uint32_t po = pred_off[blk2], dof = dst_off[blk2];
-	const uint8_t *pp = WIDE ? pred + po + 16 * hbit + rp * stride_pred : pred + po + t2 * stride_pred;
-	uint8_t *d = WIDE ? dst + dof + 16 * hbit : dst + dof + t2 * stride_dst;
+	const uint8_t *pp = pred + po + t2 * stride_pred;
+	uint8_t *d = dst + dof + t2 * stride_dst;
 	constexpr int CB = N >= 16 ? 16 : N;
 	Chunk<CB> pr[N / CB];
 
@@ -373,57 +356,11 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// profiles/r04_transform_valu_trim_ab.txt -- that kernel is not VALU-bound and liked the older instruction mix better)
 	constexpr bool DEQ_OPSEL = DEQUANT && N == 32;
 	uint32_t raw[N / 2];
-	if constexpr (WIDE)
-	{
-		// piece (q, tid): block 2 q + tid / 128 of the workgroup, row (tid % 128) / 4, columns 8 (tid % 4) ... + 7 -- row and columns do not depend on q
+	if (DEQ_OPSEL) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
+	else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
 #pragma unroll
-		for (int q = 0; q < 4; ++q)
-		{
-			uint32_t b = wg * BPWG + 2 * q + (threadIdx.x >> 7);
-			if (b >= n_blocks) b = n_blocks - 1;
-			Chunk<16> c;
-			c.load(reinterpret_cast<const uint8_t *>(coeffs + (size_t)b * (N * N) + ((threadIdx.x & 127) >> 2) * N + (threadIdx.x & 3) * 8));
-#pragma unroll
-			for (int k = 0; k < 4; ++k) raw[4 * q + k] = c.d[k];
-		}
-		pr[0].load(pp);
-		pr[1].load(pp + 16 * stride_pred);
-	}
-	else
-	{
-		if (DEQ_OPSEL) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
-		else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
-#pragma unroll
-		for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
-	}
+	for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
 	__builtin_amdgcn_sched_barrier(0);
-	if constexpr (WIDE)
-	{
-		const uint32_t rb = kPairBytes.at[LOG2 - 2][(threadIdx.x & 127) >> 2];
-		typedef short s16x2v __attribute__((ext_vector_type(2)));
-		const int round = DEQUANT ? 1 << (shift - 1) : 0;
-#pragma unroll
-		for (int q = 0; q < 4; ++q)
-		{
-			int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(tiles + (2 * q + (threadIdx.x >> 7)) * T::DWORDS) + (rb >> 2) * (T::S1 * 4) + (rb & 2))
-			               + 2 * 8 * (threadIdx.x & 3);
-#pragma unroll
-			for (int k = 0; k < 4; ++k)
-			{
-				uint32_t two = raw[4 * q + k];
-				if (DEQUANT)
-				{
-					int lo, hi;
-					asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(lo) : "v"(two), "s"(scale), "v"(round));
-					asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(two), "s"(scale), "v"(round));
-					two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo >> shift, hi >> shift));
-				}
-				row[4 * k] = (int16_t)two;
-				row[4 * k + 2] = (int16_t)(two >> 16);
-			}
-		}
-	}
-	else
 	{
 		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
 		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
@@ -516,44 +453,7 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	// pred + residual stays inside int16.  Hence clip8(pred + ((w) >> 12)) == sat_u8((w + (pred << 12)) >> 12)
 	// (w already carries the rounding constant; adding a multiple of 4096 commutes with the shift),
 	// which is one v_lshl_add per pixel and one v_ashr_pk_u8_i32 per two pixels.
-	if constexpr (WIDE)
-	{
-		// this lane's row t2 = rp + 16 h: it loaded piece h of it (pr[h]); the partner lane (tid ^ 1) loaded the other piece, as its pr[h]
-		uint32_t full[8], res[8];
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			const uint32_t own = hbit ? pr[1].d[k] : pr[0].d[k], send = hbit ? pr[0].d[k] : pr[1].d[k];
-			const uint32_t recv = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, false);
-			full[k] = hbit ? recv : own;
-			full[4 + k] = hbit ? own : recv;
-		}
-#pragma unroll
-		for (int k = 0; k < 8; ++k)
-		{
-			int tt[4];
-#pragma unroll
-			for (int b = 0; b < 4; ++b) tt[b] = w[4 * k + b] + (int)(((full[k] >> (8 * b)) & 0xff) << 12);
-			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
-			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
-			res[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-		}
-		// the lane stores piece h of rows rp and rp + 16: its own row's piece h, and the partner's row's piece h (received)
-		Chunk<16> mine, theirs;
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			mine.d[k] = hbit ? res[4 + k] : res[k];
-			const uint32_t send = hbit ? res[k] : res[4 + k];
-			theirs.d[k] = (uint32_t)__builtin_amdgcn_mov_dpp((int)send, 0xb1, 0xf, 0xf, false);
-		}
-		if (live2)
-		{
-			mine.store(d + t2 * stride_dst);
-			theirs.store(d + (rp + 16 * (1 - hbit)) * stride_dst);
-		}
-	}
-	else if (live2)
+	if (live2)
 	{
 #pragma unroll
 		for (int q = 0; q < N / CB; ++q)
