@@ -221,6 +221,21 @@ def pred_intra(dst, neighbours, neighbour_stride, mode, packed, n):
     return dst
 
 
+def pred_intra_modes(dst, neighbours, neighbour_stride, modes, packed):
+    """One intra mode per block (modes: uint8 tensor, 0..34).  Mode 1 is pinned to the reference; the others follow H.265 8.4.4.2.4 / .6 (unpinned)."""
+    assert modes.dtype == torch.uint8 and modes.is_contiguous()
+    check(lib().hevcasm_hip_pred_intra_modes_batch(dst.data_ptr(), neighbours.data_ptr(), neighbour_stride, modes.data_ptr(), packed, modes.numel(), _stream()), "pred_intra_modes_batch")
+    return dst
+
+
+def intra_filter_neighbours(neighbours, neighbour_stride, log2n, strong, n, out=None, out_stride=129):
+    """H.265 8.4.4.2.3 (unpinned): the smoothed copies of n neighbour records, out_stride bytes apart."""
+    out = torch.zeros(out_stride * n, dtype=torch.uint8, device=neighbours.device) if out is None else out
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= out_stride * (n - 1) + 129
+    check(lib().hevcasm_hip_intra_filter_neighbours_batch(out.data_ptr(), out_stride, neighbours.data_ptr(), neighbour_stride, log2n, int(strong), n, _stream()), "intra_filter_neighbours_batch")
+    return out
+
+
 def ssd_linear(src0, src1, off0, off1, size, out=None):
     n = off0.numel()
     out = torch.empty(n, dtype=torch.int32, device=src0.device) if out is None else out

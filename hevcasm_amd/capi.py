@@ -44,6 +44,8 @@ HIP_API = {
     "hevcasm_hip_me_full_search_frame_rows": (_i, [_vp, _pd, _vp, _pd, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "hevcasm_hip_subpel_refine_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),
     "hevcasm_hip_pred_intra_batch": (_i, [_vp, _vp, _pd, _i, _i, _sz, _vp]),
+    "hevcasm_hip_pred_intra_modes_batch": (_i, [_vp, _vp, _pd, _vp, _i, _sz, _vp]),
+    "hevcasm_hip_intra_filter_neighbours_batch": (_i, [_vp, _pd, _vp, _pd, _i, _i, _sz, _vp]),
     "hevcasm_hip_ssd_linear_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_frame_sse_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
 }

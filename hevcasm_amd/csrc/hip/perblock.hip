@@ -329,6 +329,20 @@ void hevcasm_hip1_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int int
 	std::memcpy(dst, a.h<uint8_t>(d), (size_t)n * n);
 }
 
+// planar / angular: the record's 4N + 1 samples (bytes [64 - 2N, 64 + 2N) and the corner at [128])
+void hevcasm_hip1_pred_intra_any(uint8_t *dst, const uint8_t *neighbours, int intraPredMode, hevcasm_pred_intra_packed packed)
+{
+	const int n = 1 << ((packed >> 1) & 0x7f);
+	Arena &a = g_arena;
+	a.reset();
+	const size_t nb = a.take(144), d = a.take((size_t)n * n);
+	std::memcpy(a.h<uint8_t>(nb) + 64 - 2 * n, neighbours + 64 - 2 * n, 4 * (size_t)n);
+	a.h<uint8_t>(nb)[128] = neighbours[128];
+	Arena::check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 144, intraPredMode, packed, 1, a.stream), "pred_intra");
+	a.wait();
+	std::memcpy(dst, a.h<uint8_t>(d), (size_t)n * n);
+}
+
 int hevcasm_hip1_ssd_linear(const uint8_t *src0, const uint8_t *src1, int size)
 {
 	Arena &a = g_arena;

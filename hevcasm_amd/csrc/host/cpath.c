@@ -361,6 +361,52 @@ void hevcasm_c_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int intraP
 	}
 }
 
+/* ---- intra planar and angular (H.265 8.4.4.2.4, 8.4.4.2.6): NOT in the reference's C (it has them as f265 assembly for 4x4 / 8x8 only, which this
+ * toolchain cannot assemble), so unpinned: written from the text, on the reference's neighbour layout (left column up to neighbours[63], top row from
+ * neighbours[64], corner at neighbours[128]: f265/intra.asm:126-131).  Every sample is looked up where the text's ref[] array would hold it. ---------- */
+
+static const signed char intra_angle_of_mode[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const short intra_inverse_angle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+
+void hevcasm_c_pred_intra_planar(uint8_t *dst, const uint8_t *neighbours, int intraPredMode, hevcasm_pred_intra_packed packed)
+{
+	(void)intraPredMode;
+	const int log2n = (packed >> 1) & 0x7f, n = 1 << log2n;
+	const uint8_t *top = neighbours + 64, *left = neighbours + 63;
+	const int top_right = top[n], bottom_left = left[-n];
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x)
+			dst[y * n + x] = (uint8_t)(((n - 1 - x) * left[-y] + (x + 1) * top_right + (n - 1 - y) * top[x] + (y + 1) * bottom_left + n) >> (log2n + 1));
+}
+
+void hevcasm_c_pred_intra_angular(uint8_t *dst, const uint8_t *neighbours, int intraPredMode, hevcasm_pred_intra_packed packed)
+{
+	const int log2n = (packed >> 1) & 0x7f, n = 1 << log2n;
+	const int angle = intra_angle_of_mode[intraPredMode], vertical = intraPredMode >= 18;
+	const int inverse = angle < 0 ? intra_inverse_angle[intraPredMode - 11] : 0;
+	/* along[i], i >= 1: sample i - 1 of the edge the mode runs along (top for vertical modes); across[k]: sample k - 1 of the other edge; [0] = corner */
+	const uint8_t *top = neighbours + 64, *left = neighbours + 63;
+#define ALONG(i) ((i) == 0 ? neighbours[128] : vertical ? top[(i) - 1] : left[-((i) - 1)])
+#define ACROSS(k) ((k) == 0 ? neighbours[128] : vertical ? left[-((k) - 1)] : top[(k) - 1])
+#define REF(i) ((i) >= 0 ? ALONG(i) : ACROSS(((i) * inverse + 128) >> 8))
+	for (int v = 0; v < n; ++v)          /* distance from the edge the mode runs along */
+	{
+		const int shift = ((v + 1) * angle) >> 5, weight = ((v + 1) * angle) & 31;
+		for (int u = 0; u < n; ++u)
+		{
+			const int a = REF(u + shift + 1);
+			const int value = weight ? ((32 - weight) * a + weight * REF(u + shift + 2) + 16) >> 5 : a;
+			dst[vertical ? v * n + u : u * n + v] = (uint8_t)value;
+		}
+	}
+	if ((packed & 1) && angle == 0)      /* modes 10 / 26 of luma blocks below 32x32: half the gradient along the other edge onto the first row / column */
+		for (int v = 0; v < n; ++v)
+			dst[vertical ? v * n : v] = (uint8_t)clampi(ALONG(1) + ((ACROSS(v + 1) - neighbours[128]) >> 1), 0, 255);
+#undef REF
+#undef ACROSS
+#undef ALONG
+}
+
 /* ---- linear SSD (diff.c:45-54) ------------------------------------------------------------ */
 
 int hevcasm_c_ssd_linear(const uint8_t *src0, const uint8_t *src1, int size)

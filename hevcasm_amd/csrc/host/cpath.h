@@ -28,7 +28,7 @@ hevcasm_transform hevcasm_c_dst_4, hevcasm_c_dct_4, hevcasm_c_dct_8, hevcasm_c_d
 hevcasm_quantize_inverse hevcasm_c_quantize_inverse;
 hevcasm_quantize hevcasm_c_quantize;
 hevcasm_quantize_reconstruct hevcasm_c_quantize_reconstruct;
-hevcasm_pred_intra hevcasm_c_pred_intra_dc;
+hevcasm_pred_intra hevcasm_c_pred_intra_dc, hevcasm_c_pred_intra_planar, hevcasm_c_pred_intra_angular;
 hevcasm_ssd_linear hevcasm_c_ssd_linear;
 
 /* HEVC interpolation filter tap k of an n-tap filter at fractional position frac. */

@@ -36,7 +36,7 @@ hevcasm_transform hevcasm_hip1_dst_4, hevcasm_hip1_dct_4, hevcasm_hip1_dct_8, he
 hevcasm_quantize_inverse hevcasm_hip1_quantize_inverse;
 hevcasm_quantize hevcasm_hip1_quantize;
 hevcasm_quantize_reconstruct hevcasm_hip1_quantize_reconstruct;
-hevcasm_pred_intra hevcasm_hip1_pred_intra_dc;
+hevcasm_pred_intra hevcasm_hip1_pred_intra_dc, hevcasm_hip1_pred_intra_any;
 hevcasm_ssd_linear hevcasm_hip1_ssd_linear;
 
 #ifdef __cplusplus

@@ -1,6 +1,9 @@
 /*
  * pred_intra.c -- selector and self-test for intra prediction (reference pred_intra.c:113-139
- * and :143-227).  As in the reference only INTRA_DC is wired; every other slot stays NULL.
+ * and :143-227).  INTRA_DC is wired as in the reference.  The reference leaves the other 34 modes' slots NULL (it has them only as f265
+ * assembly for 4x4 / 8x8, never wired); here they are filled too -- planar and angular from H.265 8.4.4.2.4 / .6 (cpath.c; the GPU kernel
+ * behind the HIP bit) -- a superset of the reference's table, and the one part of this library with no reference C to pin it.
+ * The self-test prints the reference's rows only (DC).
  */
 #include "pred_intra.h"
 #include "cpath.h"
@@ -16,9 +19,17 @@ void hevcasm_populate_pred_intra(hevcasm_table_pred_intra *table, hevcasm_instru
 	hevcasm_pred_intra *dc = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) dc = hevcasm_c_pred_intra_dc;
 	if (mask & HEVCASM_HIP) dc = hevcasm_hip1_pred_intra_dc;
+	hevcasm_pred_intra *planar = 0, *angular = 0;
+	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) { planar = hevcasm_c_pred_intra_planar; angular = hevcasm_c_pred_intra_angular; }
+	if (mask & HEVCASM_HIP) planar = angular = hevcasm_hip1_pred_intra_any;
 	for (int log2 = 2; log2 <= 5; ++log2)
 		for (int cIdx = 0; cIdx < 2; ++cIdx)
-			*hevcasm_get_pred_intra(table, 1, hevcasm_pred_intra_pack(cIdx, log2)) = dc;
+		{
+			const hevcasm_pred_intra_packed packed = hevcasm_pred_intra_pack(cIdx, log2);
+			*hevcasm_get_pred_intra(table, 0, packed) = planar;
+			*hevcasm_get_pred_intra(table, 1, packed) = dc;
+			for (int mode = 2; mode < 35; ++mode) *hevcasm_get_pred_intra(table, mode, packed) = angular;
+		}
 }
 
 typedef struct

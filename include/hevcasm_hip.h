@@ -133,13 +133,33 @@ int hevcasm_hip_frame_sse_batch(
 
 /* Batched hevcasm_pred_intra (reference pred_intra.h:55; C body pred_intra.c:61-101).  Block i
  * receives neighbours + i * neighbour_stride as its `neighbours` argument (left column ending at
- * [63], top row starting at [64]; DC reads bytes [64 - N, 64 + N)) and writes the N x N bytes at
- * dst + i * N * N.  Any neighbour_stride is legal; with 2N the records pack back to back (only the
- * 2N bytes named above are ever read).  intraPredMode must be 1 (INTRA_DC: the only mode the reference implements);
- * packed as hevcasm_pred_intra_pack(): log2 size 2..5, bit 0 = edge filter (sizes below 32). */
+ * [63] -- sample (-1, y) = [63 - y] --, top row starting at [64], corner (-1, -1) at [128]: pred_intra.c:52-58, f265/intra.asm:126-131)
+ * and writes the N x N bytes at dst + i * N * N.  packed as hevcasm_pred_intra_pack(): log2 size 2..5, bit 0 = edge filter (luma below 32x32).
+ * intraPredMode 1 (INTRA_DC) is the reference's C and bit-identical to it; it reads bytes [64 - N, 64 + N) only, any neighbour_stride is legal
+ * and with 2N the records pack back to back.
+ * intraPredMode 0 (planar) and 2..34 (angular) have NO C in the reference (only f265 assembly for 4x4 / 8x8 that cannot be assembled here):
+ * they follow H.265 8.4.4.2.4 / 8.4.4.2.6 on the same layout, with bit 0 of `packed` also enabling the boundary smoothing of modes 10 and 26
+ * (the text's disableIntraBoundaryFilter == 0 && cIdx == 0 && nTbS < 32), and are checked against this repository's restatement of that text
+ * only -- parity UNPINNED.  They read bytes [64 - 2N, 64 + 2N) and [128] of a record: records of at least 129 bytes.  The neighbours are used
+ * as given: substitution of unavailable samples and the smoothing of 8.4.4.2.3 are the caller's (hevcasm_hip_intra_filter_neighbours_batch). */
 int hevcasm_hip_pred_intra_batch(
 	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
 	int intraPredMode, int packed, size_t n_blocks, void *stream);
+
+/* The same with one mode PER BLOCK (modes[i] in 0..34): what a frame's intra blocks of one size look like to an encoder's mode decision or a
+ * decoder's reconstruction wavefront.  Parity as above: mode 1 pinned, the others unpinned. */
+int hevcasm_hip_pred_intra_modes_batch(
+	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
+	const uint8_t *modes, int packed, size_t n_blocks, void *stream);
+
+/* H.265 8.4.4.2.3 for a batch: filtered[i] = the smoothed copy of record i's 4N + 1 samples, same layout (bytes [64 - 2N, 64 + 2N) and [128] of the
+ * output record are written; filtered_stride >= 129): [1 2 1] / 4 along both edges through the corner, end samples kept; with
+ * strong_intra_smoothing != 0, 32x32 blocks whose two edges are flat (|corner + end - 2 middle| < 8 both ways) take the bi-linear form instead.
+ * Whether a block uses the filtered or the plain record is the caller's decision (the text's filterFlag: mode and size; f265 passes a filter_flag
+ * the same way, f265/intra.asm:748-768).  UNPINNED like the modes above.  `filtered` must not overlap `neighbours`. */
+int hevcasm_hip_intra_filter_neighbours_batch(
+	uint8_t *filtered, ptrdiff_t filtered_stride, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
+	int log2TrafoSize, int strong_intra_smoothing, size_t n_blocks, void *stream);
 
 /* ---- inter prediction ----------------------------------------------------------------- */
 

@@ -601,11 +601,147 @@ void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed)
 		for (int x = start; x < nTbS; ++x) dst[x + y * nTbS] = (uint8_t)dcVal;
 }
 
+/* ---- intra prediction beyond DC: PARITY UNPINNED -----------------------------------------------------------------------
+ * The reference wires INTRA_DC only (pred_intra.c:113-139); planar and the 33 angular modes exist there as f265 assembly for
+ * 4x4 and 8x8 (f265/intra.asm:216-1394), which cannot be assembled in this image, and the reference holds no vectors for them.
+ * What follows restates ITU-T H.265 (04/2013) 8.4.4.2.3 (neighbour filtering), 8.4.4.2.4 (planar) and 8.4.4.2.6 (angular) as
+ * the text has them, on the reference's neighbour layout (pred_intra.c:52-58 and f265/intra.asm:126-131: p[-1][y] =
+ * neighbours[63 - y], p[x][-1] = neighbours[64 + x], p[-1][-1] = neighbours[128]) and with the reference's packed argument
+ * (bit 0 = "edge" = cIdx == 0 && nTbS < 32, which is also the text's condition for the boundary smoothing of modes 10 and 26
+ * with disableIntraBoundaryFilter == 0).  The constants agree with the asm's tables (intra_angle 2 5 9 13 17 21 26 at
+ * intra.asm:78-84, inv_angle 256 315 390 482 630 910 1638 at :68-74).  Only mode 1 is pinned by the reference's C. */
+static int intra_p(const uint8_t *nb, int x, int y)      /* p[x][y] with x == -1 or y == -1 */
+{
+	if (x < 0 && y < 0) return nb[128];
+	return y < 0 ? nb[64 + x] : nb[63 - y];
+}
+
+static const int8_t kIntraPredAngle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
+static const int16_t kInvAngle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };   /* modes 11..25 */
+
+/* 8.4.4.2.4 */
+void orc_pred_intra_planar(uint8_t *dst, const uint8_t *nb, int packed)
+{
+	const int k = (packed >> 1) & 0x7f, n = 1 << k;
+	for (int y = 0; y < n; ++y)
+		for (int x = 0; x < n; ++x)
+			dst[x + y * n] = (uint8_t)(((n - 1 - x) * intra_p(nb, -1, y) + (x + 1) * intra_p(nb, n, -1) + (n - 1 - y) * intra_p(nb, x, -1) + (y + 1) * intra_p(nb, -1, n) + n) >> (k + 1));
+}
+
+/* 8.4.4.2.6, predModeIntra 2..34 */
+void orc_pred_intra_angular(uint8_t *dst, const uint8_t *nb, int mode, int packed)
+{
+	const int k = (packed >> 1) & 0x7f, n = 1 << k, edge = packed & 1;
+	const int angle = kIntraPredAngle[mode];
+	int refbuf[32 + 64 + 1], *ref = refbuf + 32;      /* ref[-nTbS .. 2 nTbS] */
+	for (int i = 0; i < 32 + 64 + 1; ++i) refbuf[i] = 0;
+	if (mode >= 18)
+	{
+		for (int x = 0; x <= n; ++x) ref[x] = intra_p(nb, -1 + x, -1);
+		if (angle < 0)
+		{
+			const int inv = kInvAngle[mode - 11];
+			if (((n * angle) >> 5) < -1)
+				for (int x = (n * angle) >> 5; x <= -1; ++x) ref[x] = intra_p(nb, -1, -1 + ((x * inv + 128) >> 8));
+		}
+		else
+			for (int x = n + 1; x <= 2 * n; ++x) ref[x] = intra_p(nb, -1 + x, -1);
+		for (int y = 0; y < n; ++y)
+		{
+			const int iIdx = ((y + 1) * angle) >> 5, iFact = ((y + 1) * angle) & 31;
+			for (int x = 0; x < n; ++x)
+				dst[x + y * n] = (uint8_t)(iFact ? ((32 - iFact) * ref[x + iIdx + 1] + iFact * ref[x + iIdx + 2] + 16) >> 5 : ref[x + iIdx + 1]);
+		}
+		if (mode == 26 && edge)
+			for (int y = 0; y < n; ++y)
+			{
+				const int v = intra_p(nb, 0, -1) + ((intra_p(nb, -1, y) - intra_p(nb, -1, -1)) >> 1);
+				dst[y * n] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+			}
+	}
+	else
+	{
+		for (int x = 0; x <= n; ++x) ref[x] = intra_p(nb, -1, -1 + x);
+		if (angle < 0)
+		{
+			const int inv = kInvAngle[mode - 11];
+			if (((n * angle) >> 5) < -1)
+				for (int x = (n * angle) >> 5; x <= -1; ++x) ref[x] = intra_p(nb, -1 + ((x * inv + 128) >> 8), -1);
+		}
+		else
+			for (int x = n + 1; x <= 2 * n; ++x) ref[x] = intra_p(nb, -1, -1 + x);
+		for (int y = 0; y < n; ++y)
+			for (int x = 0; x < n; ++x)
+			{
+				const int iIdx = ((x + 1) * angle) >> 5, iFact = ((x + 1) * angle) & 31;
+				dst[x + y * n] = (uint8_t)(iFact ? ((32 - iFact) * ref[y + iIdx + 1] + iFact * ref[y + iIdx + 2] + 16) >> 5 : ref[y + iIdx + 1]);
+			}
+		if (mode == 10 && edge)
+			for (int x = 0; x < n; ++x)
+			{
+				const int v = intra_p(nb, -1, 0) + ((intra_p(nb, x, -1) - intra_p(nb, -1, -1)) >> 1);
+				dst[x] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+			}
+	}
+}
+
+void orc_pred_intra(uint8_t *dst, const uint8_t *nb, int mode, int packed)
+{
+	if (mode == 0) orc_pred_intra_planar(dst, nb, packed);
+	else if (mode == 1) orc_pred_intra_dc(dst, nb, packed);
+	else if (mode >= 2 && mode <= 34) orc_pred_intra_angular(dst, nb, mode, packed);
+}
+
+/* one mode for the whole batch (the reference function's argument); modes != NULL: one mode per block */
 void orc_pred_intra_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int intraPredMode, int packed, size_t n)
 {
 	const int size = 1 << ((packed >> 1) & 0x7f);
-	if (intraPredMode != 1) return;   /* pred_intra.c:113-139: no other mode is wired */
-	for (size_t i = 0; i < n; ++i) orc_pred_intra_dc(dst + i * size * size, neighbours + (ptrdiff_t)i * neighbour_stride, packed);
+	for (size_t i = 0; i < n; ++i) orc_pred_intra(dst + i * size * size, neighbours + (ptrdiff_t)i * neighbour_stride, intraPredMode, packed);
+}
+
+void orc_pred_intra_modes_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, const uint8_t *modes, int packed, size_t n)
+{
+	const int size = 1 << ((packed >> 1) & 0x7f);
+	for (size_t i = 0; i < n; ++i) orc_pred_intra(dst + i * size * size, neighbours + (ptrdiff_t)i * neighbour_stride, modes[i], packed);
+}
+
+/* 8.4.4.2.3: the filtered neighbour array pF of one block (same layout as p; bytes outside the 4 nTbS + 1 samples are copied unchanged where both
+ * records hold them).  strong != 0: strong_intra_smoothing_enabled_flag; the bi-linear form then applies to 32x32 blocks whose two edges are flat
+ * (|p[-1][-1] + p[nTbS*2-1][-1] - 2 p[nTbS-1][-1]| < 1 << (BitDepth - 5), and the same down the left).  WHETHER a block's neighbours are filtered at all
+ * (filterFlag: mode and size) is the caller's decision, as in f265 (intra.asm:748-768 takes a filter_flag). */
+void orc_intra_filter_neighbours(uint8_t *out, const uint8_t *nb, int log2, int strong)
+{
+	const int n = 1 << log2;
+	int biInt = 0;
+	if (strong && n == 32)
+	{
+		const int a = intra_p(nb, -1, -1) + intra_p(nb, 2 * n - 1, -1) - 2 * intra_p(nb, n - 1, -1);
+		const int b = intra_p(nb, -1, -1) + intra_p(nb, -1, 2 * n - 1) - 2 * intra_p(nb, -1, n - 1);
+		biInt = (a < 0 ? -a : a) < (1 << (8 - 5)) && (b < 0 ? -b : b) < (1 << (8 - 5));
+	}
+	out[128] = biInt ? nb[128] : (uint8_t)((intra_p(nb, -1, 0) + 2 * intra_p(nb, -1, -1) + intra_p(nb, 0, -1) + 2) >> 2);
+	for (int i = 0; i < 2 * n; ++i)
+	{
+		int left, top;
+		if (i == 2 * n - 1) { left = intra_p(nb, -1, i); top = intra_p(nb, i, -1); }
+		else if (biInt)
+		{
+			left = ((63 - i) * intra_p(nb, -1, -1) + (i + 1) * intra_p(nb, -1, 63) + 32) >> 6;
+			top = ((63 - i) * intra_p(nb, -1, -1) + (i + 1) * intra_p(nb, 63, -1) + 32) >> 6;
+		}
+		else
+		{
+			left = (intra_p(nb, -1, i + 1) + 2 * intra_p(nb, -1, i) + intra_p(nb, -1, i - 1) + 2) >> 2;
+			top = (intra_p(nb, i + 1, -1) + 2 * intra_p(nb, i, -1) + intra_p(nb, i - 1, -1) + 2) >> 2;
+		}
+		out[63 - i] = (uint8_t)left;
+		out[64 + i] = (uint8_t)top;
+	}
+}
+
+void orc_intra_filter_neighbours_batch(uint8_t *out, ptrdiff_t out_stride, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int log2, int strong, size_t n)
+{
+	for (size_t i = 0; i < n; ++i) orc_intra_filter_neighbours(out + (ptrdiff_t)i * out_stride, neighbours + (ptrdiff_t)i * neighbour_stride, log2, strong);
 }
 
 /* diff.c:45-54 (unsigned accumulation: same bits as the reference's int, no UB past 2^31) */

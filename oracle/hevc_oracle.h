@@ -114,6 +114,10 @@ void orc_subpel_refine(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *
 /* pred_intra.h:55; INTRA_DC body pred_intra.c:61-101 (sample addressing pred_intra.c:52-58) */
 void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed);
 void orc_pred_intra_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int intraPredMode, int packed, size_t n);
+/* parity UNPINNED beyond mode 1 (H.265 8.4.4.2.3-6 restated; the reference has these modes only as assembly): see hevc_oracle.c */
+void orc_pred_intra(uint8_t *dst, const uint8_t *nb, int mode, int packed);
+void orc_pred_intra_modes_batch(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, const uint8_t *modes, int packed, size_t n);
+void orc_intra_filter_neighbours_batch(uint8_t *out, ptrdiff_t out_stride, const uint8_t *neighbours, ptrdiff_t neighbour_stride, int log2, int strong, size_t n);
 
 /* diff.h:52; diff.c:45-54 */
 int orc_ssd_linear(const uint8_t *p1, const uint8_t *p2, int n);

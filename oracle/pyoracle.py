@@ -192,6 +192,23 @@ def pred_intra_batch(neighbours, neighbour_stride, mode, packed, n):
     return dst
 
 
+def pred_intra_modes_batch(neighbours, neighbour_stride, modes, packed):
+    """UNPINNED beyond mode 1: H.265 8.4.4.2.4-6 restated (oracle/hevc_oracle.c)."""
+    neighbours, modes = _u8(neighbours), _u8(modes)
+    size = 1 << ((packed >> 1) & 0x7f)
+    dst = np.zeros(modes.size * size * size, dtype=np.uint8)
+    lib().orc_pred_intra_modes_batch(_p(dst), _p(neighbours), C.c_ssize_t(neighbour_stride), _p(modes), C.c_int(packed), C.c_size_t(modes.size))
+    return dst
+
+
+def intra_filter_neighbours_batch(neighbours, neighbour_stride, log2, strong, n, out_stride=129):
+    """UNPINNED: H.265 8.4.4.2.3 restated."""
+    neighbours = _u8(neighbours)
+    out = np.zeros(out_stride * n, dtype=np.uint8)
+    lib().orc_intra_filter_neighbours_batch(_p(out), C.c_ssize_t(out_stride), _p(neighbours), C.c_ssize_t(neighbour_stride), C.c_int(log2), C.c_int(strong), C.c_size_t(n))
+    return out
+
+
 def ssd_linear_batch(src0, src1, off0, off1, size):
     src0, src1, off0, off1 = _u8(src0), _u8(src1), _u32(off0), _u32(off1)
     out = np.empty(off0.size, dtype=np.int32)

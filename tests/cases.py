@@ -448,6 +448,52 @@ def frame_sse_cases(seed=1300):
     return out
 
 
+def intra_modes_cases(seed=1500):
+    """UNPINNED (no reference C beyond DC): every size x both packings x every mode 0..34 as a one-mode batch; per-block mode arrays (all modes mixed, so that
+    neighbouring lanes of a wave run different modes); records 129, 160 and 144 bytes apart; extremes (0 / 255 alternating: both ends of every blend)."""
+    out = []
+    rng = np.random.default_rng(seed)
+    for log2 in (2, 3, 4, 5):
+        for c_idx in (1, 0):
+            if c_idx == 0 and log2 == 5:
+                continue
+            packed = (8 << 8) | (log2 << 1) | (1 if c_idx == 0 else 0)
+            tag = "%d%s" % (1 << log2, "_edge" if packed & 1 else "")
+            for stride, n in ((129, 70), (160, 9)):
+                nb = wl.fill_u8(stride * n + 64, seed + 8 * log2 + c_idx + stride)
+                out.append(("intra_mixed_%s_s%d" % (tag, stride), "intra_modes", dict(neighbours=nb, neighbour_stride=stride, modes=rng.integers(0, 35, n).astype(np.uint8), packed=packed)))
+            nb = wl.fill_u8(144 * 35 * 3 + 64, seed + 99 + log2)
+            out.append(("intra_every_mode_%s" % tag, "intra_modes", dict(neighbours=nb, neighbour_stride=144, modes=np.repeat(np.arange(35, dtype=np.uint8), 3), packed=packed)))
+            ext = np.where(np.arange(129 * 35) % 2, 255, 0).astype(np.uint8)
+            out.append(("intra_extremes_%s" % tag, "intra_modes", dict(neighbours=ext, neighbour_stride=129, modes=np.arange(35, dtype=np.uint8), packed=packed)))
+            for mode in (0, 2, 10, 18, 26, 34, 11, 25):
+                out.append(("intra_mode%d_%s" % (mode, tag), "intra", dict(neighbours=wl.fill_u8(129 * 21 + 64, seed + mode + log2), neighbour_stride=129, mode=mode, packed=packed, n=21)))
+    return out
+
+
+def intra_filter_cases(seed=1600):
+    """UNPINNED: H.265 8.4.4.2.3 -- every size, plain and with strong smoothing enabled; 32x32 records with flat edges (bi-linear form), with one flat and one
+    busy edge, and random ones (never flat)."""
+    out = []
+    for log2 in (2, 3, 4, 5):
+        for strong in (0, 1):
+            n = 40
+            nb = wl.fill_u8(160 * n + 64, seed + log2)
+            if log2 == 5:
+                rec = nb[: 160 * n].reshape(n, 160)
+                ramp = (np.arange(64) // 9).astype(np.uint8)
+                rec[0:10, 64:128] = 100 + ramp          # flat top
+                rec[0:10, 0:64] = 100 + ramp[::-1]      # flat left (runs upwards)
+                rec[0:10, 128] = 100
+                rec[10:20, 64:128] = 50 + ramp          # flat top only
+                rec[10:20, 128] = 50
+            out.append(("intra_filter_%d_strong%d" % (1 << log2, strong), "intra_filter", dict(neighbours=nb, neighbour_stride=160, log2=log2, strong=strong, n=n)))
+    return out
+
+
+# families the reference has no C for: checked against the oracle's restatement of H.265 only (tests/test_intra_modes.py), never part of the golden fixtures
+UNPINNED_CASE_LISTS = dict(intra_modes=intra_modes_cases, intra_filter=intra_filter_cases)
+
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
                       intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases)
@@ -501,6 +547,10 @@ def _run_cpu(api, family, c):
         return (api.ssd_linear_batch(c["src0"], c["src1"], c["off0"], c["off1"], c["size"]),)
     if family == "frame_sse":
         return (api.frame_sse_batch(c["a"], c["stride_a"], c["b"], c["stride_b"], c["a_off"], c["b_off"], c["width"], c["height"]),)
+    if family == "intra_modes":
+        return (api.pred_intra_modes_batch(c["neighbours"], c["neighbour_stride"], c["modes"], c["packed"]),)
+    if family == "intra_filter":
+        return (_filter_samples(api.intra_filter_neighbours_batch(c["neighbours"], c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=136), 136, c["log2"], c["n"]),)
     raise ValueError(family)
 
 
@@ -571,7 +621,28 @@ def run_hip(family, c):
         return (cpu(B.ssd_linear(u8(c["src0"]), u8(c["src1"]), off(c["off0"]), off(c["off1"]), c["size"])),)
     if family == "frame_sse":
         return (cpu(B.frame_sse(u8(c["a"]), c["stride_a"], u8(c["b"]), c["stride_b"], off(c["a_off"]), off(c["b_off"]), c["width"], c["height"])),)
+    if family == "intra_modes":
+        size = 1 << ((c["packed"] >> 1) & 0x7f)
+        return (cpu(B.pred_intra_modes(plane(c["modes"].size * size * size), u8(c["neighbours"]), c["neighbour_stride"], u8(c["modes"]), c["packed"])),)
+    if family == "intra_filter":
+        full = cpu(B.intra_filter_neighbours(u8(c["neighbours"]), c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=136))
+        kept = _filter_samples(full, 136, c["log2"], c["n"])
+        mask = np.ones(full.size, dtype=bool)
+        mask[_filter_sample_index(136, c["log2"], c["n"]).reshape(-1)] = False
+        assert not full[mask].any(), "the filter kernel wrote outside the 4N + 1 samples of its records"
+        return (kept,)
     raise ValueError(family)
+
+
+def _filter_sample_index(stride, log2, n):
+    """Byte positions of the 4N + 1 samples of each of n records (bytes [64 - 2N, 64 + 2N) and [128])."""
+    size = 1 << log2
+    one = np.concatenate([np.arange(64 - 2 * size, 64 + 2 * size), [128]])
+    return np.arange(n)[:, None] * stride + one[None, :]
+
+
+def _filter_samples(buf, stride, log2, n):
+    return np.asarray(buf)[_filter_sample_index(stride, log2, n)]
 
 
 def _only_blocks(buf, stride, off, w, h):

@@ -314,6 +314,28 @@ def bench_intra():
                 torch.cuda.empty_cache()
 
 
+def bench_intra_modes():
+    """SURVEY 8f-3 beyond DC (unpinned): 2^26 output pixels per launch, 144-byte records; one mode for the batch (planar, pure vertical, a positive and a negative
+    angle from each family) and one random mode per block."""
+    for log2 in (2, 3, 4, 5):
+        size = 1 << log2
+        nb = (1 << 26) >> (2 * log2)
+        neigh = wl.fill_u8(144 * nb + 128, 450 + log2, device="cuda")
+        dst = torch.empty(nb * size * size, dtype=torch.uint8, device="cuda")
+        packed = (8 << 8) | (log2 << 1) | (1 if log2 < 5 else 0)
+        for mode in (0, 26, 30, 21, 6, 14):
+            ms = timed(lambda i: B.pred_intra(dst, neigh, 144, mode, packed, nb))
+            report("pred_intra_mode%d" % mode, nb, size * size + 4 * size + 1, ms, size="%dx%d" % (size, size))
+        modes = B.u8(np.random.default_rng(log2).integers(0, 35, nb).astype(np.uint8))
+        ms = timed(lambda i: B.pred_intra_modes(dst, neigh, 144, modes, packed))
+        report("pred_intra_modes (random per block)", nb, size * size + 4 * size + 2, ms, size="%dx%d" % (size, size))
+        filt = torch.zeros(144 * nb, dtype=torch.uint8, device="cuda")
+        ms = timed(lambda i: B.intra_filter_neighbours(neigh, 144, log2, 1, nb, out=filt, out_stride=144))
+        report("intra_filter_neighbours", nb, 2 * (4 * size + 1), ms, size="%dx%d" % (size, size))
+        del neigh, dst, modes, filt
+        torch.cuda.empty_cache()
+
+
 def bench_ssd_linear():
     """linear SSD, 2 x 256 MiB per launch cut into runs of `size` bytes (whole-frame PSNR = sum of rows)."""
     total = 1 << 28
@@ -412,4 +434,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, predlat=bench_pred_latency, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
