@@ -101,94 +101,190 @@ __global__ __launch_bounds__(kThreads) void pred_intra_dc_kernel(
 __constant__ int8_t kIntraAngle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
 __constant__ int16_t kIntraInvAngle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
 
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
+{
+	uint32_t r;
+	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+	return r;
+}
+__device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, uint32_t sh)
+{
+	uint32_t r;
+	asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh | (sh << 16)), "v"(a));     // the shift count is packed too: one per half
+	return r;
+}
+
+// Second form (round 5).  Everything angular is computed in FAMILY space: a horizontal mode m is the transpose of the vertical mode 36 - m on swapped
+// edges, so the staging step puts the edge the mode runs along ("main": top for modes 18..34, left for 2..17) into ref[] and the kernel always filters
+// along it; a lane owns 16 family-space bytes = R rows of L = min(N, 16) pixels, each row one (iIdx, iFact): L + 1 consecutive ref bytes come out of LDS
+// as aligned dwords + v_alignbyte, and the blend ((32 - f) a + f b + 16) >> 5 runs on even / odd bytes with v_pk_mad_u16 (11 instructions per 4 pixels;
+// f = 0 gives a exactly, so no branch).  Vertical modes store the 16 bytes as they are; horizontal modes scatter them transposed into an LDS tile and
+// read their row-major 16 bytes back.  Planar and DC stay per pixel (few operations each).
 template <int N>
 __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	uint8_t *__restrict__ dst, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride,
-	const uint8_t *__restrict__ modes, int uniform_mode, int edge, uint32_t n_blocks)
+	const uint8_t *__restrict__ modes, int uniform_mode, int edge, uint32_t n_blocks, uint32_t iterations)
 {
 	constexpr int LPB = N * N / 16;            // lanes per block: 1, 4, 16, 64
 	constexpr int BPWG = kThreads / LPB;
 	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-	constexpr int REF = 3 * N + 4;             // entries i = -N .. 2N + 1 at [N + i], rounded up to a dword
+	constexpr int REF = 3 * N + 12;            // entries i = -N .. 2N + 1 at [N + i]; the dword reads of a row may run 8 bytes past the last entry
+	constexpr int L = N < 16 ? N : 16, R = 16 / L;
+	constexpr int RAW = 4 * N + 4;
+	constexpr int LOADS = (N + LPB - 1) / LPB; // record dwords per lane: 4, 2, 1, 1 (the first 32 lanes at 32x32)
 	__shared__ __attribute__((aligned(16))) uint8_t refs[BPWG * REF];
+	__shared__ __attribute__((aligned(16))) uint8_t tiles[kThreads * 16];
+	__shared__ __attribute__((aligned(16))) uint8_t raws[BPWG * RAW];
 
-	const uint32_t t = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	uint32_t blk = t / LPB;
-	const int j = (int)(t % LPB);
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;
-	const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
-	const int mode = modes ? (int)modes[blk] : uniform_mode;
+	// A workgroup takes `iterations` consecutive groups of BPWG blocks.  A group's life is one global round trip (its records) and three barriers for
+	// 4 KiB of output: alone that is latency, not bandwidth (0.3 of the peak with eight workgroups per CU), so the NEXT group's records and modes are
+	// requested before this group's barriers and land while it computes.
+	const uint32_t first_group = xcd_contiguous(blockIdx.x, gridDim.x) * iterations;
+	const int j = (int)(threadIdx.x % LPB);
 	uint8_t *ref = refs + (threadIdx.x / LPB) * REF;
+	uint8_t *tile = tiles + (threadIdx.x / LPB) * (N * N);
+	uint8_t *raw = raws + (threadIdx.x / LPB) * RAW;
+	auto top_at = [&](int x) { return (int)raw[2 * N + x]; };          // p[x][-1]
+	auto left_at = [&](int y) { return (int)raw[2 * N - 1 - y]; };     // p[-1][y]
+
+	uint32_t rec[LOADS], rec_corner = 0;
+	int rec_mode = uniform_mode;
+	auto request = [&](uint32_t group)
+	{
+		uint32_t b = group * BPWG + threadIdx.x / LPB;
+		if (b >= n_blocks) b = n_blocks - 1;
+		const uint8_t *nb = neighbours + (ptrdiff_t)b * neighbour_stride;
+#pragma unroll
+		for (int q = 0; q < LOADS; ++q)
+			if (j + q * LPB < N) rec[q] = reinterpret_cast<const U1 *>(nb + 64 - 2 * N + 4 * (j + q * LPB))->v;
+		if (j == 0) rec_corner = nb[128];
+		if (modes) rec_mode = (int)modes[b];
+	};
+	request(first_group);
+
+	for (uint32_t it = 0; it < iterations; ++it)
+	{
+	const uint32_t blk = (first_group + it) * BPWG + threadIdx.x / LPB;
+	const bool live = blk < n_blocks;
+	const int mode = rec_mode;
+#pragma unroll
+	for (int q = 0; q < LOADS; ++q)
+		if (j + q * LPB < N) reinterpret_cast<uint32_t *>(raw)[j + q * LPB] = rec[q];
+	if (j == 0) raw[4 * N] = (uint8_t)rec_corner;
+	if (it + 1 < iterations) request(first_group + it + 1);
+	__syncthreads();
 
 	const int angle = kIntraAngle[mode];
 	const bool vertical = mode >= 18;
 	if (mode >= 2)
 	{
-		const int inv = angle < 0 ? (int)kIntraInvAngle[mode - 11] : 0;
-		for (int e = j; e < 3 * N + 2; e += LPB)
+		// ref[N + i], i >= 0: the corner, then the edge the mode runs along -- whole dwords at a time: the top row lies in raw[] in this order one byte
+		// off a dword boundary (v_alignbyte), the left column in the opposite order (v_alignbyte + a byte reversal); entries past 2N are never used by a
+		// sample that matters (they meet a zero weight) and take whatever the guard leaves
+		const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(raw);
+		uint32_t *ref32w = reinterpret_cast<uint32_t *>(ref);
+		for (int q = j; q < (2 * N + 12) / 4; q += LPB)
 		{
-			const int i = e - N;
-			int v = 0;
-			if (i > 2 * N) v = 0;
-			else if (i == 0) v = nb[128];
-			else if (i > 0) v = vertical ? nb[63 + i] : nb[64 - i];
-			else if (angle < 0)
+			uint32_t w = 0;
+			if (q <= 2 * N / 4)
 			{
-				const int k = min((i * inv + 128) >> 8, 2 * N);     // entries below (N * angle) >> 5 are never read: any in-record byte will do
-				v = vertical ? nb[64 - k] : nb[63 + k];
+				if (vertical)
+				{
+					const uint32_t hi = q < 2 * N / 4 ? raw32[2 * N / 4 + q] : 0u;
+					w = __builtin_amdgcn_alignbyte(hi, raw32[2 * N / 4 + q - 1], 3);      // bytes raw[2N - 1 + 4q ...]
+				}
+				else
+				{
+					const uint32_t lo = q < 2 * N / 4 ? raw32[2 * N / 4 - q - 1] : 0u;
+					w = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(raw32[2 * N / 4 - q], lo, 1), 0x00010203u);   // bytes raw[2N - 4q], raw[2N - 4q - 1], ...
+				}
+				if (q == 0) w = (w & 0xffffff00u) | raw[4 * N];
 			}
-			ref[e] = (uint8_t)v;
+			ref32w[N / 4 + q] = w;
+		}
+		if (angle < 0)
+		{
+			// i < 0: the other edge projected by the inverse angle (8.4.4.2.6); entries below (N * angle) >> 5 are never read
+			const int inv = (int)kIntraInvAngle[mode - 11];
+			for (int e = j; e < N; e += LPB)
+			{
+				const int i = e - N;
+				const int k = min((i * inv + 128) >> 8, 2 * N);
+				ref[e] = (uint8_t)(vertical ? left_at(k - 1) : top_at(k - 1));
+			}
 		}
 	}
 	else if (mode == 0)
 	{
-		for (int e = j; e < 2 * N + 2; e += LPB) ref[e] = e <= N ? nb[64 + e] : nb[63 - (e - N - 1)];      // top 0..N, then left 0..N
+		for (int e = j; e < 2 * N + 2; e += LPB) ref[e] = (uint8_t)(e <= N ? top_at(e) : left_at(e - N - 1));      // top 0..N, then left 0..N
 	}
 	else
 	{
-		for (int e = j; e < 2 * N; e += LPB) ref[e] = e < N ? nb[64 + e] : nb[63 - (e - N)];               // top 0..N-1, then left 0..N-1
+		for (int e = j; e < 2 * N; e += LPB) ref[e] = (uint8_t)(e < N ? top_at(e) : left_at(e - N));               // top 0..N-1, then left 0..N-1
 	}
 	__syncthreads();
 
-	uint8_t px[16];
+	Chunk<16> out;
 	if (mode >= 2)
 	{
+		const uint32_t *ref32 = reinterpret_cast<const uint32_t *>(ref);
 		const int corner = ref[N], first = ref[N + 1];
 #pragma unroll
-		for (int b = 0; b < 16; ++b)
+		for (int r = 0; r < R; ++r)
 		{
-			const int o = 16 * j + b, y = o / N, x = o % N;
-			const int u = vertical ? x : y, v = vertical ? y : x;
-			const int tt = (v + 1) * angle, idx = tt >> 5, f = tt & 31;
-			const int a = ref[N + u + idx + 1], c = ref[N + u + idx + 2];
-			int val = ((32 - f) * a + f * c + 16) >> 5;
-			px[b] = (uint8_t)val;
-		}
-		if (edge && angle == 0)
-		{
-			// modes 26 / 10 with the boundary smoothing: the first column / row takes half the gradient along the other edge
+			const int v = N >= 16 ? 16 * j / N : R * j + r, u0 = N >= 16 ? 16 * j % N : 0;
+			const int tt = (v + 1) * angle, idx = tt >> 5;
+			const uint32_t f = (uint32_t)tt & 31u;
+			const int s = N + u0 + idx + 1;
+			const uint32_t sh = (uint32_t)s & 3u;
+			uint32_t d[L / 4 + 2], a[L / 4 + 1];
 #pragma unroll
-			for (int b = 0; b < 16; ++b)
+			for (int k = 0; k < L / 4 + 2; ++k) d[k] = ref32[(s >> 2) + k];
+#pragma unroll
+			for (int k = 0; k < L / 4 + 1; ++k) a[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+			const uint32_t w1 = f | (f << 16), w0 = 0x00200020u - w1;
+#pragma unroll
+			for (int k = 0; k < L / 4; ++k)
 			{
-				const int o = 16 * j + b, y = o / N, x = o % N;
-				const int u = vertical ? x : y, v = vertical ? y : x;
-				if (u == 0)
-				{
-					const int other = vertical ? nb[63 - v] : nb[64 + v];
-					px[b] = (uint8_t)clip3(0, 255, first + ((other - corner) >> 1));
-				}
+				const uint32_t b = __builtin_amdgcn_alignbyte(a[k + 1], a[k], 1);
+				const uint32_t ae = a[k] & 0x00ff00ffu, ao = (a[k] >> 8) & 0x00ff00ffu, be = b & 0x00ff00ffu, bo = (b >> 8) & 0x00ff00ffu;
+				const uint32_t re = pk_lshr_u16(pk_mad_u16(ae, w0, pk_mad_u16(be, w1, 0x00100010u)), 5);
+				const uint32_t ro = pk_lshr_u16(pk_mad_u16(ao, w0, pk_mad_u16(bo, w1, 0x00100010u)), 5);
+				out.d[r * (L / 4) + k] = re | (ro << 8);
+			}
+			if (edge && angle == 0 && u0 == 0)
+			{
+				// modes 26 / 10 with the boundary smoothing: the pixel next to the main edge takes half the gradient along the other edge
+				const int other = vertical ? left_at(v) : top_at(v);
+				out.d[r * (L / 4)] = (out.d[r * (L / 4)] & 0xffffff00u) | (uint32_t)clip3(0, 255, first + ((other - corner) >> 1));
 			}
 		}
 	}
 	else if (mode == 0)
 	{
 		const int tn = ref[N], ln = ref[2 * N + 1];
+		const uint32_t *top32 = reinterpret_cast<const uint32_t *>(ref);
 #pragma unroll
-		for (int b = 0; b < 16; ++b)
+		for (int r = 0; r < R; ++r)
 		{
-			const int o = 16 * j + b, y = o / N, x = o % N;
-			px[b] = (uint8_t)(((N - 1 - x) * ref[N + 1 + y] + (x + 1) * tn + (N - 1 - y) * ref[x] + (y + 1) * ln + N) >> (LOG2 + 1));
+			const int y = N >= 16 ? 16 * j / N : R * j + r, x0 = N >= 16 ? 16 * j % N : 0;
+			const int ly = ref[N + 1 + y];
+			const int row = (y + 1) * ln + N, step = tn - ly;
+			int across = (N - 1 - x0) * ly + (x0 + 1) * tn + row;
+#pragma unroll
+			for (int k = 0; k < L / 4; ++k)
+			{
+				const uint32_t tw = top32[x0 / 4 + k];
+				uint32_t px = 0;
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+				{
+					px |= (uint32_t)(((int)((tw >> (8 * b)) & 0xff) * (N - 1 - y) + across) >> (LOG2 + 1)) << (8 * b);
+					across += step;
+				}
+				out.d[r * (L / 4) + k] = px;
+			}
 		}
 	}
 	else
@@ -197,6 +293,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 #pragma unroll
 		for (int q = 0; q < 2 * N / 4; ++q) sum = __builtin_amdgcn_sad_u8(reinterpret_cast<const uint32_t *>(ref)[q], 0, sum);
 		const int dc = (int)(sum + N) >> (LOG2 + 1);
+		uint8_t px[16];
 #pragma unroll
 		for (int b = 0; b < 16; ++b)
 		{
@@ -210,22 +307,42 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 			}
 			px[b] = (uint8_t)val;
 		}
-	}
-	Chunk<16> out;
 #pragma unroll
-	for (int k = 0; k < 4; ++k)
-		out.d[k] = px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+		for (int k = 0; k < 4; ++k)
+			out.d[k] = px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+	}
+	// horizontal modes: the lane holds family row v (output COLUMN v), positions u0 .. u0 + L - 1 (output rows): through the tile, transposed
+	const bool transposed = mode >= 2 && !vertical;
+	if (transposed)
+	{
+#pragma unroll
+		for (int r = 0; r < R; ++r)
+		{
+			const int v = N >= 16 ? 16 * j / N : R * j + r, u0 = N >= 16 ? 16 * j % N : 0;
+#pragma unroll
+			for (int b = 0; b < L; ++b) tile[(u0 + b) * N + v] = (uint8_t)(out.d[r * (L / 4) + b / 4] >> (8 * (b % 4)));
+		}
+	}
+	__syncthreads();
+	if (transposed)
+	{
+		const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + 16 * j);
+		out.d[0] = q.x; out.d[1] = q.y; out.d[2] = q.z; out.d[3] = q.w;
+	}
 	if (live) out.store(dst + (size_t)blk * (N * N) + 16 * j);
+	}
 }
 
-// H.265 8.4.4.2.3: the filtered neighbour record of each block (same layout; only the 4N + 1 samples are written).  One lane per output sample:
-// lane s < 2N: left sample y = s; 2N <= s < 4N: top sample x = s - 2N; s == 4N: the corner.  `strong`: strong_intra_smoothing_enabled_flag -- 32x32 blocks
-// whose two edges are flat take the bi-linear form, decided per block.
+// H.265 8.4.4.2.3: the filtered neighbour record of each block (same layout; only the 4N + 1 samples are written).  In memory the samples are ONE run --
+// left column upwards [64 - 2N, 64), then the top row [64, 64 + 2N) -- with the corner (stored at [128]) logically between bytes 63 and 64, and the
+// [1 2 1] filter is symmetric, so a lane filters one DWORD of that run from itself and its two neighbours (v_alignbyte by one byte each way, the corner
+// patched in at the junction, even / odd bytes on packed 16-bit adds); lane N of a block writes the corner.  `strong`: strong_intra_smoothing_enabled_flag
+// -- 32x32 blocks whose two edges are flat take the bi-linear form, decided per block.  (First form, a lane per byte: 0.04-0.07 of the HBM peak.)
 __global__ __launch_bounds__(kThreads) void intra_filter_neighbours_kernel(
 	uint8_t *__restrict__ out, ptrdiff_t out_stride, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride, int N, int strong, uint32_t n_blocks)
 {
-	const uint32_t per = 4 * N + 1;
-	const uint64_t t = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+	const uint32_t per = (uint32_t)N + 1;
+	const uint64_t t = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
 	const uint32_t blk = (uint32_t)(t / per), s = (uint32_t)(t % per);
 	if (blk >= n_blocks) return;
 	const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
@@ -237,15 +354,39 @@ __global__ __launch_bounds__(kThreads) void intra_filter_neighbours_kernel(
 		const int a = corner + nb[64 + 63] - 2 * nb[64 + 31], b = corner + nb[63 - 63] - 2 * nb[63 - 31];
 		bi = abs(a) < 8 && abs(b) < 8;
 	}
-	if (s == 4u * N) { o[128] = bi ? (uint8_t)corner : (uint8_t)((nb[63] + 2 * corner + nb[64] + 2) >> 2); return; }
-	const bool top = s >= 2u * N;
-	const int i = (int)(top ? s - 2 * N : s);
-	auto smp = [&](int k) { return k < 0 ? corner : (int)(top ? nb[64 + k] : nb[63 - k]); };
-	int v;
-	if (i == 2 * N - 1) v = smp(i);
-	else if (bi) v = ((63 - i) * corner + (i + 1) * smp(63) + 32) >> 6;
-	else v = (smp(i + 1) + 2 * smp(i) + smp(i - 1) + 2) >> 2;
-	o[top ? 64 + i : 63 - i] = (uint8_t)v;
+	if (s == (uint32_t)N) { o[128] = bi ? (uint8_t)corner : (uint8_t)((nb[63] + 2 * corner + nb[64] + 2) >> 2); return; }
+	const int m = 64 - 2 * N + 4 * (int)s;                      // the dword's first byte in the record
+	const uint32_t cur = reinterpret_cast<const U1 *>(nb + m)->v;
+	uint32_t res;
+	if (bi)
+	{
+		// sample i of an edge: ((63 - i) corner + (i + 1) end + 32) >> 6, the end sample itself kept; left sample i lies at byte 63 - i, top sample i at 64 + i
+		const bool top = m >= 64;
+		const int end = top ? nb[127] : nb[0];
+		res = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b)
+		{
+			const int i = top ? m + b - 64 : 63 - (m + b);
+			const int v = i == 63 ? end : ((63 - i) * corner + (i + 1) * end + 32) >> 6;
+			res |= (uint32_t)v << (8 * b);
+		}
+	}
+	else
+	{
+		const uint32_t prev = s > 0 ? reinterpret_cast<const U1 *>(nb + m - 4)->v : 0u;
+		const uint32_t next = s + 1 < (uint32_t)N ? reinterpret_cast<const U1 *>(nb + m + 4)->v : 0u;
+		uint32_t before = __builtin_amdgcn_alignbyte(cur, prev, 3);      // the bytes one position below each of cur's
+		uint32_t after = __builtin_amdgcn_alignbyte(next, cur, 1);       // ... and one above
+		if (m == 64) before = (before & 0xffffff00u) | (uint32_t)corner;           // below the first top sample: the corner
+		if (m == 60) after = (after & 0x00ffffffu) | ((uint32_t)corner << 24);     // above the first left sample (byte 63): the corner
+		const uint32_t even = (before & 0x00ff00ffu) + 2 * (cur & 0x00ff00ffu) + (after & 0x00ff00ffu) + 0x00020002u;
+		const uint32_t odd = ((before >> 8) & 0x00ff00ffu) + 2 * ((cur >> 8) & 0x00ff00ffu) + ((after >> 8) & 0x00ff00ffu) + 0x00020002u;
+		res = ((even >> 2) & 0x00ff00ffu) | (((odd >> 2) & 0x00ff00ffu) << 8);
+		if (s == 0) res = (res & 0xffffff00u) | (cur & 0xffu);                     // the two end samples are kept
+		if (s + 1 == (uint32_t)N) res = (res & 0x00ffffffu) | (cur & 0xff000000u);
+	}
+	reinterpret_cast<U1 *>(o + m)->v = res;
 }
 
 }  // namespace hevc
@@ -264,13 +405,17 @@ static int check_intra_args(int packed, size_t n_blocks, int *log2n)
 static int launch_intra_modes(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, const uint8_t *modes, int mode, int packed, size_t n_blocks, hipStream_t st)
 {
 	const int log2n = (packed >> 1) & 0x7f, edge = packed & 1, n = 1 << log2n;
-	const uint32_t grid = ceil_div(n_blocks * (size_t)(n * n / 16), kThreads);
+	// groups of 256 lanes (4 KiB of output); a workgroup takes up to 8 of them in a row, fewer while that would leave the device under ~8 workgroups per CU
+	const uint32_t groups = ceil_div(n_blocks * (size_t)(n * n / 16), kThreads);
+	uint32_t iterations = 8;
+	while (iterations > 1 && groups / iterations < (uint32_t)device_cus() * 8) iterations >>= 1;
+	const uint32_t grid = ceil_div(groups, iterations);
 	switch (log2n)
 	{
-	case 2: hipLaunchKernelGGL(pred_intra_modes_kernel<4>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks); break;
-	case 3: hipLaunchKernelGGL(pred_intra_modes_kernel<8>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks); break;
-	case 4: hipLaunchKernelGGL(pred_intra_modes_kernel<16>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks); break;
-	default: hipLaunchKernelGGL(pred_intra_modes_kernel<32>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks); break;
+	case 2: hipLaunchKernelGGL(pred_intra_modes_kernel<4>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
+	case 3: hipLaunchKernelGGL(pred_intra_modes_kernel<8>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
+	case 4: hipLaunchKernelGGL(pred_intra_modes_kernel<16>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
+	default: hipLaunchKernelGGL(pred_intra_modes_kernel<32>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
 	}
 	return launch_status("pred_intra_modes_kernel");
 }
@@ -319,10 +464,10 @@ extern "C" int hevcasm_hip_intra_filter_neighbours_batch(
 	if (int e = check_device()) return e;
 	if (log2TrafoSize < 2 || log2TrafoSize > 5) return set_error(HEVCASM_HIP_EINVAL, "block size must be 4, 8, 16 or 32");
 	if (n_blocks == 0) return 0;
-	if (n_blocks > 0xffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!filtered || !neighbours) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	const int n = 1 << log2TrafoSize;
-	const uint32_t grid = ceil_div(n_blocks * (size_t)(4 * n + 1), kThreads);
+	if (n_blocks > 0x7fffffffull * kThreads / (size_t)(n + 1)) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large for one launch");
+	const uint32_t grid = ceil_div(n_blocks * (size_t)(n + 1), kThreads);
 	hipLaunchKernelGGL(intra_filter_neighbours_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), filtered, filtered_stride, neighbours, neighbour_stride, n, strong_intra_smoothing,
 			(uint32_t)n_blocks);
 	return launch_status("intra_filter_neighbours_kernel");

@@ -314,12 +314,12 @@ def bench_intra():
                 torch.cuda.empty_cache()
 
 
-def bench_intra_modes():
-    """SURVEY 8f-3 beyond DC (unpinned): 2^26 output pixels per launch, 144-byte records; one mode for the batch (planar, pure vertical, a positive and a negative
-    angle from each family) and one random mode per block."""
+def bench_intra_modes(pixels=1 << 28):
+    """SURVEY 8f-3 beyond DC (unpinned): 2^28 output pixels per launch (a 2^26-pixel launch is 64 MB = 8 us at the HBM peak: launch ramp, not kernel),
+    144-byte records; one mode for the batch (planar, pure vertical, a positive and a negative angle from each family) and one random mode per block."""
     for log2 in (2, 3, 4, 5):
         size = 1 << log2
-        nb = (1 << 26) >> (2 * log2)
+        nb = pixels >> (2 * log2)
         neigh = wl.fill_u8(144 * nb + 128, 450 + log2, device="cuda")
         dst = torch.empty(nb * size * size, dtype=torch.uint8, device="cuda")
         packed = (8 << 8) | (log2 << 1) | (1 if log2 < 5 else 0)
