@@ -307,7 +307,10 @@ static int me_parts(size_t n_blocks, int W, int H, int range)
 	if (forced >= 1 && forced <= 8) parts = forced;
 	else if ((size_t)W * H * side * side >= ((size_t)1 << 23))
 	{
-		for (int p = 4; p >= 2 && parts == 1; p >>= 1)
+		// four parts only for the largest blocks (64x64 / +-64 = 2^26 byte differences): at 32x32 / +-64 two parts beat four at every list length
+		// (64 blocks 0.048 against 0.061 ms, 256 blocks 0.066 against 0.082: profiles/r05_me_small_parts_ab.txt)
+		const int most = (size_t)W * H * side * side >= ((size_t)1 << 26) ? 4 : 2;
+		for (int p = most; p >= 2 && parts == 1; p >>= 1)
 		{
 			int ws;
 			const size_t lds = me_lds_bytes(W, H, range, H + (side + p - 1) / p - 1, &ws);
