@@ -19,7 +19,7 @@ for size in ("64x64", "16x16", "64x48", "48x64"):
                 ways = int(m.group(5)) if m else (4 if "hevc::sad4_window_kernel<" in r["Kernel_Name"] else None)     # the 4-way kernel of 64-/48-wide blocks
                 if ways and r["Counter_Name"] == counter:
                     vals.setdefault((ways, counter), []).append(float(r["Counter_Value"]))
-    bench = json.load(open(os.path.join(prof, "bench_%s.json" % size)))
+    bench = json.load(open(os.path.join(prof, "bench_%s.full.json" % size)))      # the full record (--full-out): the stdout line is compact since round 5
     for ways, name in ((1, "sad"), (4, "sad_multiref_4")):
         f, w = vals.get((ways, "FETCH_SIZE")), vals.get((ways, "WRITE_SIZE"))
         if not f or not w:
