@@ -1,0 +1,65 @@
+"""The whole hot path as ONE chain on one frame (hevcasm_amd/pipeline.py): every stage's output feeds the next, on the GPU through the batch C-ABI and
+on the CPU through the oracle, and every intermediate must be identical -- a composition no single kernel test exercises (a wrong vector, a prediction
+off by one row, a coefficient order or a cbf convention would all surface downstream)."""
+import numpy as np
+import pytest
+
+from hevcasm_amd import me_frame, pipeline
+from oracle import pyoracle
+
+
+class OracleOps:
+    """The same stages through the oracle (numpy arrays throughout)."""
+
+    def me_full_search(self, cur, sc, ref, sr, cur_off, ref_off, w, h, search_range):
+        return pyoracle.me_full_search(cur, sc, ref, sr, cur_off, ref_off, w, h, search_range)
+
+    def subpel_refine(self, cur, sc, ref, sr, cur_off, ref_off, w, h):
+        return pyoracle.subpel_refine(cur, sc, ref, sr, cur_off, ref_off, w, h)
+
+    def pred_uni(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, taps, w, h):
+        return pyoracle.pred_uni_batch(taps, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, w, h)
+
+    def residual(self, cur, pred):
+        return cur.astype(np.int16) - pred.astype(np.int16)
+
+    def transform(self, residual, stride, off, tr_type, log2n):
+        return pyoracle.transform_batch(tr_type, log2n, residual, stride, off)
+
+    def quantize(self, coeffs, scale, shift, offset, n_per_block):
+        return pyoracle.quantize_batch(coeffs, scale, shift, offset, n_per_block)
+
+    def dequant_inverse_transform_add(self, dst_bytes, sd, pred, sp, dst_off, pred_off, levels, scale, shift, tr_type, log2n):
+        return pyoracle.dequant_inverse_transform_add_batch(tr_type, log2n, dst_bytes, sd, pred, sp, dst_off, pred_off, levels, scale, shift)
+
+    def ssd(self, a, sa, b, sb, a_off, b_off, w, h):
+        return pyoracle.ssd_batch(a, sa, b, sb, a_off, b_off, w, h)
+
+    def frame_sse(self, a, sa, b, sb, w, h):
+        z = np.zeros(1, dtype=np.uint32)
+        return int(pyoracle.frame_sse_batch(a, sa, b, sb, z, z, w, h)[0])
+
+
+def test_pipeline_on_the_oracle_is_a_sane_encode(oracle_lib):
+    """CPU: the chain hangs together -- motion is found, some vectors are fractional, reconstruction is close to the source."""
+    frame = me_frame.synthetic_frame_pair(192, 128, 16, seed=4, ctu=16, max_motion=6)
+    r = pipeline.stages(frame, OracleOps(), size=16, search_range=8)
+    assert r["blocks"] == 96 and (np.abs(r["mv"][:, :2]) <= 8).all() and (np.abs(r["qmv"][:, :2]) <= 3).all()
+    assert (r["mv"][:, :2] != 0).any() and r["psnr"] > 30.0
+    assert r["frame_sse"] == int(r["block_ssd"].astype(np.int64).sum())          # the frame is tiled exactly by its blocks
+    assert np.array_equal(r["cbf"] != 0, (r["levels"].reshape(96, -1) != 0).any(axis=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,size,rng", [(960, 544, 16, 8), (512, 256, 32, 12), (384, 256, 8, 6)])
+def test_pipeline_hip_equals_oracle_stage_by_stage(w, h, size, rng):
+    frame = me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + size, ctu=size, max_motion=rng - 2)
+    want = pipeline.stages(frame, OracleOps(), size=size, search_range=rng)
+    got = pipeline.HipOps.to_numpy(pipeline.stages(frame, pipeline.HipOps(), size=size, search_range=rng))
+    for key in ("mv", "qmv", "pred", "residual", "coeffs", "levels", "cbf", "recon", "block_ssd"):
+        g, wv = np.asarray(got[key]), np.asarray(want[key])
+        if key == "cbf":                                     # only zero / non-zero is meaningful (reference quantize.c:257)
+            g, wv = g != 0, wv != 0
+        assert g.shape == wv.shape and np.array_equal(g, wv), "stage %s differs (%d of %d)" % (key, int((g != wv).sum()), g.size)
+    assert got["frame_sse"] == want["frame_sse"] and got["psnr"] == want["psnr"]
+    assert (got["qmv"][:, :2] & 3).any(), "the case must exercise fractional prediction"
