@@ -187,12 +187,12 @@ def test_product_never_touches_the_oracle():
     assert "oracle" not in deps
 
 
-def _build_example(tmp_path):
+def _build_example(tmp_path, name="batch_sad", extra=()):
     import subprocess
-    exe = str(tmp_path / "batch_sad")
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "hevcasm_amd", "lib")
-    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "batch_sad.c"),
-                    "-L" + libdir, "-lhevcasm_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    subprocess.run(["gcc", "-std=gnu11", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", name + ".c"),
+                    "-L" + libdir, "-lhevcasm_hip", "-Wl,-rpath," + libdir, "-o", exe] + list(extra), check=True)
     return exe
 
 
@@ -213,3 +213,23 @@ def test_c_example_per_block_table_equals_batch_call(tmp_path):
     r = subprocess.run([_build_example(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 differ" in r.stdout
+
+
+def test_multi_gpu_example_compiles_and_refuses_without_a_gpu(tmp_path):
+    """examples/multi_gpu_sad.c (one process, a thread + stream per device, contiguous block ranges, no exchange) is plain C + pthreads."""
+    import subprocess
+    import torch
+    exe = _build_example(tmp_path, "multi_gpu_sad", ["-lpthread"])
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    assert subprocess.run([exe], capture_output=True).returncode == 77
+
+
+@pytest.mark.gpu
+def test_multi_gpu_example_ranges_gather_into_one_array(tmp_path):
+    """On the one-GPU test box: all visible devices (one rank), and four host threads sharing device 0, each with its own stream and block range."""
+    import subprocess
+    exe = _build_example(tmp_path, "multi_gpu_sad", ["-lpthread"])
+    for argv in ([], ["4", "threads"]):
+        r = subprocess.run([exe] + argv, capture_output=True, text=True)
+        assert r.returncode == 0 and " 0 differ" in r.stdout, r.stdout + r.stderr

@@ -40,10 +40,22 @@ class OracleOps:
         return int(pyoracle.frame_sse_batch(a, sa, b, sb, z, z, w, h)[0])
 
 
+def _with_half_pel_motion(frame):
+    """The generator moves blocks by whole pixels; here the lower half of the current frame becomes the mean of itself and its right-hand neighbour,
+    i.e. content half a pixel away from anything in the reference, so that the refinement has fractional winners."""
+    w, h = frame["w"], frame["h"]
+    cur = frame["cur"].reshape(h, w).astype(np.uint16)
+    low = cur[h // 2:]
+    low[:, :-1] = (low[:, :-1] + low[:, 1:] + 1) >> 1
+    frame["cur"] = np.ascontiguousarray(cur.astype(np.uint8)).reshape(-1)
+    return frame
+
+
 def test_pipeline_on_the_oracle_is_a_sane_encode(oracle_lib):
     """CPU: the chain hangs together -- motion is found, some vectors are fractional, reconstruction is close to the source."""
-    frame = me_frame.synthetic_frame_pair(192, 128, 16, seed=4, ctu=16, max_motion=6)
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(192, 128, 16, seed=4, ctu=16, max_motion=6))
     r = pipeline.stages(frame, OracleOps(), size=16, search_range=8)
+    assert (r["qmv"][:, :2] & 3).any()
     assert r["blocks"] == 96 and (np.abs(r["mv"][:, :2]) <= 8).all() and (np.abs(r["qmv"][:, :2]) <= 3).all()
     assert (r["mv"][:, :2] != 0).any() and r["psnr"] > 30.0
     assert r["frame_sse"] == int(r["block_ssd"].astype(np.int64).sum())          # the frame is tiled exactly by its blocks
@@ -53,7 +65,7 @@ def test_pipeline_on_the_oracle_is_a_sane_encode(oracle_lib):
 @pytest.mark.gpu
 @pytest.mark.parametrize("w,h,size,rng", [(960, 544, 16, 8), (512, 256, 32, 12), (384, 256, 8, 6)])
 def test_pipeline_hip_equals_oracle_stage_by_stage(w, h, size, rng):
-    frame = me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + size, ctu=size, max_motion=rng - 2)
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + size, ctu=size, max_motion=rng - 2))
     want = pipeline.stages(frame, OracleOps(), size=size, search_range=rng)
     got = pipeline.HipOps.to_numpy(pipeline.stages(frame, pipeline.HipOps(), size=size, search_range=rng))
     for key in ("mv", "qmv", "pred", "residual", "coeffs", "levels", "cbf", "recon", "block_ssd"):
