@@ -127,6 +127,30 @@ def test_search_operators_and_small_families_random_parameters():
         stride, n = int(rng.integers(2 << log2, 300)), int(rng.integers(1, 90))
         c = dict(neighbours=wl.fill_u8(stride * n + 128, 8500 + i), neighbour_stride=stride, mode=1, packed=(8 << 8) | (log2 << 1) | edge, n=n)
         cases.assert_same("fuzz intra %d edge=%d stride=%d" % (1 << log2, edge, stride), cases.run_hip("intra", c), cases.run_oracle("intra", c))
+    # round 5: whole-frame SSE -- random widths (every lane deal, rows longer than 256 chunks included), heights, strides, bottom-up planes, frame counts
+    for i in range(24):
+        w, h, n = int(rng.integers(0, 5000)) if i % 4 else int(rng.integers(0, 40)), int(rng.integers(0, 70)), int(rng.integers(1, 7 * NMUL))
+        sa, sb = w + int(rng.integers(0, 40)), w + int(rng.integers(0, 40))
+        span_a, span_b = sa * max(h, 1) + 9, sb * max(h, 1) + 9
+        up = bool(rng.integers(0, 2)) and h > 0
+        c = dict(a=wl.fill_u8(span_a * n + 16, 8600 + i), stride_a=-sa if up else sa, b=wl.fill_u8(span_b * n + 16, 8700 + i), stride_b=sb,
+                 a_off=(np.arange(n) * span_a + rng.integers(0, 4, n) + (sa * (h - 1) if up else 0)).astype(np.uint32),
+                 b_off=(np.arange(n) * span_b + rng.integers(0, 4, n)).astype(np.uint32), width=w, height=h)
+        cases.assert_same("fuzz frame_sse %dx%d x%d" % (w, h, n), cases.run_hip("frame_sse", c), cases.run_oracle("frame_sse", c))
+    # round 5 (unpinned beyond DC): a mode per block, random record strides and batch lengths (several workgroup iterations and the partial tail), random
+    # and two-level content; the neighbour smoothing with and without the strong form
+    for i in range(16):
+        log2 = int(rng.integers(2, 6))
+        edge = int(rng.integers(0, 2)) if log2 < 5 else 0
+        stride, n = int(rng.integers(129, 300)), int(rng.integers(1, 2500 * NMUL))
+        nb = wl.fill_u8(stride * n + 160, 8800 + i)
+        if i % 3 == 0:
+            nb = np.where(nb > 127, 255, 0).astype(np.uint8)
+        c = dict(neighbours=nb, neighbour_stride=stride, modes=rng.integers(0, 35, n).astype(np.uint8), packed=(8 << 8) | (log2 << 1) | edge)
+        cases.assert_same("fuzz intra modes %d edge=%d stride=%d n=%d" % (1 << log2, edge, stride, n), cases.run_hip("intra_modes", c), cases.run_oracle("intra_modes", c))
+        smooth = (nb.astype(np.int32) // 16 + 100).astype(np.uint8) if i % 2 else nb           # nearly flat records take the bi-linear form at 32x32
+        f = dict(neighbours=smooth, neighbour_stride=stride, log2=log2, strong=int(rng.integers(0, 2)), n=min(n, 400))
+        cases.assert_same("fuzz intra filter %d strong=%d" % (1 << log2, f["strong"]), cases.run_hip("intra_filter", f), cases.run_oracle("intra_filter", f))
 
 
 def test_frame_search_and_two_plane_prediction_random_geometry():
