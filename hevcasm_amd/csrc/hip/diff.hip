@@ -158,6 +158,7 @@ extern "C" int hevcasm_hip_frame_sse_batch(
 	if (n_frames == 0) return 0;
 	if (n_frames > 0xfffffull) return set_error(HEVCASM_HIP_EINVAL, "n_frames too large");
 	if (!a || !b || !a_off || !b_off || !sse) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	if (reinterpret_cast<uintptr_t>(sse) & 7u) return set_error(HEVCASM_HIP_EINVAL, "sse must be 8-byte aligned (64-bit atomic adds)");
 	hipStream_t st = as_stream(stream);
 	HEVC_HIP_TRY(hipMemsetAsync(sse, 0, 8 * n_frames, st));
 	if (width == 0 || height == 0) return 0;

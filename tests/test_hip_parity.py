@@ -639,6 +639,17 @@ def test_error_codes_not_fallbacks():
     assert fr(None, 64, p, 64, 64, 64, 16, 8, 0, 1, o.data_ptr(), None) == capi.EINVAL
     assert L.hevcasm_hip_pred_uni_8to8_batch_2planes(p, None, 64, p, p, 64, o.data_ptr(), o.data_ptr(), p, 4, 8, 8, 1, None) == capi.EINVAL
     assert L.hevcasm_hip_pred_uni_8to8_batch_2planes(p, p, 64, p, p, 64, o.data_ptr(), o.data_ptr(), p, 4, 40, 8, 1, None) == capi.EINVAL
+    # the round-5 entry points: frame SSE (dimensions, the 8-byte alignment of the sums), intra (mode range, edge flag at 32x32, missing mode array)
+    o64 = torch.zeros(4, dtype=torch.int64, device="cuda")
+    fs = L.hevcasm_hip_frame_sse_batch
+    assert fs(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o64.data_ptr(), 40000, 4, 1, None) == capi.EINVAL
+    assert fs(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o64.data_ptr(), 16, -1, 1, None) == capi.EINVAL
+    assert fs(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o64.data_ptr() + 4, 16, 4, 1, None) == capi.EINVAL
+    assert fs(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o64.data_ptr(), 16, 4, 0, None) == 0
+    assert L.hevcasm_hip_pred_intra_batch(p, p, 144, 35, (8 << 8) | (3 << 1), 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_pred_intra_batch(p, p, 144, 26, (8 << 8) | (5 << 1) | 1, 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_pred_intra_modes_batch(p, p, 144, None, (8 << 8) | (3 << 1), 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_intra_filter_neighbours_batch(p, 144, p + 2048, 144, 6, 0, 1, None) == capi.EINVAL
     # empty batches are legal no-ops
     assert L.hevcasm_hip_sad_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), capi.rect(16, 16), 0, None) == 0
     assert L.hevcasm_hip_pred_bi_8to8_batch_2planes(p, p, 64, p, p, p, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), p, p, 8, 16, 16, 0, None) == 0

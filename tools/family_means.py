@@ -7,7 +7,7 @@ for l in open(sys.argv[1]):
     if not l.startswith("{"):
         continue
     r = json.loads(l)
-    if "frac_of_hbm_peak" in r and r.get("kernel", "").startswith(("pred_", "inverse", "dequant", "transform", "quantize", "hadamard", "ssd_linear", "pred_intra")):
+    if "frac_of_hbm_peak" in r and r.get("kernel", "").startswith(("pred_", "inverse", "dequant", "transform", "quantize", "hadamard", "ssd_linear", "pred_intra", "frame_sse", "intra_filter")):
         rows[r["kernel"]].append((r["frac_of_hbm_peak"], r.get("size", "")))
 print("%-34s %5s %7s %7s %7s   %s" % ("kernel", "sizes", "mean", "min", "max", "slowest size"))
 for k, v in rows.items():
