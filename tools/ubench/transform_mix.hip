@@ -111,6 +111,35 @@ template <int N, bool WIDE> __global__ __launch_bounds__(256) void mix_coalesced
 	}
 }
 
+// Deal 3: prediction and destination BLOCK-LINEAR (stride N: block b's rows are the N x N contiguous bytes at b * N * N -- what hevcasm_pred_intra writes,
+// and what a codec keeps its prediction scratch in); every lane takes row t of ITS block (no re-deal): all three streams are contiguous runs.
+template <int N> __global__ __launch_bounds__(256) void mix_linear(uint8_t *dst, const uint8_t *pred, const int16_t *coeffs, uint32_t n_blocks)
+{
+	constexpr int BPWG = 256 / N;
+	const uint32_t nwg = gridDim.x, per_xcd = (nwg + 7) / 8, wg = (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
+	if (wg >= nwg) return;
+	const uint32_t local = threadIdx.x / N, t = threadIdx.x % N;
+	uint32_t blk = wg * BPWG + local;
+	if (blk >= n_blocks) blk = n_blocks - 1;
+	const u32x4 *c = reinterpret_cast<const u32x4 *>(coeffs + (size_t)blk * N * N + t * N);
+	u32x4 acc = c[0];
+#pragma unroll
+	for (int q = 1; q < 2 * N / 16; ++q) { const u32x4 v = c[q]; acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+	const u32x4 *p = reinterpret_cast<const u32x4 *>(pred + (size_t)blk * N * N + t * N);
+	u32x4 *d = reinterpret_cast<u32x4 *>(dst + (size_t)blk * N * N + t * N);
+	__shared__ uint32_t x[256];
+	x[threadIdx.x] = acc.x ^ acc.y ^ acc.z ^ acc.w;
+	__syncthreads();
+	const uint32_t mixin = x[(threadIdx.x * 7 + 3) & 255];
+#pragma unroll
+	for (int q = 0; q < N / 16; ++q)
+	{
+		u32x4 v = p[q];
+		v.x ^= mixin; v.y += mixin; v.z ^= mixin; v.w += mixin;
+		d[q] = v;
+	}
+}
+
 static bool g_live = false;
 static int g_deal = 0;   // 0 = the shipped deals, 1 = coalesced coefficients, 2 = + wide prediction / destination rows (N = 32)
 template <int N> void run(size_t coeffs_total)
@@ -129,7 +158,8 @@ template <int N> void run(size_t coeffs_total)
 		hipEventRecord(e0);
 		if (g_deal == 0) mix<N><<<grid, 256>>>(dst, pred, co, (uint32_t)n, per_row, per_frame);
 		else if (g_deal == 1) mix_coalesced<N, false><<<grid, 256>>>(dst, pred, co, (uint32_t)n, per_row, per_frame);
-		else mix_coalesced<N, true><<<grid, 256>>>(dst, pred, co, (uint32_t)n, per_row, per_frame);
+		else if (g_deal == 2) mix_coalesced<N, true><<<grid, 256>>>(dst, pred, co, (uint32_t)n, per_row, per_frame);
+		else mix_linear<N><<<grid, 256>>>(dst, pred, co, (uint32_t)n);
 		hipEventRecord(e1); hipDeviceSynchronize();
 		float t; hipEventElapsedTime(&t, e0, e1);
 		if (rep) ms.push_back(t);
@@ -153,7 +183,7 @@ int main(int argc, char **)
 		run<32>((size_t)1 << 28);
 		return 0;
 	}
-	for (int deal = 0; deal < 3; ++deal)
+	for (int deal = 0; deal < 4; ++deal)
 		for (size_t total : { (size_t)1 << 26, (size_t)1 << 28 })
 		{
 			g_deal = deal;
