@@ -126,19 +126,22 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	uint8_t *__restrict__ dst, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride,
 	const uint8_t *__restrict__ modes, int uniform_mode, int edge, uint32_t n_blocks, uint32_t iterations)
 {
-	constexpr int LPB = N * N / 16;            // lanes per block: 1, 4, 16, 64
+	constexpr int PX = N < 16 ? N : 16;        // output bytes per lane = one family row (4x4, 8x8: a whole row; 16: a row; 32: half a row)
+	constexpr int LPB = N * N / PX;            // lanes per block: 4, 8, 16, 64.  (A lane per 16 bytes at 4x4 / 8x8 -- 1 and 4 lanes per block -- measured the
+	                                           // same: small blocks are bound by their RECORDS, >= 129 bytes fetched per 16 / 64 bytes written: 4x4 moves
+	                                           // 5.0 TB/s of real traffic at "0.13" of algorithmic bytes, profiles/r05_intra_modes.txt)
 	constexpr int BPWG = kThreads / LPB;
 	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	constexpr int REF = 3 * N + 12;            // entries i = -N .. 2N + 1 at [N + i]; the dword reads of a row may run 8 bytes past the last entry
-	constexpr int L = N < 16 ? N : 16, R = 16 / L;
+	constexpr int L = PX;
 	constexpr int RAW = 4 * N + 4;
-	constexpr int LOADS = (N + LPB - 1) / LPB; // record dwords per lane: 4, 2, 1, 1 (the first 32 lanes at 32x32)
+	constexpr int LOADS = (N + LPB - 1) / LPB; // record dwords per lane: 1 (the first 32 lanes at 32x32)
 	__shared__ __attribute__((aligned(16))) uint8_t refs[BPWG * REF];
-	__shared__ __attribute__((aligned(16))) uint8_t tiles[kThreads * 16];
+	__shared__ __attribute__((aligned(16))) uint8_t tiles[kThreads * PX];
 	__shared__ __attribute__((aligned(16))) uint8_t raws[BPWG * RAW];
 
 	// A workgroup takes `iterations` consecutive groups of BPWG blocks.  A group's life is one global round trip (its records) and three barriers for
-	// 4 KiB of output: alone that is latency, not bandwidth (0.3 of the peak with eight workgroups per CU), so the NEXT group's records and modes are
+	// 1 - 4 KiB of output: alone that is latency, not bandwidth (0.3 of the peak with eight workgroups per CU), so the NEXT group's records and modes are
 	// requested before this group's barriers and land while it computes.
 	const uint32_t first_group = xcd_contiguous(blockIdx.x, gridDim.x) * iterations;
 	const int j = (int)(threadIdx.x % LPB);
@@ -225,15 +228,13 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	}
 	__syncthreads();
 
-	Chunk<16> out;
+	Chunk<PX> out;
 	if (mode >= 2)
 	{
 		const uint32_t *ref32 = reinterpret_cast<const uint32_t *>(ref);
 		const int corner = ref[N], first = ref[N + 1];
-#pragma unroll
-		for (int r = 0; r < R; ++r)
 		{
-			const int v = N >= 16 ? 16 * j / N : R * j + r, u0 = N >= 16 ? 16 * j % N : 0;
+			const int v = PX * j / N, u0 = PX * j % N;
 			const int tt = (v + 1) * angle, idx = tt >> 5;
 			const uint32_t f = (uint32_t)tt & 31u;
 			const int s = N + u0 + idx + 1;
@@ -251,13 +252,13 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 				const uint32_t ae = a[k] & 0x00ff00ffu, ao = (a[k] >> 8) & 0x00ff00ffu, be = b & 0x00ff00ffu, bo = (b >> 8) & 0x00ff00ffu;
 				const uint32_t re = pk_lshr_u16(pk_mad_u16(ae, w0, pk_mad_u16(be, w1, 0x00100010u)), 5);
 				const uint32_t ro = pk_lshr_u16(pk_mad_u16(ao, w0, pk_mad_u16(bo, w1, 0x00100010u)), 5);
-				out.d[r * (L / 4) + k] = re | (ro << 8);
+				out.d[k] = re | (ro << 8);
 			}
 			if (edge && angle == 0 && u0 == 0)
 			{
 				// modes 26 / 10 with the boundary smoothing: the pixel next to the main edge takes half the gradient along the other edge
 				const int other = vertical ? left_at(v) : top_at(v);
-				out.d[r * (L / 4)] = (out.d[r * (L / 4)] & 0xffffff00u) | (uint32_t)clip3(0, 255, first + ((other - corner) >> 1));
+				out.d[0] = (out.d[0] & 0xffffff00u) | (uint32_t)clip3(0, 255, first + ((other - corner) >> 1));
 			}
 		}
 	}
@@ -265,10 +266,8 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	{
 		const int tn = ref[N], ln = ref[2 * N + 1];
 		const uint32_t *top32 = reinterpret_cast<const uint32_t *>(ref);
-#pragma unroll
-		for (int r = 0; r < R; ++r)
 		{
-			const int y = N >= 16 ? 16 * j / N : R * j + r, x0 = N >= 16 ? 16 * j % N : 0;
+			const int y = PX * j / N, x0 = PX * j % N;
 			const int ly = ref[N + 1 + y];
 			const int row = (y + 1) * ln + N, step = tn - ly;
 			int across = (N - 1 - x0) * ly + (x0 + 1) * tn + row;
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 					px |= (uint32_t)(((int)((tw >> (8 * b)) & 0xff) * (N - 1 - y) + across) >> (LOG2 + 1)) << (8 * b);
 					across += step;
 				}
-				out.d[r * (L / 4) + k] = px;
+				out.d[k] = px;
 			}
 		}
 	}
@@ -293,11 +292,11 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 #pragma unroll
 		for (int q = 0; q < 2 * N / 4; ++q) sum = __builtin_amdgcn_sad_u8(reinterpret_cast<const uint32_t *>(ref)[q], 0, sum);
 		const int dc = (int)(sum + N) >> (LOG2 + 1);
-		uint8_t px[16];
+		uint8_t px[PX];
 #pragma unroll
-		for (int b = 0; b < 16; ++b)
+		for (int b = 0; b < PX; ++b)
 		{
-			const int o = 16 * j + b, y = o / N, x = o % N;
+			const int o = PX * j + b, y = o / N, x = o % N;
 			int val = dc;
 			if (edge)
 			{
@@ -308,28 +307,24 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 			px[b] = (uint8_t)val;
 		}
 #pragma unroll
-		for (int k = 0; k < 4; ++k)
+		for (int k = 0; k < PX / 4; ++k)
 			out.d[k] = px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
 	}
 	// horizontal modes: the lane holds family row v (output COLUMN v), positions u0 .. u0 + L - 1 (output rows): through the tile, transposed
 	const bool transposed = mode >= 2 && !vertical;
 	if (transposed)
 	{
+		const int v = PX * j / N, u0 = PX * j % N;
 #pragma unroll
-		for (int r = 0; r < R; ++r)
-		{
-			const int v = N >= 16 ? 16 * j / N : R * j + r, u0 = N >= 16 ? 16 * j % N : 0;
-#pragma unroll
-			for (int b = 0; b < L; ++b) tile[(u0 + b) * N + v] = (uint8_t)(out.d[r * (L / 4) + b / 4] >> (8 * (b % 4)));
-		}
+		for (int b = 0; b < L; ++b) tile[(u0 + b) * N + v] = (uint8_t)(out.d[b / 4] >> (8 * (b % 4)));
 	}
 	__syncthreads();
 	if (transposed)
 	{
-		const u32x4 q = *reinterpret_cast<const u32x4 *>(tile + 16 * j);
-		out.d[0] = q.x; out.d[1] = q.y; out.d[2] = q.z; out.d[3] = q.w;
+#pragma unroll
+		for (int k = 0; k < PX / 4; ++k) out.d[k] = reinterpret_cast<const uint32_t *>(tile + PX * j)[k];
 	}
-	if (live) out.store(dst + (size_t)blk * (N * N) + 16 * j);
+	if (live) out.store(dst + (size_t)blk * (N * N) + PX * j);
 	}
 }
 
@@ -405,8 +400,9 @@ static int check_intra_args(int packed, size_t n_blocks, int *log2n)
 static int launch_intra_modes(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride, const uint8_t *modes, int mode, int packed, size_t n_blocks, hipStream_t st)
 {
 	const int log2n = (packed >> 1) & 0x7f, edge = packed & 1, n = 1 << log2n;
-	// groups of 256 lanes (4 KiB of output); a workgroup takes up to 8 of them in a row, fewer while that would leave the device under ~8 workgroups per CU
-	const uint32_t groups = ceil_div(n_blocks * (size_t)(n * n / 16), kThreads);
+	// groups of 256 lanes (a lane = one row of a 4x4 / 8x8 block, 16 bytes of a larger one); a workgroup takes up to 8 groups in a row, fewer while that
+	// would leave the device under ~8 workgroups per CU
+	const uint32_t groups = ceil_div(n_blocks * (size_t)(n < 16 ? n : n * n / 16), kThreads);
 	uint32_t iterations = 8;
 	while (iterations > 1 && groups / iterations < (uint32_t)device_cus() * 8) iterations >>= 1;
 	const uint32_t grid = ceil_div(groups, iterations);
