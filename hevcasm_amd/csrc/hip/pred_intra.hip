@@ -143,6 +143,14 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	// A workgroup takes `iterations` consecutive groups of BPWG blocks.  A group's life is one global round trip (its records) and three barriers for
 	// 1 - 4 KiB of output: alone that is latency, not bandwidth (0.3 of the peak with eight workgroups per CU), so the NEXT group's records and modes are
 	// requested before this group's barriers and land while it computes.
+	// A block's lanes all sit in ONE wave (4, 8, 16 or 64 of them) and its LDS areas are its own, so the three hand-overs of an iteration (record -> edge
+	// arrays -> rows -> transposed tile) need the wave's own LDS accesses in order, not a workgroup barrier: the four waves run free of each other.
+	auto block_sync = []()
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	};
 	const uint32_t first_group = xcd_contiguous(blockIdx.x, gridDim.x) * iterations;
 	const int j = (int)(threadIdx.x % LPB);
 	uint8_t *ref = refs + (threadIdx.x / LPB) * REF;
@@ -170,13 +178,13 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	{
 	const uint32_t blk = (first_group + it) * BPWG + threadIdx.x / LPB;
 	const bool live = blk < n_blocks;
-	const int mode = rec_mode;
+	const int mode = rec_mode;      // (as a scalar where the wave's blocks share it -- one mode per batch, 32x32: measured level or slower, not kept)
 #pragma unroll
 	for (int q = 0; q < LOADS; ++q)
 		if (j + q * LPB < N) reinterpret_cast<uint32_t *>(raw)[j + q * LPB] = rec[q];
 	if (j == 0) raw[4 * N] = (uint8_t)rec_corner;
 	if (it + 1 < iterations) request(first_group + it + 1);
-	__syncthreads();
+	block_sync();
 
 	const int angle = kIntraAngle[mode];
 	const bool vertical = mode >= 18;
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	{
 		for (int e = j; e < 2 * N; e += LPB) ref[e] = (uint8_t)(e < N ? top_at(e) : left_at(e - N));               // top 0..N-1, then left 0..N-1
 	}
-	__syncthreads();
+	block_sync();
 
 	Chunk<PX> out;
 	if (mode >= 2)
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 #pragma unroll
 		for (int b = 0; b < L; ++b) tile[(u0 + b) * N + v] = (uint8_t)(out.d[b / 4] >> (8 * (b % 4)));
 	}
-	__syncthreads();
+	block_sync();
 	if (transposed)
 	{
 #pragma unroll
@@ -406,13 +414,15 @@ static int launch_intra_modes(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t
 	uint32_t iterations = 8;
 	while (iterations > 1 && groups / iterations < (uint32_t)device_cus() * 8) iterations >>= 1;
 	const uint32_t grid = ceil_div(groups, iterations);
+#define HEVC_INTRA(NN) hipLaunchKernelGGL((pred_intra_modes_kernel<NN>), dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations)
 	switch (log2n)
 	{
-	case 2: hipLaunchKernelGGL(pred_intra_modes_kernel<4>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
-	case 3: hipLaunchKernelGGL(pred_intra_modes_kernel<8>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
-	case 4: hipLaunchKernelGGL(pred_intra_modes_kernel<16>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
-	default: hipLaunchKernelGGL(pred_intra_modes_kernel<32>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations); break;
+	case 2: HEVC_INTRA(4); break;
+	case 3: HEVC_INTRA(8); break;
+	case 4: HEVC_INTRA(16); break;
+	default: HEVC_INTRA(32); break;
 	}
+#undef HEVC_INTRA
 	return launch_status("pred_intra_modes_kernel");
 }
 
