@@ -5,98 +5,118 @@
     ->  hevcasm_pred_uni_8to8 at the winning vector  ->  residual  ->  hevcasm_transform  ->  hevcasm_quantize (levels, cbf)
     ->  hevcasm_quantize_inverse + hevcasm_inverse_transform_add (fused)  ->  reconstruction  ->  hevcasm_ssd per block, frame SSE / PSNR
 
-`stages(frame, ops)` runs the chain on whatever `ops` provides: `HipOps` = the batch C-ABI on device tensors (hevcasm_amd.batch; frames stay in HBM
-from the first stage to the last, only the 12-byte search answers are looked at on the host to build the next stage's descriptors), or -- in tests --
-an oracle-backed object with the same methods.  The one step the reference's library has no function for is the residual (current - prediction as
-int16): a codec does that itself; here it is a torch / numpy subtraction.  Host-side plumbing only; no arithmetic of the hot path lives here."""
+`stages(frame, ops)` runs the chain on whatever `ops` provides: `HipOps` = the batch C-ABI on device tensors (hevcasm_amd.batch), or -- in tests -- an
+oracle-backed object with the same methods on numpy arrays.  With HipOps NOTHING visits the host between the first stage and the last: the search
+answers become the next stage's descriptors by a few tensor operations on the device, so the whole chain is a fixed sequence of launches on one stream
+and can be captured into a HIP graph and replayed per frame (`HipOps.capture`; examples/frame_pipeline.py times both).  The two steps the reference's
+library has no function for are the residual (current - prediction as int16) and turning vectors into offsets: a codec does those itself; here they are
+torch / numpy arithmetic.  Host-side plumbing only; no arithmetic of the hot path lives here."""
 import numpy as np
 
 
 def block_grid(w, h, size, stride_cur, stride_ref, pad):
     by, bx = np.meshgrid(np.arange(h // size), np.arange(w // size), indexing="ij")
     cur_off = (by * size * stride_cur + bx * size).reshape(-1).astype(np.uint32)
-    ref_off = ((by * size + pad) * stride_ref + bx * size + pad).reshape(-1).astype(np.int64)
+    ref_off = ((by * size + pad) * stride_ref + bx * size + pad).reshape(-1).astype(np.uint32)
     return cur_off, ref_off
 
 
 def stages(frame, ops, size=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1):
-    """-> dict of every intermediate (numpy): mv, qmv, pred, residual, coeffs, levels, cbf, recon, block_ssd, frame_sse, psnr."""
+    """-> dict of every intermediate, in the backend's array type (HipOps.to_numpy() converts): mv, qmv, pred, residual, coeffs, levels, cbf, recon,
+    block_ssd, frame_sse (one element)."""
     w, h, pad = frame["w"], frame["h"], frame["pad"]
     sc, sr = frame["stride_cur"], frame["stride_ref"]
     log2n = size.bit_length() - 1
-    cur_off, ref_base = block_grid(w, h, size, sc, sr, pad)
-    n = cur_off.size
-    mv = ops.me_full_search(frame["cur"], sc, frame["ref"], sr, cur_off, ref_base.astype(np.uint32), size, size, search_range)          # (dx, dy, cost)
-    ref_int = ref_base + mv[:, 1].astype(np.int64) * sr + mv[:, 0]
-    qmv = ops.subpel_refine(frame["cur"], sc, frame["ref"], sr, cur_off, ref_int.astype(np.uint32), size, size)                            # (qx, qy, cost), quarter pels
-    ref_sub = ref_int + (qmv[:, 1] >> 2).astype(np.int64) * sr + (qmv[:, 0] >> 2)
-    frac = ((qmv[:, 0] & 3) | ((qmv[:, 1] & 3) << 4)).astype(np.uint8)
-    pred = ops.pred_uni(w * h, sc, frame["ref"], sr, cur_off, ref_sub.astype(np.uint32), frac, 8, size, size)                              # a plane laid out like the current frame
-    residual = ops.residual(frame["cur"], pred)                                                                                             # int16 plane, stride sc
+    cur, ref, cur_off, ref_base = ops.plan(frame, size)                                       # resident planes and descriptor arrays (uploaded once per frame / geometry)
+    mv = ops.me_full_search(cur, sc, ref, sr, cur_off, ref_base, size, size, search_range)   # (dx, dy, cost) per block
+    ref_int = ops.offsets_after_search(ref_base, mv, sr)
+    qmv = ops.subpel_refine(cur, sc, ref, sr, cur_off, ref_int, size, size)                  # (qx, qy, cost), quarter pels
+    ref_sub, frac = ops.subpel_descriptors(ref_int, qmv, sr)
+    pred = ops.pred_uni(w * h, sc, ref, sr, cur_off, ref_sub, frac, 8, size, size)           # a plane laid out like the current frame
+    residual = ops.residual(cur, pred)                                                       # int16 plane, stride sc
     coeffs = ops.transform(residual, sc, cur_off, 0, log2n)
     levels, cbf = ops.quantize(coeffs, qscale, qshift, qoffset, size * size)
     recon = ops.dequant_inverse_transform_add(w * h, sc, pred, sc, cur_off, cur_off, levels, dqscale, dqshift, 0, log2n)
-    block_ssd = ops.ssd(frame["cur"], sc, recon, sc, cur_off, cur_off, size, size)
-    frame_sse = ops.frame_sse(frame["cur"], sc, recon, sc, w, h)
-    psnr = float("inf") if frame_sse == 0 else 10.0 * np.log10(255.0 * 255.0 * w * h / float(frame_sse))
-    return dict(mv=mv, qmv=qmv, pred=pred, residual=residual, coeffs=coeffs, levels=levels, cbf=cbf, recon=recon, block_ssd=block_ssd,
-                frame_sse=int(frame_sse), psnr=psnr, blocks=n)
+    block_ssd = ops.ssd(cur, sc, recon, sc, cur_off, cur_off, size, size)
+    frame_sse = ops.frame_sse(cur, sc, recon, sc, w, h)
+    return dict(mv=mv, qmv=qmv, pred=pred, residual=residual, coeffs=coeffs, levels=levels, cbf=cbf, recon=recon, block_ssd=block_ssd, frame_sse=frame_sse)
+
+
+def psnr(frame_sse, w, h):
+    return float("inf") if frame_sse == 0 else 10.0 * np.log10(255.0 * 255.0 * w * h / float(frame_sse))
 
 
 class HipOps:
-    """The chain's stages on the GPU: device tensors in, numpy out only where the host needs to look (the search answers) or at the very end."""
+    """The chain's stages on the GPU.  Everything is a device tensor from plan() on; no method synchronises or copies to the host."""
 
     def __init__(self, device="cuda"):
         import torch
         from . import batch
         self.t, self.B, self.device = torch, batch, device
-        self._planes = {}
+        self._plans = {}
 
-    def _dev(self, a, dtype):
-        """Upload once per array: the frames stay resident across the stages."""
-        key = id(a)
-        if key not in self._planes:
-            self._planes[key] = (a, self.t.from_numpy(np.ascontiguousarray(a)).to(self.device))
-        return self._planes[key][1]
-
-    def _off(self, o):
-        return self.B.off32(np.ascontiguousarray(o, dtype=np.uint32))
+    def plan(self, frame, size):
+        key = (id(frame["cur"]), id(frame["ref"]), size)
+        if key not in self._plans:
+            cur_off, ref_base = block_grid(frame["w"], frame["h"], size, frame["stride_cur"], frame["stride_ref"], frame["pad"])
+            up = lambda a: self.t.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            self._plans[key] = (frame, up(frame["cur"]), up(frame["ref"]), self.B.off32(cur_off), self.B.off32(ref_base),
+                                self.B.off32(np.zeros(1, dtype=np.uint32)))
+        p = self._plans[key]
+        self._zero = p[5]
+        return p[1], p[2], p[3], p[4]
 
     def me_full_search(self, cur, sc, ref, sr, cur_off, ref_off, w, h, search_range):
-        out = self.B.me_full_search(self._dev(cur, None), sc, self._dev(ref, None), sr, self._off(cur_off), self._off(ref_off), w, h, search_range)
-        self.t.cuda.synchronize()
-        return out.cpu().numpy()
+        return self.B.me_full_search(cur, sc, ref, sr, cur_off, ref_off, w, h, search_range)
+
+    def offsets_after_search(self, ref_base, mv, sr):
+        return ref_base + mv[:, 1] * sr + mv[:, 0]                      # int32 arithmetic = the u32 offsets' bits
 
     def subpel_refine(self, cur, sc, ref, sr, cur_off, ref_off, w, h):
-        out = self.B.subpel_refine(self._dev(cur, None), sc, self._dev(ref, None), sr, self._off(cur_off), self._off(ref_off), w, h)
-        self.t.cuda.synchronize()
-        return out.cpu().numpy()
+        return self.B.subpel_refine(cur, sc, ref, sr, cur_off, ref_off, w, h)
+
+    def subpel_descriptors(self, ref_int, qmv, sr):
+        ref_sub = ref_int + (qmv[:, 1] >> 2) * sr + (qmv[:, 0] >> 2)
+        frac = ((qmv[:, 0] & 3) | ((qmv[:, 1] & 3) << 4)).to(self.t.uint8)
+        return ref_sub, frac
 
     def pred_uni(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, taps, w, h):
         dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)
-        return self.B.pred_uni(dst, sd, self._dev(ref, None), sr, self._off(dst_off), self._off(ref_off), self.B.u8(frac), taps, w, h)
+        return self.B.pred_uni(dst, sd, ref, sr, dst_off, ref_off, frac, taps, w, h)
 
     def residual(self, cur, pred):
-        return self._dev(cur, None).to(self.t.int16) - pred.to(self.t.int16)
+        return cur.to(self.t.int16) - pred.to(self.t.int16)
 
     def transform(self, residual, stride, off, tr_type, log2n):
-        return self.B.transform(residual, stride, self._off(off), tr_type, log2n)
+        return self.B.transform(residual, stride, off, tr_type, log2n)
 
     def quantize(self, coeffs, scale, shift, offset, n_per_block):
         return self.B.quantize(coeffs, scale, shift, offset, n_per_block)
 
     def dequant_inverse_transform_add(self, dst_bytes, sd, pred, sp, dst_off, pred_off, levels, scale, shift, tr_type, log2n):
         dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)
-        return self.B.dequant_inverse_transform_add(dst, sd, pred, sp, self._off(dst_off), self._off(pred_off), levels, scale, shift, tr_type, log2n)
+        return self.B.dequant_inverse_transform_add(dst, sd, pred, sp, dst_off, pred_off, levels, scale, shift, tr_type, log2n)
 
     def ssd(self, a, sa, b, sb, a_off, b_off, w, h):
-        return self.B.ssd(self._dev(a, None), sa, b, sb, self._off(a_off), self._off(b_off), w, h)
+        return self.B.ssd(a, sa, b, sb, a_off, b_off, w, h)
 
     def frame_sse(self, a, sa, b, sb, w, h):
-        zero = self._off(np.zeros(1, dtype=np.uint32))
-        out = self.B.frame_sse(self._dev(a, None), sa, b, sb, zero, zero, w, h)
-        self.t.cuda.synchronize()
-        return int(out[0])
+        return self.B.frame_sse(a, sa, b, sb, self._zero, self._zero, w, h)
+
+    def capture(self, frame, **kw):
+        """The whole chain of `frame` as ONE HIP graph (torch.cuda.CUDAGraph: stream capture of the launches stages() issues).
+        -> (graph, results): graph.replay() re-runs the chain on the frame's resident planes, results are the tensors it writes."""
+        t = self.t
+        side = t.cuda.Stream()
+        side.wait_stream(t.cuda.current_stream())
+        with t.cuda.stream(side):                  # warm-up on a side stream: uploads, allocator, first launches
+            stages(frame, self, **kw)
+        t.cuda.current_stream().wait_stream(side)
+        t.cuda.synchronize()
+        graph = t.cuda.CUDAGraph()
+        with t.cuda.graph(graph):
+            results = stages(frame, self, **kw)
+        return graph, results
 
     @staticmethod
     def to_numpy(results):

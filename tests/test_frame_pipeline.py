@@ -11,11 +11,22 @@ from oracle import pyoracle
 class OracleOps:
     """The same stages through the oracle (numpy arrays throughout)."""
 
+    def plan(self, frame, size):
+        cur_off, ref_base = pipeline.block_grid(frame["w"], frame["h"], size, frame["stride_cur"], frame["stride_ref"], frame["pad"])
+        return frame["cur"], frame["ref"], cur_off, ref_base
+
     def me_full_search(self, cur, sc, ref, sr, cur_off, ref_off, w, h, search_range):
         return pyoracle.me_full_search(cur, sc, ref, sr, cur_off, ref_off, w, h, search_range)
 
+    def offsets_after_search(self, ref_base, mv, sr):
+        return (ref_base.astype(np.int64) + mv[:, 1].astype(np.int64) * sr + mv[:, 0]).astype(np.uint32)
+
     def subpel_refine(self, cur, sc, ref, sr, cur_off, ref_off, w, h):
         return pyoracle.subpel_refine(cur, sc, ref, sr, cur_off, ref_off, w, h)
+
+    def subpel_descriptors(self, ref_int, qmv, sr):
+        ref_sub = (ref_int.astype(np.int64) + (qmv[:, 1] >> 2).astype(np.int64) * sr + (qmv[:, 0] >> 2)).astype(np.uint32)
+        return ref_sub, ((qmv[:, 0] & 3) | ((qmv[:, 1] & 3) << 4)).astype(np.uint8)
 
     def pred_uni(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, taps, w, h):
         return pyoracle.pred_uni_batch(taps, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, w, h)
@@ -37,7 +48,7 @@ class OracleOps:
 
     def frame_sse(self, a, sa, b, sb, w, h):
         z = np.zeros(1, dtype=np.uint32)
-        return int(pyoracle.frame_sse_batch(a, sa, b, sb, z, z, w, h)[0])
+        return pyoracle.frame_sse_batch(a, sa, b, sb, z, z, w, h)
 
 
 def _with_half_pel_motion(frame):
@@ -56,9 +67,9 @@ def test_pipeline_on_the_oracle_is_a_sane_encode(oracle_lib):
     frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(192, 128, 16, seed=4, ctu=16, max_motion=6))
     r = pipeline.stages(frame, OracleOps(), size=16, search_range=8)
     assert (r["qmv"][:, :2] & 3).any()
-    assert r["blocks"] == 96 and (np.abs(r["mv"][:, :2]) <= 8).all() and (np.abs(r["qmv"][:, :2]) <= 3).all()
-    assert (r["mv"][:, :2] != 0).any() and r["psnr"] > 30.0
-    assert r["frame_sse"] == int(r["block_ssd"].astype(np.int64).sum())          # the frame is tiled exactly by its blocks
+    assert r["mv"].shape == (96, 3) and (np.abs(r["mv"][:, :2]) <= 8).all() and (np.abs(r["qmv"][:, :2]) <= 3).all()
+    assert (r["mv"][:, :2] != 0).any() and pipeline.psnr(int(r["frame_sse"][0]), 192, 128) > 30.0
+    assert int(r["frame_sse"][0]) == int(r["block_ssd"].astype(np.int64).sum())          # the frame is tiled exactly by its blocks
     assert np.array_equal(r["cbf"] != 0, (r["levels"].reshape(96, -1) != 0).any(axis=1))
 
 
@@ -68,10 +79,34 @@ def test_pipeline_hip_equals_oracle_stage_by_stage(w, h, size, rng):
     frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + size, ctu=size, max_motion=rng - 2))
     want = pipeline.stages(frame, OracleOps(), size=size, search_range=rng)
     got = pipeline.HipOps.to_numpy(pipeline.stages(frame, pipeline.HipOps(), size=size, search_range=rng))
-    for key in ("mv", "qmv", "pred", "residual", "coeffs", "levels", "cbf", "recon", "block_ssd"):
+    _same_stages(got, want)
+    assert (got["qmv"][:, :2] & 3).any(), "the case must exercise fractional prediction"
+
+
+def _same_stages(got, want):
+    for key in ("mv", "qmv", "pred", "residual", "coeffs", "levels", "cbf", "recon", "block_ssd", "frame_sse"):
         g, wv = np.asarray(got[key]), np.asarray(want[key])
         if key == "cbf":                                     # only zero / non-zero is meaningful (reference quantize.c:257)
             g, wv = g != 0, wv != 0
         assert g.shape == wv.shape and np.array_equal(g, wv), "stage %s differs (%d of %d)" % (key, int((g != wv).sum()), g.size)
-    assert got["frame_sse"] == want["frame_sse"] and got["psnr"] == want["psnr"]
-    assert (got["qmv"][:, :2] & 3).any(), "the case must exercise fractional prediction"
+
+
+@pytest.mark.gpu
+def test_pipeline_as_one_hip_graph():
+    """The chain has no host step between its launches, so it captures into ONE HIP graph; replayed (twice), its outputs are the eager run's and the
+    oracle's, and after the frame's content is changed IN PLACE on the device a replay follows it."""
+    import torch
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(640, 352, 16, seed=21, ctu=16, max_motion=6))
+    want = pipeline.stages(frame, OracleOps(), size=16, search_range=8)
+    ops = pipeline.HipOps()
+    graph, results = ops.capture(frame, size=16, search_range=8)
+    for _ in range(2):
+        graph.replay()
+    _same_stages(pipeline.HipOps.to_numpy(results), want)
+    # new content in the resident planes (the next frame of a sequence): same graph, new answers
+    frame2 = _with_half_pel_motion(me_frame.synthetic_frame_pair(640, 352, 16, seed=22, ctu=16, max_motion=6))
+    cur_dev, ref_dev, _, _ = ops.plan(frame, 16)
+    cur_dev.copy_(torch.from_numpy(frame2["cur"]))
+    ref_dev.copy_(torch.from_numpy(frame2["ref"]))
+    graph.replay()
+    _same_stages(pipeline.HipOps.to_numpy(results), pipeline.stages(frame2, OracleOps(), size=16, search_range=8))
