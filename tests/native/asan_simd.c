@@ -172,8 +172,35 @@ static void test_quant_and_costs(void)
 	}
 }
 
+/* the host C intra entries (planar, DC, every angular mode) on records of EXACTLY the bytes the layout promises: the 4N + 1 samples at the end of a
+ * heap block that stops at byte 128, preceded by nothing below byte 64 - 2N (the record pointer is moved so that byte 64 - 2N is the block's first):
+ * a read outside [64 - 2N, 64 + 2N) or [128] is an ASan error; for sizes below 32 the bytes between 64 + 2N and 128 are poison values (they lie inside
+ * the block) and must not change the result. */
+static void test_intra(void)
+{
+	for (int log2n = 2; log2n <= 5; ++log2n)
+		for (int edge = 0; edge <= (log2n < 5); ++edge)
+		{
+			const int n = 1 << log2n, packed = (8 << 8) | (log2n << 1) | edge;
+			const size_t first = (size_t)(64 - 2 * n), bytes = 129 - first;
+			uint8_t *block = malloc(bytes), *nb = block - first;          /* nb[64 - 2N] is block[0]; nothing below it exists */
+			uint8_t *a = malloc((size_t)n * n), *b = malloc((size_t)n * n);
+			for (int mode = 0; mode < 35; ++mode)
+			{
+				for (size_t i = 0; i < bytes; ++i) block[i] = (uint8_t)rnd();
+				hevcasm_pred_intra *f = mode == 0 ? hevcasm_c_pred_intra_planar : mode == 1 ? hevcasm_c_pred_intra_dc : hevcasm_c_pred_intra_angular;
+				f(a, nb, mode, packed);
+				for (int i = 64 + 2 * n; i < 128; ++i) nb[i] ^= 0x5a;     /* bytes of the record that no sample lives in */
+				f(b, nb, mode, packed);
+				CHECK(!memcmp(a, b, (size_t)n * n), "intra %dx%d mode %d reads bytes outside its samples", n, n, mode);
+			}
+			free(block); free(a); free(b);
+		}
+}
+
 int main(void)
 {
+	test_intra();
 	test_pred();
 	test_transforms();
 	test_quant_and_costs();
