@@ -1053,3 +1053,59 @@ def test_frame_sse_full_size():
     s = B.frame_sse(c, stride, d, stride, B.off32(a_off), B.off32(a_off), fw, fh)
     torch.cuda.synchronize()
     assert bool((s == 9 * fw * fh).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [2, 4, 8])
+def test_satd_full_size_properties(size):
+    """Hadamard SATD over 2^26 pixels per launch (the bench's size; the oracle cases stop at a few hundred blocks): SATD(x, x) = 0; symmetric; bounded below
+    by the DC term -- |sum of the block's differences| is one of the N^2 coefficients the sum of absolutes runs over, so SATD >= (|sum d| + N / 4) / (N / 2)
+    (hadamard.c:98, :110) -- and above by N^2 times the largest coefficient; first and last 4096 blocks against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    n = (1 << 26) // (size * size)
+    side = max(size, 4)
+    c = wl.sad_case(side, side, n, 5150 + size, frame=(wl.FRAME_W, wl.FRAME_H), device="cuda")
+    src, ref, so, ro = c["src"], c["ref"], B.off32(c["src_off"]), B.off32(c["ref_off"])
+    log2 = size.bit_length() - 1
+    zero = B.hadamard_satd(src, c["stride_src"], src, c["stride_src"], so, so, log2)
+    assert int(zero.abs().max()) == 0
+    ab = B.hadamard_satd(src, c["stride_src"], ref, c["stride_ref"], so, ro, log2)
+    ba = B.hadamard_satd(ref, c["stride_ref"], src, c["stride_src"], ro, so, log2)
+    assert torch.equal(ab, ba)
+    rows = torch.arange(size, device="cuda", dtype=torch.int64)
+    ia = torch.from_numpy(c["src_off"].astype(np.int64)).cuda()[:, None, None] + rows[None, :, None] * c["stride_src"] + rows[None, None, :]
+    ib = torch.from_numpy(c["ref_off"].astype(np.int64)).cuda()[:, None, None] + rows[None, :, None] * c["stride_ref"] + rows[None, None, :]
+    d = src[ia].to(torch.int32) - ref[ib].to(torch.int32)
+    dc = d.sum(dim=(1, 2)).abs()
+    half = max(size // 2, 1)
+    assert bool((ab >= (dc + size // 4) // half).all()) and bool((ab <= (size * size * d.abs().sum(dim=(1, 2)) + size // 4) // half).all())
+    src_h, ref_h, got = src.cpu().numpy(), ref.cpu().numpy(), ab.cpu().numpy()
+    for sl in (slice(0, 4096), slice(n - 4096, n)):
+        want = pyoracle.hadamard_satd_batch(size, src_h, c["stride_src"], ref_h, c["stride_ref"], c["src_off"][sl], c["ref_off"][sl])
+        assert np.array_equal(got[sl], want), (size, sl)
+
+
+@pytest.mark.gpu
+def test_ssd_linear_full_size_properties():
+    """hevcasm_hip_ssd_linear_batch over 2 x 256 MiB cut into runs of every kernel variant's length: zero on identical runs, symmetric, the runs of a
+    plane add up to the plane's frame SSE (64-bit), first and last runs against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B, workload as wl
+    from oracle import pyoracle
+    total = 1 << 28
+    a, b = wl.fill_u8(total, 61, device="cuda"), wl.fill_u8(total, 62, device="cuda")
+    zero32 = B.off32(np.zeros(1, dtype=np.uint32))
+    whole = int(B.frame_sse(a, 1 << 14, b, 1 << 14, zero32, zero32, 1 << 14, 1 << 14)[0])        # the same bytes as 16384 rows of 16384
+    a_h, b_h = a[: 1 << 20].cpu().numpy(), b[: 1 << 20].cpu().numpy()
+    for size in (48, 0x200, 1920, 32768):
+        n = total // size
+        off = B.off32((np.arange(n, dtype=np.int64) * size).astype(np.uint32))
+        ab = B.ssd_linear(a, b, off, off, size)
+        assert torch.equal(ab, B.ssd_linear(b, a, off, off, size)) and int(B.ssd_linear(a, a, off, off, size).abs().max()) == 0
+        if n * size == total:
+            assert int(ab.to(torch.int64).sum()) == whole, size
+        k = min(n, (1 << 20) // size)
+        want = pyoracle.ssd_linear_batch(a_h, b_h, (np.arange(k, dtype=np.int64) * size).astype(np.uint32), (np.arange(k, dtype=np.int64) * size).astype(np.uint32), size)
+        assert np.array_equal(ab[:k].cpu().numpy(), want), size
