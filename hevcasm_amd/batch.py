@@ -216,23 +216,36 @@ def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metr
 
 
 def pred_intra(dst, neighbours, neighbour_stride, mode, packed, n):
-    """Batched hevcasm_pred_intra (INTRA_DC): block i reads neighbours + i * neighbour_stride, writes dst[i * N * N ...]."""
-    check(lib().hevcasm_hip_pred_intra_batch(dst.data_ptr(), neighbours.data_ptr(), neighbour_stride, mode, packed, n, _stream()), "pred_intra_batch")
+    """Batched hevcasm_pred_intra, one mode for the batch: block i reads neighbours + i * neighbour_stride, writes dst[i * N * N ...].
+    packed | INTRA_COMPACT: compact records (see pred_intra_modes)."""
+    check(lib().hevcasm_hip_pred_intra_batch(dst.data_ptr(), _intra_base(neighbours, packed, (packed >> 1) & 0x7f), neighbour_stride, mode, packed, n, _stream()), "pred_intra_batch")
     return dst
 
 
+INTRA_COMPACT = 0x10000     # HEVCASM_HIP_INTRA_COMPACT: the corner sample at [64 + 2N], records of 4N + 1 contiguous bytes
+
+
+def _intra_base(neighbours, packed_or_log2, log2n):
+    """The `neighbours` argument: the tensor's first byte is record 0's byte 0 -- or, for compact records, record 0's first SAMPLE (byte 64 - 2N of the
+    record), in which case the pointer handed over lies 64 - 2N bytes before the tensor (never dereferenced there)."""
+    return neighbours.data_ptr() - ((64 - (2 << log2n)) if packed_or_log2 & INTRA_COMPACT else 0)
+
+
 def pred_intra_modes(dst, neighbours, neighbour_stride, modes, packed):
-    """One intra mode per block (modes: uint8 tensor, 0..34).  Mode 1 is pinned to the reference; the others follow H.265 8.4.4.2.4 / .6 (unpinned)."""
+    """One intra mode per block (modes: uint8 tensor, 0..34).  Mode 1 is pinned to the reference; the others follow H.265 8.4.4.2.4 / .6 (unpinned).
+    packed | INTRA_COMPACT: `neighbours` holds compact records (4N + 1 samples each, neighbour_stride apart, the first at the tensor's first byte)."""
     assert modes.dtype == torch.uint8 and modes.is_contiguous()
-    check(lib().hevcasm_hip_pred_intra_modes_batch(dst.data_ptr(), neighbours.data_ptr(), neighbour_stride, modes.data_ptr(), packed, modes.numel(), _stream()), "pred_intra_modes_batch")
+    check(lib().hevcasm_hip_pred_intra_modes_batch(dst.data_ptr(), _intra_base(neighbours, packed, (packed >> 1) & 0x7f), neighbour_stride, modes.data_ptr(), packed, modes.numel(),
+                                                   _stream()), "pred_intra_modes_batch")
     return dst
 
 
 def intra_filter_neighbours(neighbours, neighbour_stride, log2n, strong, n, out=None, out_stride=129):
     """H.265 8.4.4.2.3 (unpinned): the smoothed copies of n neighbour records, out_stride bytes apart."""
     out = torch.zeros(out_stride * n, dtype=torch.uint8, device=neighbours.device) if out is None else out
-    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= out_stride * (n - 1) + 129
-    check(lib().hevcasm_hip_intra_filter_neighbours_batch(out.data_ptr(), out_stride, neighbours.data_ptr(), neighbour_stride, log2n, int(strong), n, _stream()), "intra_filter_neighbours_batch")
+    assert out.dtype == torch.uint8 and out.is_contiguous() and out.numel() >= out_stride * (n - 1) + ((4 << (log2n & 0xff)) + 1 if log2n & INTRA_COMPACT else 129)
+    check(lib().hevcasm_hip_intra_filter_neighbours_batch(_intra_base(out, log2n, log2n & 0xff), out_stride, _intra_base(neighbours, log2n, log2n & 0xff), neighbour_stride, log2n, int(strong), n,
+                                                          _stream()), "intra_filter_neighbours_batch")
     return out
 
 

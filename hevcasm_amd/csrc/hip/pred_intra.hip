@@ -124,7 +124,7 @@ __device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, uint32_t sh)
 template <int N>
 __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	uint8_t *__restrict__ dst, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride,
-	const uint8_t *__restrict__ modes, int uniform_mode, int edge, uint32_t n_blocks, uint32_t iterations)
+	const uint8_t *__restrict__ modes, int uniform_mode, int edge, uint32_t n_blocks, uint32_t iterations, int corner_at /* 128, or 64 + 2N for compact records */)
 {
 	constexpr int PX = N < 16 ? N : 16;        // output bytes per lane = one family row (4x4, 8x8: a whole row; 16: a row; 32: half a row)
 	constexpr int LPB = N * N / PX;            // lanes per block: 4, 8, 16, 64.  (A lane per 16 bytes at 4x4 / 8x8 -- 1 and 4 lanes per block -- measured the
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 #pragma unroll
 		for (int q = 0; q < LOADS; ++q)
 			if (j + q * LPB < N) rec[q] = reinterpret_cast<const U1 *>(nb + 64 - 2 * N + 4 * (j + q * LPB))->v;
-		if (j == 0) rec_corner = nb[128];
+		if (j == 0) rec_corner = nb[corner_at];
 		if (modes) rec_mode = (int)modes[b];
 	};
 	request(first_group);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 // patched in at the junction, even / odd bytes on packed 16-bit adds); lane N of a block writes the corner.  `strong`: strong_intra_smoothing_enabled_flag
 // -- 32x32 blocks whose two edges are flat take the bi-linear form, decided per block.  (First form, a lane per byte: 0.04-0.07 of the HBM peak.)
 __global__ __launch_bounds__(kThreads) void intra_filter_neighbours_kernel(
-	uint8_t *__restrict__ out, ptrdiff_t out_stride, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride, int N, int strong, uint32_t n_blocks)
+	uint8_t *__restrict__ out, ptrdiff_t out_stride, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride, int N, int strong, uint32_t n_blocks, int corner_at)
 {
 	const uint32_t per = (uint32_t)N + 1;
 	const uint64_t t = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
@@ -350,14 +350,14 @@ __global__ __launch_bounds__(kThreads) void intra_filter_neighbours_kernel(
 	if (blk >= n_blocks) return;
 	const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
 	uint8_t *o = out + (ptrdiff_t)blk * out_stride;
-	const int corner = nb[128];
+	const int corner = nb[corner_at];
 	bool bi = false;
 	if (strong && N == 32)
 	{
 		const int a = corner + nb[64 + 63] - 2 * nb[64 + 31], b = corner + nb[63 - 63] - 2 * nb[63 - 31];
 		bi = abs(a) < 8 && abs(b) < 8;
 	}
-	if (s == (uint32_t)N) { o[128] = bi ? (uint8_t)corner : (uint8_t)((nb[63] + 2 * corner + nb[64] + 2) >> 2); return; }
+	if (s == (uint32_t)N) { o[corner_at] = bi ? (uint8_t)corner : (uint8_t)((nb[63] + 2 * corner + nb[64] + 2) >> 2); return; }
 	const int m = 64 - 2 * N + 4 * (int)s;                      // the dword's first byte in the record
 	const uint32_t cur = reinterpret_cast<const U1 *>(nb + m)->v;
 	uint32_t res;
@@ -414,7 +414,8 @@ static int launch_intra_modes(uint8_t *dst, const uint8_t *neighbours, ptrdiff_t
 	uint32_t iterations = 8;
 	while (iterations > 1 && groups / iterations < (uint32_t)device_cus() * 8) iterations >>= 1;
 	const uint32_t grid = ceil_div(groups, iterations);
-#define HEVC_INTRA(NN) hipLaunchKernelGGL((pred_intra_modes_kernel<NN>), dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations)
+	const int corner_at = (packed & HEVCASM_HIP_INTRA_COMPACT) ? 64 + 2 * n : 128;
+#define HEVC_INTRA(NN) hipLaunchKernelGGL((pred_intra_modes_kernel<NN>), dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, modes, mode, edge, (uint32_t)n_blocks, iterations, corner_at)
 	switch (log2n)
 	{
 	case 2: HEVC_INTRA(4); break;
@@ -468,6 +469,8 @@ extern "C" int hevcasm_hip_intra_filter_neighbours_batch(
 	int log2TrafoSize, int strong_intra_smoothing, size_t n_blocks, void *stream)
 {
 	if (int e = check_device()) return e;
+	const bool compact = (log2TrafoSize & HEVCASM_HIP_INTRA_COMPACT) != 0;      // the same flag as in `packed`, on the size argument here
+	log2TrafoSize &= ~HEVCASM_HIP_INTRA_COMPACT;
 	if (log2TrafoSize < 2 || log2TrafoSize > 5) return set_error(HEVCASM_HIP_EINVAL, "block size must be 4, 8, 16 or 32");
 	if (n_blocks == 0) return 0;
 	if (!filtered || !neighbours) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
@@ -475,6 +478,6 @@ extern "C" int hevcasm_hip_intra_filter_neighbours_batch(
 	if (n_blocks > 0x7fffffffull * kThreads / (size_t)(n + 1)) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large for one launch");
 	const uint32_t grid = ceil_div(n_blocks * (size_t)(n + 1), kThreads);
 	hipLaunchKernelGGL(intra_filter_neighbours_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), filtered, filtered_stride, neighbours, neighbour_stride, n, strong_intra_smoothing,
-			(uint32_t)n_blocks);
+			(uint32_t)n_blocks, compact ? 64 + 2 * n : 128);
 	return launch_status("intra_filter_neighbours_kernel");
 }

@@ -146,6 +146,14 @@ int hevcasm_hip_pred_intra_batch(
 	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
 	int intraPredMode, int packed, size_t n_blocks, void *stream);
 
+/* Batch-API extension of `packed` (not part of the reference's packing; bits 0..15 stay f265's): COMPACT RECORDS.  The reference's layout puts the corner
+ * at [128] whatever the block size, so a 4x4 block drags a 129-byte record behind its 17 samples and the batch moves 5x its algorithmic bytes.  With
+ * this flag the corner is read at [64 + 2N] -- directly behind the top row -- so a record is the 4N + 1 contiguous bytes [64 - 2N, 64 + 2N] and
+ * neighbour_stride may be as small as 4N + 1.  `neighbours` still points 64 - 2N bytes BEFORE block 0's first sample (it may point before the allocation:
+ * nothing below [64 - 2N] is ever read).  Accepted in `packed` by the two intra prediction entry points (INTRA_DC never reads the corner and accepts it
+ * too) and, or-ed into log2TrafoSize, by hevcasm_hip_intra_filter_neighbours_batch (input and output records alike). */
+#define HEVCASM_HIP_INTRA_COMPACT 0x10000
+
 /* The same with one mode PER BLOCK (modes[i] in 0..34): what a frame's intra blocks of one size look like to an encoder's mode decision or a
  * decoder's reconstruction wavefront.  Parity as above: mode 1 pinned, the others unpinned. */
 int hevcasm_hip_pred_intra_modes_batch(

@@ -154,3 +154,44 @@ def test_hip_intra_full_size_against_the_definition():
             assert np.array_equal(host[sl.start * size * size: sl.stop * size * size], want), (log2, sl)
         del nb, dst, modes
         torch.cuda.empty_cache()
+
+
+def _compact(nb, stride, log2, n):
+    """The 4N + 1 samples of n reference-layout records, as compact records 4N + 1 bytes apart (+ 3 of padding)."""
+    size = 1 << log2
+    cs = 4 * size + 1 + 3
+    out = np.zeros(cs * n + 8, dtype=np.uint8)
+    rec = np.asarray(nb)[: stride * (n - 1) + 129]
+    for i in range(n):
+        out[i * cs: i * cs + 4 * size] = nb[i * stride + 64 - 2 * size: i * stride + 64 + 2 * size]
+        out[i * cs + 4 * size] = nb[i * stride + 128]
+    return out, cs
+
+
+@pytest.mark.gpu
+def test_hip_compact_records_equal_reference_layout_records():
+    """HEVCASM_HIP_INTRA_COMPACT (a batch-API extension: the corner directly behind the top row, records of 4N + 1 bytes): prediction with a mode per block, one
+    mode per batch (DC included) and the neighbour smoothing give what the same samples give in the reference's 129-byte layout."""
+    import torch
+    from hevcasm_amd import batch as B
+    rng = np.random.default_rng(5)
+    for log2, edge, packed in _packings():
+        size, n = 1 << log2, 333
+        nb = wl.fill_u8(144 * n + 64, 70 + log2)
+        modes = rng.integers(0, 35, n).astype(np.uint8)
+        comp, cs = _compact(nb, 144, log2, n)
+        want = pyoracle.pred_intra_modes_batch(nb, 144, modes, packed)
+        dst = torch.zeros(n * size * size, dtype=torch.uint8, device="cuda")
+        B.pred_intra_modes(dst, B.u8(comp), cs, B.u8(modes), packed | B.INTRA_COMPACT)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), want), (log2, edge)
+        for mode in (1, 0, 26, 13):
+            B.pred_intra(dst, B.u8(comp), cs, mode, packed | B.INTRA_COMPACT, n)
+            torch.cuda.synchronize()
+            assert np.array_equal(dst.cpu().numpy(), pyoracle.pred_intra_modes_batch(nb, 144, np.full(n, mode, dtype=np.uint8), packed)), (log2, edge, mode)
+        f = B.intra_filter_neighbours(B.u8(comp), cs, log2 | B.INTRA_COMPACT, 1, n, out_stride=cs)
+        torch.cuda.synchronize()
+        got, _ = f.cpu().numpy(), None
+        ref = pyoracle.intra_filter_neighbours_batch(nb, 144, log2, 1, n, out_stride=144)
+        want_c, _ = _compact(ref, 144, log2, n)
+        assert np.array_equal(got[: cs * n].reshape(n, cs)[:, : 4 * size + 1], want_c[: cs * n].reshape(n, cs)[:, : 4 * size + 1]), log2

@@ -329,6 +329,12 @@ def bench_intra_modes(pixels=1 << 28):
         modes = B.u8(np.random.default_rng(log2).integers(0, 35, nb).astype(np.uint8))
         ms = timed(lambda i: B.pred_intra_modes(dst, neigh, 144, modes, packed))
         report("pred_intra_modes (random per block)", nb, size * size + 4 * size + 2, ms, size="%dx%d" % (size, size))
+        # compact records (HEVCASM_HIP_INTRA_COMPACT: 4N + 1 contiguous samples per block instead of the reference's 129-byte layout)
+        cs = 4 * size + 1
+        comp = wl.fill_u8(cs * nb + 64, 460 + log2, device="cuda")
+        ms = timed(lambda i: B.pred_intra_modes(dst, comp, cs, modes, packed | B.INTRA_COMPACT))
+        report("pred_intra_modes compact records", nb, size * size + 4 * size + 2, ms, size="%dx%d" % (size, size))
+        del comp
         filt = torch.zeros(144 * nb, dtype=torch.uint8, device="cuda")
         ms = timed(lambda i: B.intra_filter_neighbours(neigh, 144, log2, 1, nb, out=filt, out_stride=144))
         report("intra_filter_neighbours", nb, 2 * (4 * size + 1), ms, size="%dx%d" % (size, size))
