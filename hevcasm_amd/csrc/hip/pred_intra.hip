@@ -17,6 +17,13 @@
 
 namespace hevc {
 
+// A lane's 16 output bytes are one global round trip (its share of the 2N neighbour bytes) and one store: a workgroup that does this once is all latency
+// (eight of them per CU keep 3.4 TB/s of stores going, a fill kernel reaches 5-7).  So a workgroup takes DC_UNROLL consecutive groups of 256 lanes and
+// issues every group's loads before the first group's arithmetic.  Same-box A/B at 2^28 pixels (profiles/r05_intra_dc_unroll_ab.txt): four groups against
+// one: 32x32 -20 %, 16x16 -4 ... -7 %, 8x8 +0.5 ... +7 %, 4x4 -3 ... +7 % (the small blocks are bound by their records); eight groups: no better anywhere.
+// So: four groups from 16x16 up, one below.
+template <int N> struct DcUnroll { static constexpr int K = N >= 16 ? 4 : 1; };
+
 template <int N>
 __global__ __launch_bounds__(kThreads) void pred_intra_dc_kernel(
 	uint8_t *__restrict__ dst, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride,
@@ -24,70 +31,89 @@ __global__ __launch_bounds__(kThreads) void pred_intra_dc_kernel(
 {
 	constexpr int LPB = N * N / 16;            // lanes per block: 1, 4, 16, 64
 	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-	const uint32_t t = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	uint32_t blk = t / LPB;
-	const uint32_t j = t % LPB;
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;
-	const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
+	constexpr int K = DcUnroll<N>::K;
+	constexpr int LOADERS = N == 4 ? 1 : 2 * N / 16;
+	constexpr int ROWS = N >= 16 ? 1 : 16 / N, COLS = N >= 16 ? 16 : N;
+	const uint32_t t0 = xcd_contiguous(blockIdx.x, gridDim.x) * (kThreads * K) + threadIdx.x;
 
-	// DC value, pred_intra.c:66-76: (N + sum of the 2N samples) >> (log2 N + 1)
-	uint32_t sum = 0;
-	if (N == 4)
-	{
-		Chunk<8> c;
-		c.load(nb + 60);
-		sum = __builtin_amdgcn_sad_u8(c.d[0], 0, __builtin_amdgcn_sad_u8(c.d[1], 0, 0));
-	}
-	else if ((int)j < 2 * N / 16)
-	{
-		Chunk<16> c;
-		c.load(nb + 64 - N + 16 * j);
+	// phase 1: every group's loads (no lane is switched off: a lane past the batch repeats the last block, a lane that is not one of its block's loaders
+	// repeats a loader's chunk -- the same lines, no branch between the loads)
+	Chunk<N == 4 ? 8 : 16> sums[K];
+	Chunk<COLS> tops[K];
+	uint32_t lefts[K][ROWS], corner_l[K], corner_t[K];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) sum = __builtin_amdgcn_sad_u8(c.d[k], 0, sum);
-	}
-	if (N >= 8)
+	for (int k = 0; k < K; ++k)
 	{
-		constexpr int LOADERS = 2 * N / 16;
+		const uint32_t t = t0 + (uint32_t)k * kThreads;
+		uint32_t blk = t / LPB;
+		const uint32_t j = t % LPB;
+		if (blk >= n_blocks) blk = n_blocks - 1;
+		const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
+		if (N == 4) sums[k].load(nb + 60);
+		else sums[k].load(nb + 64 - N + 16 * (j % LOADERS));
+		if (filter_edge)
+		{
+			const int y0 = 16 * (int)j / N, x0 = 16 * (int)j % N;
+			tops[k].load(nb + 64 + x0);                       // samples (x0 .. x0 + COLS - 1, -1): used by the lanes of row 0
 #pragma unroll
-		for (int d = LOADERS / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, kWave);
-		sum = __shfl(sum, (int)((threadIdx.x & 63) - j), kWave);      // the block's first lane holds the total
+			for (int r = 0; r < ROWS; ++r) lefts[k][r] = nb[63 - (y0 + r)];
+			corner_l[k] = nb[63];
+			corner_t[k] = nb[64];
+		}
 	}
-	const int dc = (int)(sum + N) >> (LOG2 + 1);
+	// phase 2: per group, the DC value and the 16 bytes
+#pragma unroll
+	for (int k = 0; k < K; ++k)
+	{
+		const uint32_t t = t0 + (uint32_t)k * kThreads;
+		const uint32_t blk = t / LPB, j = t % LPB;
+		const bool live = blk < n_blocks;
+		// DC value, pred_intra.c:66-76: (N + sum of the 2N samples) >> (log2 N + 1)
+		uint32_t sum = 0;
+		if (N == 4) sum = __builtin_amdgcn_sad_u8(sums[k].d[0], 0, __builtin_amdgcn_sad_u8(sums[k].d[1], 0, 0));
+		else
+		{
+			if ((int)j < LOADERS)
+			{
+#pragma unroll
+				for (int q = 0; q < 4; ++q) sum = __builtin_amdgcn_sad_u8(sums[k].d[q], 0, sum);
+			}
+#pragma unroll
+			for (int d = LOADERS / 2; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, kWave);
+			sum = __shfl(sum, (int)((threadIdx.x & 63) - j), kWave);      // the block's first lane holds the total
+		}
+		const int dc = (int)(sum + N) >> (LOG2 + 1);
 
-	Chunk<16> out;
+		Chunk<16> out;
 #pragma unroll
-	for (int k = 0; k < 4; ++k) out.d[k] = (uint32_t)dc * 0x01010101u;
-	if (filter_edge)
-	{
-		// pred_intra.c:80-93: first row and first column blend the neighbours into the DC value.
-		// A lane owns 16 consecutive output bytes = ROWS rows of min(N, 16) columns.
-		constexpr int ROWS = N >= 16 ? 1 : 16 / N, COLS = N >= 16 ? 16 : N;
-		const int y0 = 16 * (int)j / N, x0 = 16 * (int)j % N;
-		uint8_t px[16];
-#pragma unroll
-		for (int b = 0; b < 16; ++b) px[b] = (uint8_t)dc;
-		if (y0 == 0)
+		for (int q = 0; q < 4; ++q) out.d[q] = (uint32_t)dc * 0x01010101u;
+		if (filter_edge)
 		{
-			Chunk<COLS> top;                       // samples (x0 .. x0 + COLS - 1, -1)
-			top.load(nb + 64 + x0);
+			// pred_intra.c:80-93: first row and first column blend the neighbours into the DC value.
+			// A lane owns 16 consecutive output bytes = ROWS rows of min(N, 16) columns.
+			const int y0 = 16 * (int)j / N, x0 = 16 * (int)j % N;
+			uint8_t px[16];
 #pragma unroll
-			for (int b = 0; b < COLS; ++b) px[b] = (uint8_t)((((top.d[b / 4] >> (8 * (b % 4))) & 0xff) + 3 * dc + 2) >> 2);
+			for (int b = 0; b < 16; ++b) px[b] = (uint8_t)dc;
+			if (y0 == 0)
+			{
+#pragma unroll
+				for (int b = 0; b < COLS; ++b) px[b] = (uint8_t)((((tops[k].d[b / 4] >> (8 * (b % 4))) & 0xff) + 3 * dc + 2) >> 2);
+			}
+			if (x0 == 0)
+			{
+#pragma unroll
+				for (int r = 0; r < ROWS; ++r)
+					if (y0 + r > 0) px[r * COLS] = (uint8_t)((lefts[k][r] + 3 * dc + 2) >> 2);
+				if (y0 == 0) px[0] = (uint8_t)((corner_l[k] + 2 * dc + corner_t[k] + 2) >> 2);
+			}
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+				out.d[q] = px[4 * q] | ((uint32_t)px[4 * q + 1] << 8) | ((uint32_t)px[4 * q + 2] << 16) | ((uint32_t)px[4 * q + 3] << 24);
 		}
-		if (x0 == 0)
-		{
-#pragma unroll
-			for (int r = 0; r < ROWS; ++r)
-				if (y0 + r > 0) px[r * COLS] = (uint8_t)((nb[63 - (y0 + r)] + 3 * dc + 2) >> 2);
-			if (y0 == 0) px[0] = (uint8_t)((nb[63] + 2 * dc + nb[64] + 2) >> 2);
-		}
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-			out.d[k] = px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
+		if (live) out.store(dst + (size_t)blk * (N * N) + 16 * j);
 	}
-	if (live) out.store(dst + (size_t)blk * (N * N) + 16 * j);
 }
-
 
 // ---- all 35 modes (round 5; parity unpinned beyond DC) -------------------------------------------------------------------
 //
@@ -441,7 +467,7 @@ extern "C" int hevcasm_hip_pred_intra_batch(
 	hipStream_t st = as_stream(stream);
 	if (intraPredMode != 1) return launch_intra_modes(dst, neighbours, neighbour_stride, nullptr, intraPredMode, packed, n_blocks, st);
 	const int n = 1 << log2n;
-	const uint32_t grid = ceil_div(n_blocks * (size_t)(n * n / 16), kThreads);
+	const uint32_t grid = ceil_div(n_blocks * (size_t)(n * n / 16), (size_t)kThreads * (n >= 16 ? DcUnroll<16>::K : DcUnroll<4>::K));
 	switch (log2n)
 	{
 	case 2: hipLaunchKernelGGL(pred_intra_dc_kernel<4>, dim3(grid), dim3(kThreads), 0, st, dst, neighbours, neighbour_stride, filter_edge, (uint32_t)n_blocks); break;

@@ -298,13 +298,14 @@ def bench_satd():
         torch.cuda.empty_cache()
 
 
-def bench_intra():
-    """INTRA_DC over 2^26 output pixels per launch, 128-byte neighbour records."""
+def bench_intra(pixels=1 << 28):
+    """INTRA_DC over 2^28 output pixels per launch (2^26 until round 5: a 64 MB launch is 8 us at the HBM peak, i.e. mostly ramp), 128-byte
+    neighbour records and packed ones."""
     for log2 in (2, 3, 4, 5):
         for edge in ((0, 1) if log2 < 5 else (0,)):
             for stride in (128, 2 << log2):     # the reference's 128-byte record, and records packed back to back
                 size = 1 << log2
-                nb = (1 << 26) >> (2 * log2)
+                nb = pixels >> (2 * log2)
                 neigh = wl.fill_u8(stride * nb + 128, 400 + log2, device="cuda")
                 dst = torch.empty(nb * size * size, dtype=torch.uint8, device="cuda")
                 packed = (8 << 8) | (log2 << 1) | edge
