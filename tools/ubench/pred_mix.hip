@@ -21,9 +21,9 @@ __device__ inline void put(uint8_t *p, u32x4 v, int sb) { if (sb == 16) *reinter
 __device__ inline uint32_t fold(u32x2 v) { return v.x + v.y; }
 __device__ inline uint32_t fold(u32x4 v) { return (v.x + v.y) ^ (v.z + v.w); }
 
-struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes, DS, split; };
-constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0, 0, 0 };
-constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0, 0, 0 };
+struct Geo { int FW, FH, RS, RH, margin, before, pitch, store_bytes, DS, split; long long plane2_ref, plane2_dst; /* round 5: a lane does the SAME PU of a second plane too (Cb + Cr in one lane): byte distances, 0 = off */ };
+constexpr Geo kLuma = { 1920, 1080, 1952, 1112, 7, 3, 0, 0, 0, 0, 0, 0 };
+constexpr Geo kChroma = { 960, 540, 992, 572, 3, 1, 0, 0, 0, 0, 0, 0 };
 
 template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(256) void mix(uint8_t *dst, const uint8_t *ref, const uint8_t *ref1, int W, int H, int L, int ppw, uint32_t n, int per_row, int per_frame, int mode, int coherent, Geo g)
 {
@@ -80,12 +80,22 @@ template <int D, int LB, bool ALIGNED, int REFS> __global__ __launch_bounds__(25
 			const int nx = r + D < rows ? r + D : rows - 1;
 			ring[i] = reinterpret_cast<const UV<LB> *>(ref + ro + (size_t)nx * RS)->v;
 			acc = (acc << 1 | acc >> 31) ^ fold(v);
+			V v2 = v;
+			if (g.plane2_ref)      // the second plane's row of the same window (not ringed: issued and consumed within the row, as a first-order model)
+			{
+				v2 = reinterpret_cast<const UV<LB> *>(ref + g.plane2_ref + ro + (size_t)(r < rows ? r : rows - 1) * RS)->v;
+				if (REFS == 2) acc += fold(reinterpret_cast<const UV<LB> *>(ref1 + g.plane2_ref + ro1 + (size_t)(r < rows ? r : rows - 1) * RS)->v);
+			}
 			if (REFS == 2)
 			{
 				acc += fold(ring1[i]);
 				ring1[i] = reinterpret_cast<const UV<LB> *>(ref1 + ro1 + (size_t)nx * RS)->v;
 			}
-			if (mode == 0 && r >= first_out && r - first_out < H && stores) { V o = v; o.x = acc; o.y = acc ^ v.y; put(dst + dof + (size_t)(r - first_out) * DS, o, SB); }
+			if (mode == 0 && r >= first_out && r - first_out < H && stores)
+			{
+				V o = v; o.x = acc; o.y = acc ^ v.y; put(dst + dof + (size_t)(r - first_out) * DS, o, SB);
+				if (g.plane2_dst) { V o2 = v2; o2.x ^= acc; put(dst + g.plane2_dst + dof + (size_t)(r - first_out) * DS, o2, SB); }
+			}
 		}
 	}
 	if (mode == 1 && stores) { V o = ring[0]; o.x = acc; o.y = ~acc; put(dst + dof, o, SB); }
@@ -119,6 +129,7 @@ template <int D, int LB, bool ALIGNED, int REFS = 1> float run(int W, int H, int
 	const int refs = g.split ? 2 : REFS;
 	const double bytes = (mode == 0 ? refs * ld + st : mode == 1 ? refs * ld : st) * n;
 	if (!g_quiet)
+	if (!g_quiet && g.plane2_ref) printf("[two planes per lane] ");
 	printf("%s %2dx%-2d %3d frames  %d ref  %-11s D=%-2d  %2d-byte lanes %-9s %-11s  mean %.4f ms  min %.4f ms  ->  %.0f GB/s of this mode's bytes\n", g.margin == 7 ? "luma  " : g.pitch ? "chroma (strip deal)" : "chroma (stream deal)", W, H, frames, REFS, coherent ? "one vector" : "vector/PU", D, LB, ALIGNED ? "aligned" : "unaligned",
 			mode == 0 ? "loads+stores" : mode == 1 ? "loads only" : "stores only", sum / ms.size(), best, bytes / (sum / ms.size() * 1e-3) / 1e9);
 	return sum / ms.size();
@@ -160,6 +171,22 @@ int main(int argc, char **argv)
 				run<8, 8, false>(64, 64, 64, 0, dst, ref, 0, g);
 				run<8, 8, false>(16, 16, 64, 1, dst, ref, 0, g);
 			}
+		return 0;
+	}
+	if (argc > 1 && argv[1][0] == '2')
+	{
+		// Cb + Cr: two launches' worth of planes in one grid (what ships: blockIdx.y picks the plane; here 128 planes) against BOTH planes in one lane (64 planes,
+		// every lane loads and stores the same PU of plane b as well)
+		Geo strip = kChroma; strip.pitch = 8; strip.store_bytes = 8;
+		Geo both = strip; both.plane2_ref = (long long)64 * kChroma.RH * kChroma.RS; both.plane2_dst = (long long)64 * kChroma.FH * kChroma.FW;
+		const int csizes[][2] = { { 8, 8 }, { 16, 16 }, { 8, 16 }, { 4, 8 } };
+		for (auto &sz : csizes)
+		{
+			run<4, 16, true>(sz[0], sz[1], 128, 0, dst, ref, 0, strip);
+			run<4, 16, true>(sz[0], sz[1], 64, 0, dst, ref, 0, both);
+			run<4, 16, true, 2>(sz[0], sz[1], 128, 0, dst, ref, 0, strip);
+			run<4, 16, true, 2>(sz[0], sz[1], 64, 0, dst, ref, 0, both);
+		}
 		return 0;
 	}
 	const bool chroma = argc > 1;
