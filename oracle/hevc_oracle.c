@@ -608,8 +608,13 @@ void orc_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int packed)
  * the text has them, on the reference's neighbour layout (pred_intra.c:52-58 and f265/intra.asm:126-131: p[-1][y] =
  * neighbours[63 - y], p[x][-1] = neighbours[64 + x], p[-1][-1] = neighbours[128]) and with the reference's packed argument
  * (bit 0 = "edge" = cIdx == 0 && nTbS < 32, which is also the text's condition for the boundary smoothing of modes 10 and 26
- * with disableIntraBoundaryFilter == 0).  The constants agree with the asm's tables (intra_angle 2 5 9 13 17 21 26 at
- * intra.asm:78-84, inv_angle 256 315 390 482 630 910 1638 at :68-74).  Only mode 1 is pinned by the reference's C. */
+ * with disableIntraBoundaryFilter == 0).  Read as TEXT, the assembly agrees with this restatement wherever its arithmetic is visible: the angle tables
+ * (intra_angle 2 5 9 13 17 21 26 at intra.asm:78-84, inv_angle 256 315 390 482 630 910 1638 at :68-74); the angular blend is weights (32 - f, f)
+ * on neighbouring pairs, then vpmulhrsw by 1024 = (x + 16) >> 5 (DO_PRED, :1153-1157); planar rounds with vpmulhrsw by 2048 at 8x8 = (x + 8) >> 4 and
+ * by 4096 at 4x4 = (x + 4) >> 3 (:250, :1069), i.e. (sum + N) >> (log2 N + 1), with the weight pairs (7,1) (6,2) ... (0,8) = (N - 1 - x, x + 1)
+ * (planar_wgt_hor, :51-52); the boundary smoothing of the pure horizontal mode is left + ((top - top_left) >> 1), arithmetic shift (:1301-1311);
+ * the neighbour filter rounds with vpmulhrsw by 8192 = (x + 2) >> 2 (:863).  That is evidence by reading, not a pin: only mode 1 is pinned by the
+ * reference's C. */
 static int intra_p(const uint8_t *nb, int x, int y)      /* p[x][y] with x == -1 or y == -1 */
 {
 	if (x < 0 && y < 0) return nb[128];
