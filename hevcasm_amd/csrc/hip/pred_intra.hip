@@ -367,12 +367,13 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 // [1 2 1] filter is symmetric, so a lane filters one DWORD of that run from itself and its two neighbours (v_alignbyte by one byte each way, the corner
 // patched in at the junction, even / odd bytes on packed 16-bit adds); lane N of a block writes the corner.  `strong`: strong_intra_smoothing_enabled_flag
 // -- 32x32 blocks whose two edges are flat take the bi-linear form, decided per block.  (First form, a lane per byte: 0.04-0.07 of the HBM peak.)
+template <int N>      // (a template since round 5's second look: the lane -> (block, dword) split divides by N + 1, which as a runtime 64-bit division cost more than the filter)
 __global__ __launch_bounds__(kThreads) void intra_filter_neighbours_kernel(
-	uint8_t *__restrict__ out, ptrdiff_t out_stride, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride, int N, int strong, uint32_t n_blocks, int corner_at)
+	uint8_t *__restrict__ out, ptrdiff_t out_stride, const uint8_t *__restrict__ neighbours, ptrdiff_t neighbour_stride, int strong, uint32_t n_blocks, int corner_at)
 {
-	const uint32_t per = (uint32_t)N + 1;
-	const uint64_t t = (uint64_t)xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	const uint32_t blk = (uint32_t)(t / per), s = (uint32_t)(t % per);
+	constexpr uint32_t per = (uint32_t)N + 1;
+	const uint32_t t = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;      // n_blocks * (N + 1) < 2^32: checked by the entry point
+	const uint32_t blk = t / per, s = t % per;
 	if (blk >= n_blocks) return;
 	const uint8_t *nb = neighbours + (ptrdiff_t)blk * neighbour_stride;
 	uint8_t *o = out + (ptrdiff_t)blk * out_stride;
@@ -501,9 +502,18 @@ extern "C" int hevcasm_hip_intra_filter_neighbours_batch(
 	if (n_blocks == 0) return 0;
 	if (!filtered || !neighbours) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	const int n = 1 << log2TrafoSize;
-	if (n_blocks > 0x7fffffffull * kThreads / (size_t)(n + 1)) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large for one launch");
+	if (n_blocks > (0xffffffffull - kThreads) / (size_t)(n + 1)) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large for one launch");
 	const uint32_t grid = ceil_div(n_blocks * (size_t)(n + 1), kThreads);
-	hipLaunchKernelGGL(intra_filter_neighbours_kernel, dim3(grid), dim3(kThreads), 0, as_stream(stream), filtered, filtered_stride, neighbours, neighbour_stride, n, strong_intra_smoothing,
-			(uint32_t)n_blocks, compact ? 64 + 2 * n : 128);
+	const int corner_at = compact ? 64 + 2 * n : 128;
+#define HEVC_FILTER(NN) hipLaunchKernelGGL(intra_filter_neighbours_kernel<NN>, dim3(grid), dim3(kThreads), 0, as_stream(stream), filtered, filtered_stride, neighbours, neighbour_stride, \
+	strong_intra_smoothing, (uint32_t)n_blocks, corner_at)
+	switch (n)
+	{
+	case 4: HEVC_FILTER(4); break;
+	case 8: HEVC_FILTER(8); break;
+	case 16: HEVC_FILTER(16); break;
+	default: HEVC_FILTER(32); break;
+	}
+#undef HEVC_FILTER
 	return launch_status("intra_filter_neighbours_kernel");
 }
