@@ -462,6 +462,9 @@ def intra_modes_cases(seed=1500):
             for stride, n in ((129, 70), (160, 9)):
                 nb = wl.fill_u8(stride * n + 64, seed + 8 * log2 + c_idx + stride)
                 out.append(("intra_mixed_%s_s%d" % (tag, stride), "intra_modes", dict(neighbours=nb, neighbour_stride=stride, modes=rng.integers(0, 35, n).astype(np.uint8), packed=packed)))
+            # records that OVERLAP (16 bytes apart: a sliding window over one sample array -- legal, the records are only read)
+            out.append(("intra_overlapping_records_%s" % tag, "intra_modes", dict(neighbours=wl.fill_u8(16 * 300 + 160, seed + 77 + log2), neighbour_stride=16,
+                                                                                   modes=rng.integers(0, 35, 300).astype(np.uint8), packed=packed)))
             nb = wl.fill_u8(144 * 35 * 3 + 64, seed + 99 + log2)
             out.append(("intra_every_mode_%s" % tag, "intra_modes", dict(neighbours=nb, neighbour_stride=144, modes=np.repeat(np.arange(35, dtype=np.uint8), 3), packed=packed)))
             ext = np.where(np.arange(129 * 35) % 2, 255, 0).astype(np.uint8)
