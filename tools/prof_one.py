@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One family / one configuration, a few launches on cold buffers -- the target of rocprofv3 --pmc.
 usage: prof_one.py pred_uni TAPS W H | pred_bi TAPS W H | inverse LOG2 [LOG2_COEFFS] | deqinv LOG2 [LOG2_COEFFS] | forward LOG2 [LOG2_COEFFS] | sad W H WAYS | me
+       | frame_sse W H FRAMES | intra LOG2 [compact] | intra_dc LOG2
 Several configurations in one process: separate them with "+" (pick ones whose kernels have different names: the summary is per kernel name)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,6 +50,25 @@ def _one(kind):
               B.sad_multiref(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4, w, h)
           else:
               B.sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], B.off32(c["src_off"]), ro4.view(n, 4)[:, 0].contiguous(), w, h)
+  elif kind == "frame_sse":
+      fw, fh, frames = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+      stride = fw + 128
+      for i in range(3):
+          a, b = wl.fill_u8(stride * fh * frames + 64, 510 + i, device="cuda"), wl.fill_u8(stride * fh * frames + 64, 520 + i, device="cuda")
+          off = B.off32((np.arange(frames, dtype=np.int64) * stride * fh + 64).astype(np.uint32))
+          B.frame_sse(a, stride, b, stride, off, off, fw, fh)
+  elif kind in ("intra", "intra_dc"):
+      lg = int(sys.argv[2]); size = 1 << lg; nb = (1 << 28) >> (2 * lg)
+      compact = len(sys.argv) > 3 and sys.argv[3] == "compact"
+      packed = (8 << 8) | (lg << 1) | (1 if lg < 5 else 0)
+      for i in range(3):
+          dst = torch.empty(nb * size * size, dtype=torch.uint8, device="cuda")
+          if kind == "intra_dc":
+              B.pred_intra(dst, wl.fill_u8(128 * nb + 128, 400 + i, device="cuda"), 128, 1, packed, nb)
+          else:
+              stride = 4 * size + 1 if compact else 144
+              modes = B.u8(np.random.default_rng(i).integers(0, 35, nb).astype(np.uint8))
+              B.pred_intra_modes(dst, wl.fill_u8(stride * nb + 192, 450 + i, device="cuda"), stride, modes, packed | (B.INTRA_COMPACT if compact else 0))
   elif kind == "me":
       # config #5: the whole 3840x2160 frame through the frame-rows entry point, one launch per frame pair
       from hevcasm_amd import me_frame
