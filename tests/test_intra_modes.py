@@ -65,6 +65,24 @@ def test_structural_properties(oracle_lib):
             assert (pyoracle.pred_intra_modes_batch(flat, 129, np.array([mode], dtype=np.uint8), packed) == 77).all()
 
 
+def test_transpose_symmetry_of_the_mode_set(oracle_lib):
+    """The mode set is symmetric about the diagonal: with the two edges swapped, mode m predicts the transpose of what mode 36 - m predicts (2 <-> 34, 10 <-> 26,
+    18 <-> 18), and planar / DC predict their own transposes.  The oracle restates the text's two branches (vertical, horizontal) separately, so this checks
+    one against the other; the boundary smoothing is included (it swaps with the modes)."""
+    rng = np.random.default_rng(13)
+    for log2, edge, packed in _packings():
+        n = 1 << log2
+        nb = rng.integers(0, 256, 129, dtype=np.uint8)
+        swapped = nb.copy()
+        swapped[64:64 + 2 * n] = nb[63::-1][:2 * n]            # new top = old left
+        swapped[63::-1][:2 * n] = nb[64:64 + 2 * n]            # new left = old top
+        for mode in range(35):
+            mirror = mode if mode < 2 else 36 - mode
+            a = pyoracle.pred_intra_modes_batch(nb, 129, np.array([mode], dtype=np.uint8), packed).reshape(n, n)
+            b = pyoracle.pred_intra_modes_batch(swapped, 129, np.array([mirror], dtype=np.uint8), packed).reshape(n, n)
+            assert np.array_equal(a, b.T), (log2, edge, mode)
+
+
 def test_neighbour_filter_oracle_equals_the_second_restatement(oracle_lib):
     for name, family, c in cases.intra_filter_cases():
         got = pyoracle.intra_filter_neighbours_batch(c["neighbours"], c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=129).reshape(c["n"], 129)
