@@ -153,22 +153,29 @@ def cpu_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     ms_each = max(20, int(1000.0 * budget_s / len(combos)))
     cases = {(w, h): wl.sad_case(w, h, sample_blocks, 9000 + w * 64 + h, ways=4, frame=(wl.FRAME_W, wl.FRAME_H)) for (w, h) in sizes}
 
-    def worker(_):
+    def worker(ms):
         rates = {}
         with pyref.RefProc() as p:
             for (w, h, ways) in combos:
                 c = cases[(w, h)]
                 ro = c["ref_off"] if ways == 4 else np.ascontiguousarray(c["ref_off"].reshape(-1, 4)[:, 0])
-                secs, blocks = p.bench_sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], ro, w, h, ways, ms_each)
+                secs, blocks = p.bench_sad(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"], ro, w, h, ways, ms)
                 rates[(w, h, ways)] = blocks / secs
         return rates
 
+    mix = lambda r: len(combos) / sum(1.0 / r[c] for c in combos)     # throughput of the mix (equal block counts per (size, ways)): harmonic combination
+    # "each on 1 core and on all host cores".  The 1-core column is a RUN of its own (round 6; it used to be value / cores): ONE refdrv
+    # process with the host otherwise idle, same mix, a quarter of the per-combination time (a single core has the whole memory system to itself,
+    # so it is not the all-core rate divided by the cores)
+    ms_one = max(20, ms_each // 4)
+    one = worker(ms_one)
     with ThreadPoolExecutor(procs_n) as ex:
-        per_proc = list(ex.map(worker, range(procs_n)))
-    # throughput of the same mix (equal block counts per (size, ways)): harmonic combination per process, summed
-    total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
+        per_proc = list(ex.map(worker, [ms_each] * procs_n))
+    total = sum(mix(r) for r in per_proc)
     sad16 = sum(r[(16, 16, 1)] for r in per_proc)
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="reference", value_per_core=round(total / procs_n / 1e6, 3),
+                value_1core=round(mix(one) / 1e6, 3), sad16_1core_mblocks=round(one[(16, 16, 1)] / 1e6, 3),
+                sample_1core="ONE refdrv process alone on the host: %d (size, ways) x %d blocks x %d ms, same mix" % (len(combos), sample_blocks, ms_one),
                 sample="reference C (refdrv, gcc -O3): %d procs x %d (size, ways) x %d blocks x %d ms, same mix" % (procs_n, len(combos), sample_blocks, ms_each),
                 sad16x16_single_ref_mblocks_per_s=round(sad16 / 1e6, 3), **cores_info)
 
@@ -189,8 +196,8 @@ def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
     ms_each = max(20, int(1000.0 * budget_s / (2 * len(sizes))))
     want = set((w, h) for (w, h) in sizes)
 
-    def worker(i):
-        out = subprocess.run([exe, "%x" % mask, str(ms_each), str(sample_blocks), str(1234 + i)], capture_output=True, text=True,
+    def worker(i, ms=None):
+        out = subprocess.run([exe, "%x" % mask, str(ms or ms_each), str(sample_blocks), str(1234 + i)], capture_output=True, text=True,
                              env=dict(os.environ, HEVCASM_DISABLE_HIP="1"), timeout=600)
         if out.returncode != 0:
             raise RuntimeError("hevcasm_host_bench failed: " + out.stderr[-500:])
@@ -201,12 +208,14 @@ def host_simd_baseline(sizes, sample_blocks, budget_s, max_procs=16):
                 rates[(int(w), int(h), int(ways))] = int(blocks) / float(secs)
         return rates
 
+    one = worker(99, max(20, ms_each // 4))      # the 1-core column: one process alone on the host, a run of its own
     with ThreadPoolExecutor(procs_n) as ex:
         per_proc = list(ex.map(worker, range(procs_n)))
     combos = sorted(per_proc[0])
     total = sum(len(combos) / sum(1.0 / r[c] for c in combos) for r in per_proc)
     names = [n for n, bit in (("SSE2", capi.SSE2), ("AVX2", capi.AVX2)) if mask & bit]
     return dict(value=round(total / 1e6, 3), unit="Mblocks/s", cores=procs_n, kind="port", value_per_core=round(total / procs_n / 1e6, 3),
+                value_1core=round(len(combos) / sum(1.0 / one[c] for c in combos) / 1e6, 3),
                 sample="host tables, mask %#x (%s intrinsics): %d procs x %d combos x %d blocks x %d ms, same mix"
                        % (mask, "/".join(names) or "no SIMD", procs_n, len(combos), sample_blocks, ms_each),
                 sad16x16_single_ref_mblocks_per_s=round(sum(r.get((16, 16, 1), 0.0) for r in per_proc) / 1e6, 3), **cores_info)
@@ -357,15 +366,15 @@ def cpu_family_legs(budget_s, max_procs=16, sample_pus=8100):
 # ---------------------------------------------------------------------------------------------------------------------------
 # The ONE line on stdout (a 26 kB line did not parse).  The line the driver reads is compact() of the full
 # record: < 4 kB, strict JSON, printed last and alone on the real stdout; the full record (detail, per_family, every flattened
-# key) goes to profiles/bench_last.json and nothing else may reach stdout (main() points fd 1 at stderr while it runs).
+# key) goes to gpurun_out/bench_last.json (untracked; --full-out names another place) and nothing else may reach stdout (main() points fd 1 at stderr while it runs).
 
 HEADLINE_FAMILIES = ("sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "idct16", "idct32", "fused_idct32", "fdct32")
 PATTERN_HEADLINES = ("pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8")
 LINE_LIMIT = 4096
-ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_ms", "bytes_per_block",
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch", "avg_launch_ms", "bytes_per_block",
                  "me_valu_frac", "me_frame_ms", "frac_nominal", "hbm_frac", "per_family_error")
-CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "simd_value", "simd_cores", "gpu_multiple", "checked_ctus", "mismatches", "simd_error", "family_error")
-CONFIG_KEYS = ("workload", "blocks_per_step_per_gpu", "launches_per_step", "parallelism", "frame", "step_ms_median", "step_ms_min", "library",
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core", "simd_value", "simd_value_1core", "simd_cores", "gpu_multiple", "checked_ctus", "mismatches", "simd_error", "family_error")
+CONFIG_KEYS = ("workload", "blocks_per_step_per_gpu", "launches_per_step", "parallelism", "frame", "step_ms_median", "step_ms_min", "library", "library_sha256",
                "me_split", "ctus_per_rank", "slowest_rank_ms", "rank0_kernel_ms", "frames_per_s", "gsad_evals_per_s")
 
 
@@ -415,15 +424,18 @@ def compact(full):
                 if k in cpu:
                     c[k] = cpu[k]
         line["cpu_baseline"] = c
-    line["full_record"] = full.get("full_record", "profiles/bench_last.json")
+    line["full_record"] = full.get("full_record", "gpurun_out/bench_last.json")
     return _finite(line)
 
 
 def emit(full, out_fd=None, full_path=None):
     """Write the full record beside the profiles and the compact line -- alone, last, newline-terminated -- to the real stdout."""
     full = _finite(full)
-    full_path = full_path or os.path.join(ROOT, "profiles", "bench_last.json")
+    # the full record goes to an UNTRACKED place by default (gpurun_out/ is git-ignored and is merged back from the GPU box): a plain `python bench.py`
+    # -- the driver's included -- must not rewrite committed evidence (ADVICE round 5); the snapshots that are evidence are copied to profiles/r0N_*
+    full_path = full_path or os.path.join(ROOT, "gpurun_out", "bench_last.json")
     try:
+        os.makedirs(os.path.dirname(os.path.abspath(full_path)), exist_ok=True)
         with open(full_path, "w") as f:
             json.dump(full, f, indent=1, allow_nan=False)
             f.write("\n")
@@ -437,7 +449,15 @@ def emit(full, out_fd=None, full_path=None):
         if slim.get("cpu_baseline"):
             slim["cpu_baseline"] = {k: v for k, v in slim["cpu_baseline"].items() if k in CPU_KEYS}
         text = json.dumps(slim, allow_nan=False, separators=(",", ":"))
-    assert len(text) < LINE_LIMIT and "\n" not in text
+    if len(text) >= LINE_LIMIT or "\n" in text:      # last resort, never an exception: the contract's top-level keys and the three roofline numbers
+        slim = compact(full)
+        rf = slim.get("roofline") or {}
+        slim["roofline"] = {k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+        cb = slim.get("cpu_baseline") or {}
+        slim["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind")} if cb else None
+        slim["config"] = {"workload": str((slim.get("config") or {}).get("workload", ""))[:120]}
+        slim["truncated"] = True
+        text = json.dumps(slim, allow_nan=False, separators=(",", ":")).replace("\n", " ")
     data = (text + "\n").encode()
     if out_fd is None:
         sys.stdout.flush()
@@ -515,15 +535,15 @@ def main():
     ap.add_argument("--workload", default="sad", choices=("sad", "me5"), help="sad = BASELINE.json configs[1] (the metric's configuration); me5 = configs[4], full search sharded by CTU rows")
     ap.add_argument("--plumbing", default=None, metavar="RECORD.json", help="TEST ONLY (tests/test_bench_plumbing.py): no GPU, no measurement -- the launcher / rank / "
                     "barrier / emit path alone, emitting the given full record with n_gpus = the ranks that met")
-    ap.add_argument("--full-out", default=None, help="where the full record goes (default profiles/bench_last.json)")
+    ap.add_argument("--full-out", default=None, help="where the full record goes (default gpurun_out/bench_last.json, untracked)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_as_ranks(args, sys.argv[1:]))
     args.out_fd = quiet_stdout()
     stale = sorted(k for k in os.environ if k.startswith("HEVCASM_") and k not in ("HEVCASM_BENCH_ONE_DEVICE", "HEVCASM_DIST_BACKEND"))
     if stale:
-        print("bench.py: WARNING: %s set in the environment -- the measurement is not of the default library configuration (recorded in config.env_switches)" % ", ".join(stale), file=sys.stderr)
-        print("bench.py: (printed with a bare print(): fd 1 is stderr until the result line)")
+        # (a plain print(): fd 1 points at stderr until the result line, so this cannot land beside it -- tests/test_bench_plumbing.py leans on exactly that)
+        print("bench.py: WARNING: %s set in the environment -- the measurement is not of the default library configuration (recorded in config.env_switches)" % ", ".join(stale))
     if args.plumbing:
         return plumbing_run(args)
 
@@ -623,14 +643,9 @@ def main():
 
     # HBM bytes per launch of the dominant kernel from the PMC passes (profiles/traffic.json, made by
     # tools/make_traffic.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command)
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
-            t = json.load(f).get("%s %s" % (dom["kernel"], dom["size"]))
-        if t and t.get("blocks_per_launch") == dom_d["blocks"] // dom_d["launches"]:
-            traffic = t["hbm_bytes_per_launch"]
-    except (OSError, ValueError):
-        pass
+    # -- and only when that file was measured on THIS build of the library: it carries the sha256 of the .so the counters were taken on (round 6:
+    # a kernel change that alters the traffic must not keep reporting the old bytes); otherwise traffic = null and traffic_stale says why
+    traffic, traffic_stale = traffic_for("%s %s" % (dom["kernel"], dom["size"]), dom_d["blocks"] // dom_d["launches"])
 
     blocks_per_step = sum(c["n"] for (_, _, c) in launches)
     n_launches = len(launches)
@@ -662,7 +677,7 @@ def main():
             try:
                 simd = host_simd_baseline(sizes, args.cpu_sample_blocks, min(args.cpu_seconds, 8.0), args.cpu_procs)
                 if simd:
-                    cpu.update(simd_value=simd["value"], simd_cores=simd["cores"], simd_gpu_multiple=round(value / simd["value"], 1),
+                    cpu.update(simd_value=simd["value"], simd_cores=simd["cores"], simd_gpu_multiple=round(value / simd["value"], 1), simd_value_1core=simd["value_1core"],
                                simd_sad16_mblocks=simd["sad16x16_single_ref_mblocks_per_s"], simd_sample=simd["sample"])
             except Exception as e:   # noqa: BLE001 -- a host-side failure must not discard the GPU result
                 cpu["simd_error"] = repr(e)[:110]
@@ -696,6 +711,7 @@ def main():
                     # what a plain read stream reaches on this part (profiles/r01_hbm_stream.txt: tools/ubench/hbm_stream.hip, 4.3 GB, streaming loads)
                     "measured_read_stream_gbs": 7043.6,
                     "traffic_over_stream": round(traffic / dom_avg_s / 1e9 / 7043.6, 4) if traffic else None,
+                    "traffic_stale": traffic_stale,
                     # SURVEY 8(d)'s literal 5WH+16 counts the four overlapping candidates as disjoint: what it would read
                     "survey_5wh16_gbs": round((5 * dom_key[0] * dom_key[1] + 16) * (dom_d["blocks"] / dom_d["launches"]) / dom_avg_s / 1e9, 1) if dom_key[2] == 4 else None,
                     "note": "4-way priced at COMPULSORY bytes (src + plane share + descriptors): candidates overlap; see DESIGN.md 5",
@@ -720,10 +736,43 @@ def main():
         dist.destroy_process_group()
 
 
+def library_sha256():
+    """Content hash of the library that is loaded: the identity profiles/traffic.json is matched on."""
+    import hashlib
+    from hevcasm_amd import capi
+    h = hashlib.sha256()
+    with open(capi.LIB_PATH, "rb") as f:
+        for piece in iter(lambda: f.read(1 << 20), b""):
+            h.update(piece)
+    return h.hexdigest()
+
+
+def traffic_for(kernel_key, blocks_per_launch, path=None):
+    """(HBM bytes per launch from the PMC passes, None) when profiles/traffic.json was measured on the library now loaded and on this launch size;
+    (None, reason) otherwise -- a counter figure of another build is not this build's traffic."""
+    try:
+        with open(path or os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            doc = json.load(f)
+    except (OSError, ValueError):
+        return None, "profiles/traffic.json absent or unreadable"
+    t = doc.get(kernel_key)
+    if not t:
+        return None, "no PMC pass of %s on record" % kernel_key
+    if t.get("blocks_per_launch") != blocks_per_launch:
+        return None, "PMC pass was taken at %s blocks per launch, this run has %d" % (t.get("blocks_per_launch"), blocks_per_launch)
+    meta = doc.get("_measured_on") or {}
+    if not meta.get("library_sha256"):
+        return None, "traffic.json carries no library hash (measured before round 6)"
+    if meta["library_sha256"] != library_sha256():
+        return None, "PMC passes were taken on library %s (git %s), loaded library is %s" % (meta["library_sha256"][:12], str(meta.get("git_head"))[:12], library_sha256()[:12])
+    return t["hbm_bytes_per_launch"], None
+
+
 def library_record():
     """Which build of the library was measured, and any HEVCASM_* environment switch that was set (there should be none)."""
     from hevcasm_amd import capi
-    return dict(library=os.path.relpath(capi.LIB_PATH, ROOT), env_switches={k: v for k, v in os.environ.items() if k.startswith("HEVCASM_")})
+    return dict(library=os.path.relpath(capi.LIB_PATH, ROOT), library_sha256=library_sha256()[:16],
+                env_switches={k: v for k, v in os.environ.items() if k.startswith("HEVCASM_")})
 
 
 # byte differences per second the chip can issue through v_qsad_pk_u16_u8 (16 per lane and instruction): measured by

@@ -18,6 +18,10 @@ HIP_API = {
     "hevcasm_hip_available": (_i, []),
     "hevcasm_hip_set_device": (_i, [_i]),
     "hevcasm_hip_last_error": (C.c_char_p, []),
+    "hevcasm_hip_set_failure_handler": (_vp, [_vp]),
+    "hevcasm_hip_latched": (_i, []),
+    "hevcasm_hip_latch_reason": (C.c_char_p, []),
+    "hevcasm_hip_latch_reset": (None, []),
     "hevcasm_hip_malloc": (_i, [C.POINTER(_vp), _sz]),
     "hevcasm_hip_free": (_i, [_vp]),
     "hevcasm_hip_upload": (_i, [_vp, _vp, _sz, _vp]),
@@ -71,6 +75,7 @@ HOST_API = {
     "hevcasm_populate_quantize": (None, [_vp, _i]),
     "hevcasm_populate_quantize_reconstruct": (None, [_vp, _i]),
     "hevcasm_populate_pred_intra": (None, [_vp, _i]),
+    "hevcasm_populate_pred_intra_all_modes": (None, [_vp, _i]),
     "hevcasm_get_ssd_linear": (_vp, [_i, _i]),
     "hevcasm_test_sad": _test_fn,
     "hevcasm_test_sad_multiref": _test_fn,

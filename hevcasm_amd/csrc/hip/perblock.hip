@@ -9,8 +9,11 @@
 // batch API; one launch per block, so this is the verification path (hevcasm_test's HIP
 // column), not the throughput path.
 //
-// No fallback: a HIP failure here aborts with the error text, because the per-block signatures
-// cannot report errors and returning a CPU-computed value would hide a broken GPU path.
+// No fallback: the per-block signatures cannot report errors and returning a CPU-computed value would hide a
+// broken GPU path.  A HIP failure here latches the device "unavailable" for the process (shim.hip: later
+// hevcasm_populate_*() calls fill their slots from the other bits of the mask), hands the error text to the
+// application's failure handler and returns with its outputs unspecified -- or, without a handler, aborts
+// (include/hevcasm_hip.h: hevcasm_hip_set_failure_handler).
 
 #include "common.hpp"
 #include "../host/perblock.h"
@@ -29,38 +32,45 @@ struct Arena
 	uint8_t *dev = nullptr;
 	hipStream_t stream = nullptr;
 	size_t used = 0;
+	bool failed = false;      // this call has failed: every later step of it is skipped, its outputs are left as they are
 
-	void init()
+	bool fail(const char *what, const char *detail)
 	{
-		if (host) return;
-		check(hipHostMalloc(reinterpret_cast<void **>(&host), kArenaBytes, hipHostMallocMapped), "hipHostMalloc");
-		check(hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0), "hipHostGetDevicePointer");
-		check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate");
+		char text[256];
+		std::snprintf(text, sizeof(text), "hevcasm HIP per-block path: %s failed: %s", what, detail);
+		failed = true;
+		hevcasm_hip1_failed(text);      // latches; calls the application's handler, or aborts
+		return false;
 	}
-	static void check(hipError_t e, const char *what)
+	bool check(hipError_t e, const char *what) { return e == hipSuccess ? true : fail(what, hipGetErrorString(e)); }
+	bool check_call(int rc, const char *what) { return rc == 0 ? true : fail(what, hevcasm_hip_last_error()); }
+	bool init()
 	{
-		if (e == hipSuccess) return;
-		std::fprintf(stderr, "hevcasm HIP per-block path: %s failed: %s\n", what, hipGetErrorString(e));
-		std::abort();
+		if (host) return true;
+		uint8_t *h = nullptr, *d = nullptr;
+		hipStream_t st = nullptr;
+		if (!check(hipHostMalloc(reinterpret_cast<void **>(&h), kArenaBytes, hipHostMallocMapped), "hipHostMalloc")) return false;
+		if (!check(hipHostGetDevicePointer(reinterpret_cast<void **>(&d), h, 0), "hipHostGetDevicePointer") ||
+		    !check(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate"))
+		{
+			(void)hipHostFree(h);
+			return false;
+		}
+		host = h; dev = d; stream = st;
+		return true;
 	}
-	static void check_call(int rc, const char *what)
-	{
-		if (rc == 0) return;
-		std::fprintf(stderr, "hevcasm HIP per-block path: %s failed: %s\n", what, hevcasm_hip_last_error());
-		std::abort();
-	}
-	void reset() { init(); used = 0; }
-	// returns the offset of a 64-byte aligned region
+	bool reset() { failed = false; used = 0; return init(); }
+	// returns the offset of a 64-byte aligned region (offset 0 after a failure: still inside the arena, the call is abandoned anyway)
 	size_t take(size_t bytes)
 	{
 		const size_t at = (used + 63) & ~size_t(63);
-		if (at + bytes > kArenaBytes) { std::fprintf(stderr, "hevcasm HIP per-block path: staging arena exhausted\n"); std::abort(); }
+		if (at + bytes > kArenaBytes) { if (!failed) fail("staging", "arena exhausted"); return 0; }
 		used = at + bytes;
 		return at;
 	}
 	template <typename T> T *h(size_t off) { return reinterpret_cast<T *>(host + off); }
 	template <typename T> T *d(size_t off) { return reinterpret_cast<T *>(dev + off); }
-	void wait() { check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+	bool wait() { return check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 };
 
 thread_local Arena g_arena;
@@ -111,7 +121,7 @@ size_t stage_u32(Arena &a, uint32_t v0, uint32_t v1 = 0, uint32_t v2 = 0, uint32
 void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, ptrdiff_t stride_ref, int w, int h, int xFrac, int yFrac)
 {
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	ptrdiff_t sr;
 	const size_t r = stage_reference(a, ref, stride_ref, taps, w, h, xFrac, yFrac, &sr);
 	const ptrdiff_t sd = (w + 15) & ~15;
@@ -119,9 +129,9 @@ void pred_uni(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref, 
 	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)r);
 	const size_t fr = a.take(16);
 	a.h<uint8_t>(fr)[0] = (uint8_t)(xFrac | (yFrac << 4));
-	Arena::check_call(hevcasm_hip_pred_uni_8to8_batch(a.dev, sd, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint8_t>(fr),
-			taps, w, h, 1, a.stream), "pred_uni");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_pred_uni_8to8_batch(a.dev, sd, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint8_t>(fr),
+			taps, w, h, 1, a.stream), "pred_uni")) return;
+	if (!a.wait()) return;
 	for (int y = 0; y < h; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)w);
 }
 
@@ -129,7 +139,7 @@ void pred_bi(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, 
 		int w, int h, int xFrac0, int yFrac0, int xFrac1, int yFrac1)
 {
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	ptrdiff_t sr, sr1;
 	const size_t r0 = stage_reference(a, ref0, stride_ref, taps, w, h, xFrac0, yFrac0, &sr);
 	const size_t r1 = stage_reference(a, ref1, stride_ref, taps, w, h, xFrac1, yFrac1, &sr1);
@@ -139,9 +149,9 @@ void pred_bi(int taps, uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *ref0, 
 	const size_t fr = a.take(16);
 	a.h<uint8_t>(fr)[0] = (uint8_t)(xFrac0 | (yFrac0 << 4));
 	a.h<uint8_t>(fr)[1] = (uint8_t)(xFrac1 | (yFrac1 << 4));
-	Arena::check_call(hevcasm_hip_pred_bi_8to8_batch(a.dev, sd, a.dev, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint32_t>(offs) + 2,
-			a.d<uint8_t>(fr), a.d<uint8_t>(fr) + 1, taps, w, h, 1, a.stream), "pred_bi");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_pred_bi_8to8_batch(a.dev, sd, a.dev, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<uint32_t>(offs) + 2,
+			a.d<uint8_t>(fr), a.d<uint8_t>(fr) + 1, taps, w, h, 1, a.stream), "pred_bi")) return;
+	if (!a.wait()) return;
 	for (int y = 0; y < h; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)w);
 }
 
@@ -149,7 +159,7 @@ void inverse(int trType, int log2n, uint8_t *dst, ptrdiff_t stride_dst, const ui
 {
 	const int n = 1 << log2n;
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	ptrdiff_t sp;
 	const size_t p = stage_plane(a, pred, stride_pred, n, n, &sp);
 	const ptrdiff_t sd = (n + 15) & ~15;
@@ -157,9 +167,9 @@ void inverse(int trType, int log2n, uint8_t *dst, ptrdiff_t stride_dst, const ui
 	const size_t c = a.take(sizeof(int16_t) * n * n);
 	std::memcpy(a.h<int16_t>(c), coeffs, sizeof(int16_t) * n * n);
 	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)p);
-	Arena::check_call(hevcasm_hip_inverse_transform_add_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(c),
-			trType, log2n, 1, a.stream), "inverse_transform_add");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_inverse_transform_add_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(c),
+			trType, log2n, 1, a.stream), "inverse_transform_add")) return;
+	if (!a.wait()) return;
 	for (int y = 0; y < n; ++y) std::memcpy(dst + y * stride_dst, a.h<uint8_t>(d) + y * sd, (size_t)n);
 }
 
@@ -167,13 +177,13 @@ void forward(int trType, int log2n, int16_t *coeffs, const int16_t *src, ptrdiff
 {
 	const int n = 1 << log2n;
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	const size_t s = a.take(sizeof(int16_t) * n * n);
 	for (int y = 0; y < n; ++y) std::memcpy(a.h<int16_t>(s) + y * n, src + y * src_stride, sizeof(int16_t) * n);
 	const size_t c = a.take(sizeof(int16_t) * n * n);
 	const size_t offs = stage_u32(a, 0);
-	Arena::check_call(hevcasm_hip_transform_batch(a.d<int16_t>(c), a.d<int16_t>(s), n, a.d<uint32_t>(offs), trType, log2n, 1, a.stream), "transform");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_transform_batch(a.d<int16_t>(c), a.d<int16_t>(s), n, a.d<uint32_t>(offs), trType, log2n, 1, a.stream), "transform")) return;
+	if (!a.wait()) return;
 	std::memcpy(coeffs, a.h<int16_t>(c), sizeof(int16_t) * n * n);
 }
 
@@ -185,14 +195,14 @@ int hevcasm_hip1_sad(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *re
 {
 	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return 0;
 	ptrdiff_t ss, sr;
 	const size_t s = stage_plane(a, src, stride_src, w, h, &ss);
 	const size_t r = stage_plane(a, ref, stride_ref, w, h, &sr);
 	const size_t offs = stage_u32(a, (uint32_t)s, (uint32_t)r);
 	const size_t out = a.take(16);
-	Arena::check_call(hevcasm_hip_sad_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), rect, 1, a.stream), "sad");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_sad_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), rect, 1, a.stream), "sad")) return 0;
+	if (!a.wait()) return 0;
 	return *a.h<int>(out);
 }
 
@@ -200,7 +210,7 @@ void hevcasm_hip1_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const
 {
 	const int w = (int)(rect >> 8), h = (int)(rect & 0xff);
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	ptrdiff_t ss, sr = 0;
 	const size_t s = stage_plane(a, src, stride_src, w, h, &ss);
 	size_t r[4];
@@ -208,22 +218,22 @@ void hevcasm_hip1_sad_multiref_4(const uint8_t *src, ptrdiff_t stride_src, const
 	const size_t so = stage_u32(a, (uint32_t)s);
 	const size_t ro = stage_u32(a, (uint32_t)r[0], (uint32_t)r[1], (uint32_t)r[2], (uint32_t)r[3]);
 	const size_t out = a.take(16);
-	Arena::check_call(hevcasm_hip_sad_multiref_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(so), a.d<uint32_t>(ro), a.d<int>(out), rect, 1, a.stream), "sad_multiref");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_sad_multiref_batch(a.dev, ss, a.dev, sr, a.d<uint32_t>(so), a.d<uint32_t>(ro), a.d<int>(out), rect, 1, a.stream), "sad_multiref")) return;
+	if (!a.wait()) return;
 	std::memcpy(sad, a.h<int>(out), 4 * sizeof(int));
 }
 
 int hevcasm_hip1_ssd(const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB, int w, int h)
 {
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return 0;
 	ptrdiff_t sa, sb;
 	const size_t pa = stage_plane(a, srcA, stride_srcA, w, h, &sa);
 	const size_t pb = stage_plane(a, srcB, stride_srcB, w, h, &sb);
 	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
 	const size_t out = a.take(16);
-	Arena::check_call(hevcasm_hip_ssd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), w, h, 1, a.stream), "ssd");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_ssd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), w, h, 1, a.stream), "ssd")) return 0;
+	if (!a.wait()) return 0;
 	return *a.h<int>(out);
 }
 
@@ -231,14 +241,14 @@ static int satd1(int log2n, const uint8_t *srcA, ptrdiff_t stride_srcA, const ui
 {
 	const int n = 1 << log2n;
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return 0;
 	ptrdiff_t sa, sb;
 	const size_t pa = stage_plane(a, srcA, stride_srcA, n, n, &sa);
 	const size_t pb = stage_plane(a, srcB, stride_srcB, n, n, &sb);
 	const size_t offs = stage_u32(a, (uint32_t)pa, (uint32_t)pb);
 	const size_t out = a.take(16);
-	Arena::check_call(hevcasm_hip_hadamard_satd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), log2n, 1, a.stream), "hadamard_satd");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_hadamard_satd_batch(a.dev, sa, a.dev, sb, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), log2n, 1, a.stream), "hadamard_satd")) return 0;
+	if (!a.wait()) return 0;
 	return *a.h<int>(out);
 }
 int hevcasm_hip1_satd_2(const uint8_t *a, ptrdiff_t sa, const uint8_t *b, ptrdiff_t sb) { return satd1(1, a, sa, b, sb); }
@@ -268,11 +278,11 @@ void hevcasm_hip1_quantize_inverse(int16_t *dst, const int16_t *src, int scale, 
 	for (int done = 0; done < n;)
 	{
 		const int m = n - done < 32768 ? n - done : 32768;
-		a.reset();
+		if (!a.reset()) return;
 		const size_t s = a.take(sizeof(int16_t) * m), d = a.take(sizeof(int16_t) * m);
 		std::memcpy(a.h<int16_t>(s), src + done, sizeof(int16_t) * m);
-		Arena::check_call(hevcasm_hip_quantize_inverse(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, (size_t)m, a.stream), "quantize_inverse");
-		a.wait();
+		if (a.failed || !a.check_call(hevcasm_hip_quantize_inverse(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, (size_t)m, a.stream), "quantize_inverse")) return;
+		if (!a.wait()) return;
 		std::memcpy(dst + done, a.h<int16_t>(d), sizeof(int16_t) * m);
 		done += m;
 	}
@@ -287,12 +297,12 @@ int hevcasm_hip1_quantize(int16_t *dst, const int16_t *src, int scale, int shift
 	{
 		const int left = n - done;
 		const int npb = left >= 1024 ? 1024 : left >= 256 ? 256 : left >= 64 ? 64 : 16;
-		if (left < 16) { std::fprintf(stderr, "hevcasm HIP per-block path: quantize n must be a multiple of 16\n"); std::abort(); }
-		a.reset();
+		if (!a.reset()) return 0;
+		if (left < 16) { a.fail("quantize", "n must be a multiple of 16"); return 0; }
 		const size_t s = a.take(sizeof(int16_t) * npb), d = a.take(sizeof(int16_t) * npb), c = a.take(16);
 		std::memcpy(a.h<int16_t>(s), src + done, sizeof(int16_t) * npb);
-		Arena::check_call(hevcasm_hip_quantize_batch(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, offset, npb, 1, a.d<int>(c), a.stream), "quantize");
-		a.wait();
+		if (a.failed || !a.check_call(hevcasm_hip_quantize_batch(a.d<int16_t>(d), a.d<int16_t>(s), scale, shift, offset, npb, 1, a.d<int>(c), a.stream), "quantize")) return 0;
+		if (!a.wait()) return 0;
 		std::memcpy(dst + done, a.h<int16_t>(d), sizeof(int16_t) * npb);
 		cbf |= *a.h<int>(c);
 		done += npb;
@@ -303,7 +313,7 @@ int hevcasm_hip1_quantize(int16_t *dst, const int16_t *src, int scale, int shift
 void hevcasm_hip1_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const int16_t *res, int n)
 {
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	ptrdiff_t sp;
 	const size_t p = stage_plane(a, pred, stride_pred, n, n, &sp);
 	const ptrdiff_t sd = (n + 15) & ~15;
@@ -311,8 +321,8 @@ void hevcasm_hip1_quantize_reconstruct(uint8_t *rec, ptrdiff_t stride_rec, const
 	const size_t r = a.take(sizeof(int16_t) * n * n);
 	std::memcpy(a.h<int16_t>(r), res, sizeof(int16_t) * n * n);
 	const size_t offs = stage_u32(a, (uint32_t)d, (uint32_t)p);
-	Arena::check_call(hevcasm_hip_quantize_reconstruct_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(r), n, 1, a.stream), "quantize_reconstruct");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_quantize_reconstruct_batch(a.dev, sd, a.dev, sp, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int16_t>(r), n, 1, a.stream), "quantize_reconstruct")) return;
+	if (!a.wait()) return;
 	for (int y = 0; y < n; ++y) std::memcpy(rec + y * stride_rec, a.h<uint8_t>(d) + y * sd, (size_t)n);
 }
 
@@ -320,12 +330,12 @@ void hevcasm_hip1_pred_intra_dc(uint8_t *dst, const uint8_t *neighbours, int int
 {
 	const int n = 1 << ((packed >> 1) & 0x7f);
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	// stage bytes [64 - n, 64 + n) of the caller's array at the same indices of a 128-byte record
 	const size_t nb = a.take(128), d = a.take((size_t)n * n);
 	std::memcpy(a.h<uint8_t>(nb) + 64 - n, neighbours + 64 - n, 2 * (size_t)n);
-	Arena::check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 128, intraPredMode, packed, 1, a.stream), "pred_intra");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 128, intraPredMode, packed, 1, a.stream), "pred_intra")) return;
+	if (!a.wait()) return;
 	std::memcpy(dst, a.h<uint8_t>(d), (size_t)n * n);
 }
 
@@ -334,12 +344,12 @@ void hevcasm_hip1_pred_intra_any(uint8_t *dst, const uint8_t *neighbours, int in
 {
 	const int n = 1 << ((packed >> 1) & 0x7f);
 	Arena &a = g_arena;
-	a.reset();
+	if (!a.reset()) return;
 	const size_t nb = a.take(144), d = a.take((size_t)n * n);
 	std::memcpy(a.h<uint8_t>(nb) + 64 - 2 * n, neighbours + 64 - 2 * n, 4 * (size_t)n);
 	a.h<uint8_t>(nb)[128] = neighbours[128];
-	Arena::check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 144, intraPredMode, packed, 1, a.stream), "pred_intra");
-	a.wait();
+	if (a.failed || !a.check_call(hevcasm_hip_pred_intra_batch(a.d<uint8_t>(d), a.d<uint8_t>(nb), 144, intraPredMode, packed, 1, a.stream), "pred_intra")) return;
+	if (!a.wait()) return;
 	std::memcpy(dst, a.h<uint8_t>(d), (size_t)n * n);
 }
 
@@ -352,14 +362,14 @@ int hevcasm_hip1_ssd_linear(const uint8_t *src0, const uint8_t *src1, int size)
 	for (int done = 0; done < size || (size == 0 && done == 0); done += piece_max)
 	{
 		const int piece = size - done < piece_max ? size - done : piece_max;
-		a.reset();
+		if (!a.reset()) return 0;
 		const size_t p0 = a.take((size_t)piece + 16), p1 = a.take((size_t)piece + 16);
 		std::memcpy(a.h<uint8_t>(p0), src0 + done, (size_t)piece);
 		std::memcpy(a.h<uint8_t>(p1), src1 + done, (size_t)piece);
 		const size_t offs = stage_u32(a, (uint32_t)p0, (uint32_t)p1);
 		const size_t out = a.take(16);
-		Arena::check_call(hevcasm_hip_ssd_linear_batch(a.dev, a.dev, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), piece, 1, a.stream), "ssd_linear");
-		a.wait();
+		if (a.failed || !a.check_call(hevcasm_hip_ssd_linear_batch(a.dev, a.dev, a.d<uint32_t>(offs), a.d<uint32_t>(offs) + 1, a.d<int>(out), piece, 1, a.stream), "ssd_linear")) return 0;
+		if (!a.wait()) return 0;
 		total += (unsigned)*a.h<int>(out);
 		if (size == 0) break;
 	}

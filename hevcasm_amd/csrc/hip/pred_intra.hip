@@ -196,7 +196,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 		for (int q = 0; q < LOADS; ++q)
 			if (j + q * LPB < N) rec[q] = reinterpret_cast<const U1 *>(nb + 64 - 2 * N + 4 * (j + q * LPB))->v;
 		if (j == 0) rec_corner = nb[corner_at];
-		if (modes) rec_mode = (int)modes[b];
+		if (modes) rec_mode = min((int)modes[b], 34);      // a byte above 34 is not a mode: clamped, so that the tables below are never indexed past their ends (the header calls the result unspecified)
 	};
 	request(first_group);
 
@@ -502,6 +502,11 @@ extern "C" int hevcasm_hip_intra_filter_neighbours_batch(
 	if (n_blocks == 0) return 0;
 	if (!filtered || !neighbours) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	const int n = 1 << log2TrafoSize;
+	{
+		// a record is written at bytes [64 - 2N, 64 + 2N) and the corner byte: records closer than that overwrite each other
+		const ptrdiff_t need = compact ? 4 * n + 1 : 129, have = filtered_stride < 0 ? -filtered_stride : filtered_stride;
+		if (have < need) return set_error(HEVCASM_HIP_EINVAL, "filtered_stride too small: at least 129, or 4N + 1 for compact records");
+	}
 	if (n_blocks > (0xffffffffull - kThreads) / (size_t)(n + 1)) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large for one launch");
 	const uint32_t grid = ceil_div(n_blocks * (size_t)(n + 1), kThreads);
 	const int corner_at = compact ? 64 + 2 * n : 128;

@@ -7,7 +7,9 @@
 
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 namespace hevc {
 
@@ -119,6 +121,73 @@ extern "C" int hevcasm_hip_set_device(int device)
 }
 
 extern "C" const char *hevcasm_hip_last_error(void) { return g_error; }
+
+// ---- the per-block path's latch (round 6) ---------------------------------------------------------------------------------
+// The reference's per-block function types have no error return (sad.h:50 ...), so a HIP failure behind a HEVCASM_HIP table slot cannot be
+// reported by the call that hit it.  What the library can do is make sure it happens ONCE: the first failure latches the device "unavailable"
+// for the whole process, with its text, and from then on hevcasm_populate_*() treats the HEVCASM_HIP bit as not set -- the reference's own
+// convention for "not available" is a slot filled from the other bits of the mask, or NULL (ssd.c:65-69).  Never a CPU result from a HIP slot.
+static std::atomic<int> g_latched{0};
+static std::mutex g_latch_mutex;
+static char g_latch_text[256] = "";
+static hevcasm_hip_failure_handler *g_failure_handler = nullptr;
+
+extern "C" int hevcasm_hip_latched(void) { return g_latched.load(std::memory_order_acquire); }
+
+extern "C" const char *hevcasm_hip_latch_reason(void) { return g_latch_text; }
+
+extern "C" void hevcasm_hip1_latch(const char *reason)
+{
+	std::lock_guard<std::mutex> lock(g_latch_mutex);
+	if (g_latched.load(std::memory_order_relaxed)) return;      // the first failure's text is the one kept
+	std::snprintf(g_latch_text, sizeof(g_latch_text), "%s", reason ? reason : "");
+	g_latched.store(1, std::memory_order_release);
+}
+
+extern "C" void hevcasm_hip_latch_reset(void)
+{
+	std::lock_guard<std::mutex> lock(g_latch_mutex);
+	g_latch_text[0] = 0;
+	g_latched.store(0, std::memory_order_release);
+}
+
+extern "C" hevcasm_hip_failure_handler *hevcasm_hip_set_failure_handler(hevcasm_hip_failure_handler *handler)
+{
+	std::lock_guard<std::mutex> lock(g_latch_mutex);
+	hevcasm_hip_failure_handler *old = g_failure_handler;
+	g_failure_handler = handler;
+	return old;
+}
+
+// A per-block entry failed: latch, then hand the text to the application's handler; without one, print it and abort (the call's result would be
+// undefined and no caller of a function type without an error return checks for that).
+extern "C" void hevcasm_hip1_failed(const char *text)
+{
+	hevcasm_hip1_latch(text);
+	hevcasm_hip_failure_handler *h;
+	{
+		std::lock_guard<std::mutex> lock(g_latch_mutex);
+		h = g_failure_handler;
+	}
+	if (h) { h(text); return; }
+	std::fprintf(stderr, "%s\n", text);
+	std::abort();
+}
+
+// What hevcasm_populate_*() does with the mask it is given: the HEVCASM_HIP bit (1 << 9) survives only while a gfx950 device is usable and no
+// per-block call has failed; asking for it without a device latches too, so that the reason can be read back.
+extern "C" int hevcasm_hip1_effective_mask(int mask)
+{
+	const int hip_bit = 1 << 9;
+	if (!(mask & hip_bit)) return mask;
+	if (hevcasm_hip_latched()) return mask & ~hip_bit;
+	if (!hevcasm_hip_available())
+	{
+		hevcasm_hip1_latch("HEVCASM_HIP asked for, but no usable gfx950 (MI355X) device is current: table slots filled from the other bits of the mask");
+		return mask & ~hip_bit;
+	}
+	return mask;
+}
 
 extern "C" int hevcasm_hip_malloc(void **dev_ptr, size_t bytes)
 {

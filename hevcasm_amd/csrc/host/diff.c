@@ -10,6 +10,7 @@
 
 hevcasm_ssd_linear *hevcasm_get_ssd_linear(int size, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	(void)size;
 	hevcasm_ssd_linear *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_ssd_linear;

@@ -11,6 +11,7 @@
 
 void hevcasm_populate_hadamard_satd(hevcasm_table_hadamard_satd *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	static hevcasm_hadamard_satd *const c_path[3] = { hevcasm_c_satd_2, hevcasm_c_satd_4, hevcasm_c_satd_8 };
 	static hevcasm_hadamard_satd *const hip_path[3] = { hevcasm_hip1_satd_2, hevcasm_hip1_satd_4, hevcasm_hip1_satd_8 };
 	hevcasm_hadamard_satd *const *src = 0;

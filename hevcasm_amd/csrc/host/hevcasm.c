@@ -68,13 +68,13 @@ static int env_set(const char *name)
 hevcasm_instruction_set hevcasm_instruction_set_support(void)
 {
 	int mask = HEVCASM_C_REF | HEVCASM_C_OPT | x86_mask();
-	if (env_set("HEVCASM_ENABLE_HIP") && !env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available()) mask |= HEVCASM_HIP;
+	if (env_set("HEVCASM_ENABLE_HIP") && !env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available() && !hevcasm_hip_latched()) mask |= HEVCASM_HIP;
 	return (hevcasm_instruction_set)mask;
 }
 
 hevcasm_instruction_set hevcasm_instruction_set_hip(void)
 {
-	return (hevcasm_instruction_set)((!env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available()) ? HEVCASM_HIP : 0);
+	return (hevcasm_instruction_set)((!env_set("HEVCASM_DISABLE_HIP") && hevcasm_hip_available() && !hevcasm_hip_latched()) ? HEVCASM_HIP : 0);
 }
 
 void hevcasm_print_instruction_set_support(FILE *f, hevcasm_instruction_set mask)

@@ -6,8 +6,10 @@
  * memory, launches the SAME batched kernel as the hevcasm_hip_*_batch API with n_blocks = 1 and
  * waits for it (hip/perblock.hip).  They exist so that hevcasm_test() gains a HIP column that
  * checks the GPU kernels block by block against the C path; they are correct but pay a launch
- * per block -- throughput callers use hevcasm_hip.h.  On any HIP failure they abort(): the
- * reference's function types have no error channel and a silent CPU result would be a lie.
+ * per block -- throughput callers use hevcasm_hip.h.  The reference's function types have no error
+ * channel and a silent CPU result would be a lie: a HIP failure latches the device "unavailable" for the
+ * process, goes to the application's failure handler (or aborts), and later hevcasm_populate_*() calls
+ * drop the HEVCASM_HIP bit (hevcasm_hip1_effective_mask; include/hevcasm_hip.h, hevcasm_hip_latched).
  */
 #ifndef HEVCASM_PERBLOCK_H
 #define HEVCASM_PERBLOCK_H
@@ -38,6 +40,11 @@ hevcasm_quantize hevcasm_hip1_quantize;
 hevcasm_quantize_reconstruct hevcasm_hip1_quantize_reconstruct;
 hevcasm_pred_intra hevcasm_hip1_pred_intra_dc, hevcasm_hip1_pred_intra_any;
 hevcasm_ssd_linear hevcasm_hip1_ssd_linear;
+
+/* shim.hip: the mask a populate function works with -- HEVCASM_HIP removed when the device is unusable or latched */
+int hevcasm_hip1_effective_mask(int mask);
+void hevcasm_hip1_latch(const char *reason);
+void hevcasm_hip1_failed(const char *text);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,7 @@
 
 void hevcasm_populate_pred_uni_8to8(hevcasm_table_pred_uni_8to8 *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	for (int taps = 4; taps <= 8; taps += 4)
 	{
 		hevcasm_pred_uni_8to8 *f = 0;
@@ -39,6 +40,7 @@ void hevcasm_populate_pred_uni_8to8(hevcasm_table_pred_uni_8to8 *table, hevcasm_
 
 void hevcasm_populate_pred_bi_8to8(hevcasm_table_pred_bi_8to8 *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	for (int taps = 4; taps <= 8; taps += 4)
 	{
 		hevcasm_pred_bi_8to8 *f = 0;

@@ -1,9 +1,10 @@
 /*
  * pred_intra.c -- selector and self-test for intra prediction (reference pred_intra.c:113-139
- * and :143-227).  INTRA_DC is wired as in the reference.  The reference leaves the other 34 modes' slots NULL (it has them only as f265
- * assembly for 4x4 / 8x8, never wired); here they are filled too -- planar and angular from H.265 8.4.4.2.4 / .6 (cpath.c; the GPU kernel
- * behind the HIP bit) -- a superset of the reference's table, and the one part of this library with no reference C to pin it.
- * The self-test prints the reference's rows only (DC).
+ * and :143-227).  hevcasm_populate_pred_intra() fills the table as the reference does: INTRA_DC only, every other slot NULL (the reference has
+ * the other 34 modes only as f265 assembly for 4x4 / 8x8, never wired) -- so a non-NULL slot still means "pinned to the reference's C".
+ * The other modes -- planar and angular from H.265 8.4.4.2.4 / .6 (cpath.c; the GPU kernel behind the HIP bit), the one part of this library
+ * with no reference C to pin it -- are an explicit opt-in: hevcasm_populate_pred_intra_all_modes() (round 6; until
+ * round 5 the plain populate filled them, which made the table differ from the reference's).  The self-test prints the reference's rows only (DC).
  */
 #include "pred_intra.h"
 #include "cpath.h"
@@ -13,15 +14,16 @@
 #include <stdlib.h>
 #include <string.h>
 
-void hevcasm_populate_pred_intra(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask)
+static void populate(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask, int all_modes)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	memset(table, 0, sizeof(*table));
 	hevcasm_pred_intra *dc = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) dc = hevcasm_c_pred_intra_dc;
 	if (mask & HEVCASM_HIP) dc = hevcasm_hip1_pred_intra_dc;
 	hevcasm_pred_intra *planar = 0, *angular = 0;
-	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) { planar = hevcasm_c_pred_intra_planar; angular = hevcasm_c_pred_intra_angular; }
-	if (mask & HEVCASM_HIP) planar = angular = hevcasm_hip1_pred_intra_any;
+	if (all_modes && (mask & (HEVCASM_C_REF | HEVCASM_C_OPT))) { planar = hevcasm_c_pred_intra_planar; angular = hevcasm_c_pred_intra_angular; }
+	if (all_modes && (mask & HEVCASM_HIP)) planar = angular = hevcasm_hip1_pred_intra_any;
 	for (int log2 = 2; log2 <= 5; ++log2)
 		for (int cIdx = 0; cIdx < 2; ++cIdx)
 		{
@@ -31,6 +33,12 @@ void hevcasm_populate_pred_intra(hevcasm_table_pred_intra *table, hevcasm_instru
 			for (int mode = 2; mode < 35; ++mode) *hevcasm_get_pred_intra(table, mode, packed) = angular;
 		}
 }
+
+/* the reference's table: INTRA_DC, nothing else (pred_intra.c:113-139) */
+void hevcasm_populate_pred_intra(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask) { populate(table, mask, 0); }
+
+/* opt-in: all 35 modes; the 34 beyond DC follow the text of H.265, not any reference C (unpinned) */
+void hevcasm_populate_pred_intra_all_modes(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask) { populate(table, mask, 1); }
 
 typedef struct
 {

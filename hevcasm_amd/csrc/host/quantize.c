@@ -17,6 +17,7 @@
 
 void hevcasm_populate_quantize_inverse(hevcasm_table_quantize_inverse *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	hevcasm_quantize_inverse *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize_inverse;
 #if defined(__x86_64__) || defined(__i386__)
@@ -28,6 +29,7 @@ void hevcasm_populate_quantize_inverse(hevcasm_table_quantize_inverse *table, he
 
 void hevcasm_populate_quantize(hevcasm_table_quantize *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	hevcasm_quantize *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize;
 #if defined(__x86_64__) || defined(__i386__)
@@ -39,6 +41,7 @@ void hevcasm_populate_quantize(hevcasm_table_quantize *table, hevcasm_instructio
 
 void hevcasm_populate_quantize_reconstruct(hevcasm_table_quantize_reconstruct *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	hevcasm_quantize_reconstruct *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_quantize_reconstruct;
 #if defined(__x86_64__) || defined(__i386__)

@@ -16,6 +16,7 @@
 
 void hevcasm_populate_inverse_transform_add(hevcasm_table_inverse_transform_add *table, hevcasm_instruction_set mask, int encoder)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	static hevcasm_inverse_transform_add *const c_path[5] = { hevcasm_c_idst_4, hevcasm_c_idct_4, hevcasm_c_idct_8, hevcasm_c_idct_16, hevcasm_c_idct_32 };
 	static hevcasm_inverse_transform_add *const hip_path[5] = { hevcasm_hip1_idst_4, hevcasm_hip1_idct_4, hevcasm_hip1_idct_8, hevcasm_hip1_idct_16, hevcasm_hip1_idct_32 };
 	hevcasm_inverse_transform_add *f[5] = { 0, 0, 0, 0, 0 };
@@ -34,6 +35,7 @@ void hevcasm_populate_inverse_transform_add(hevcasm_table_inverse_transform_add 
 
 void hevcasm_populate_transform(hevcasm_table_transform *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	static hevcasm_transform *const c_path[5] = { hevcasm_c_dst_4, hevcasm_c_dct_4, hevcasm_c_dct_8, hevcasm_c_dct_16, hevcasm_c_dct_32 };
 	static hevcasm_transform *const hip_path[5] = { hevcasm_hip1_dst_4, hevcasm_hip1_dct_4, hevcasm_hip1_dct_8, hevcasm_hip1_dct_16, hevcasm_hip1_dct_32 };
 	hevcasm_transform *f[5] = { 0, 0, 0, 0, 0 };

@@ -39,6 +39,7 @@ static hevcasm_sad *select_sad(int w, int h, hevcasm_instruction_set mask)
 
 void hevcasm_populate_sad(hevcasm_table_sad *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	for (int h = 4; h <= 64; h += 4)
 		for (int w = 4; w <= 64; w += 4)
 			*hevcasm_get_sad(table, w, h) = select_sad(w, h, mask);
@@ -58,6 +59,7 @@ static hevcasm_sad_multiref *select_sad_multiref(int w, int h, hevcasm_instructi
 
 void hevcasm_populate_sad_multiref(hevcasm_table_sad_multiref *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	for (int h = 4; h <= 64; h += 4)
 		for (int w = 4; w <= 64; w += 4)
 			*hevcasm_get_sad_multiref(table, 4, w, h) = select_sad_multiref(w, h, mask);

@@ -11,6 +11,7 @@
 
 void hevcasm_populate_ssd(hevcasm_table_ssd *table, hevcasm_instruction_set mask)
 {
+	mask = (hevcasm_instruction_set)hevcasm_hip1_effective_mask(mask);   /* HEVCASM_HIP only while the device is usable and unlatched */
 	hevcasm_ssd *f = 0;
 	if (mask & (HEVCASM_C_REF | HEVCASM_C_OPT)) f = hevcasm_c_ssd;
 	hevcasm_ssd *wide = f;

@@ -58,6 +58,21 @@ int hevcasm_hip_available(void);
 int hevcasm_hip_set_device(int device);
 const char *hevcasm_hip_last_error(void);
 
+/* The per-block table entries behind the HEVCASM_HIP mask bit (hevcasm.h) have the reference's function types, which have no error return
+ * (sad.h:50, pred_inter.h:56 ...).  A HIP failure inside one of them -- or asking hevcasm_populate_*() for the bit when no gfx950 device is usable --
+ * LATCHES the device "unavailable" for the process: the text of the first failure is kept (hevcasm_hip_latch_reason(), also printed to stderr when
+ * no handler is installed) and every later hevcasm_populate_*() / hevcasm_get_ssd_linear() treats HEVCASM_HIP as not set, i.e. fills its slots from
+ * the other bits of the mask or with NULL, the reference's convention for "not available" (ssd.c:65-69).  The CALL THAT FAILED cannot deliver a
+ * result: it calls the handler installed here with the text and, when the handler returns, returns with its outputs unspecified (0 for the
+ * functions that return a value); without a handler it aborts the process, as the reference's asserts do.  There is never a CPU result from a HIP slot.
+ * hevcasm_hip_latch_reset() clears the latch (e.g. after the application has reset the device); the batch entry points below are not affected by the
+ * latch -- they report every failure through their return value. */
+typedef void hevcasm_hip_failure_handler(const char *text);
+hevcasm_hip_failure_handler *hevcasm_hip_set_failure_handler(hevcasm_hip_failure_handler *handler);   /* returns the previous handler (NULL = abort) */
+int hevcasm_hip_latched(void);
+const char *hevcasm_hip_latch_reason(void);
+void hevcasm_hip_latch_reset(void);
+
 /* Thin device-memory helpers so that a C codec needs no HIP headers. */
 int hevcasm_hip_malloc(void **dev_ptr, size_t bytes);
 int hevcasm_hip_free(void *dev_ptr);
@@ -155,7 +170,9 @@ int hevcasm_hip_pred_intra_batch(
 #define HEVCASM_HIP_INTRA_COMPACT 0x10000
 
 /* The same with one mode PER BLOCK (modes[i] in 0..34): what a frame's intra blocks of one size look like to an encoder's mode decision or a
- * decoder's reconstruction wavefront.  Parity as above: mode 1 pinned, the others unpinned. */
+ * decoder's reconstruction wavefront.  Parity as above: mode 1 pinned, the others unpinned.  `modes` is device memory, so the entry point cannot
+ * refuse a bad byte as hevcasm_hip_pred_intra_batch refuses a bad intraPredMode: a byte above 34 is treated as mode 34 (the block's pixels are
+ * then those of mode 34 -- defined, never an out-of-range access). */
 int hevcasm_hip_pred_intra_modes_batch(
 	uint8_t *dst, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
 	const uint8_t *modes, int packed, size_t n_blocks, void *stream);
@@ -164,7 +181,8 @@ int hevcasm_hip_pred_intra_modes_batch(
  * output record are written; filtered_stride >= 129): [1 2 1] / 4 along both edges through the corner, end samples kept; with
  * strong_intra_smoothing != 0, 32x32 blocks whose two edges are flat (|corner + end - 2 middle| < 8 both ways) take the bi-linear form instead.
  * Whether a block uses the filtered or the plain record is the caller's decision (the text's filterFlag: mode and size; f265 passes a filter_flag
- * the same way, f265/intra.asm:748-768).  UNPINNED like the modes above.  `filtered` must not overlap `neighbours`. */
+ * the same way, f265/intra.asm:748-768).  UNPINNED like the modes above.  `filtered` must not overlap `neighbours`; |filtered_stride| below 129
+ * (4N + 1 with compact records) is refused with HEVCASM_HIP_EINVAL: the output records would overwrite each other. */
 int hevcasm_hip_intra_filter_neighbours_batch(
 	uint8_t *filtered, ptrdiff_t filtered_stride, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
 	int log2TrafoSize, int strong_intra_smoothing, size_t n_blocks, void *stream);

@@ -50,6 +50,12 @@ static inline hevcasm_pred_intra **hevcasm_get_pred_intra(hevcasm_table_pred_int
 
 void HEVCASM_API hevcasm_populate_pred_intra(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask);
 
+/* Not in the reference: the same table with ALL 35 modes filled -- planar (0) and angular (2..34) after H.265 8.4.4.2.4 / 8.4.4.2.6 on the same
+ * neighbour layout (the corner sample p[-1][-1] at neighbours[128], f265/intra.asm:126-131), bit 0 of `packed` also switching the boundary
+ * smoothing of modes 10 / 26.  The reference has these modes only as un-wired f265 assembly, so nothing pins them to it: an explicit opt-in, so
+ * that a non-NULL slot of hevcasm_populate_pred_intra()'s table keeps meaning "the reference's function". */
+void HEVCASM_API hevcasm_populate_pred_intra_all_modes(hevcasm_table_pred_intra *table, hevcasm_instruction_set mask);
+
 void HEVCASM_API hevcasm_test_pred_intra(int *error_count, hevcasm_instruction_set mask);
 
 #ifdef __cplusplus

@@ -225,6 +225,35 @@ def test_an_oversized_record_still_gives_a_line(tmp_path):
     full["roofline"]["note"] = "x" * 5000
     text = bench.emit(full, os.open(os.devnull, os.O_WRONLY), str(tmp_path / "f.json"))
     assert len(text) < 4096 and "extra" not in text
+    # round 6: even a record whose CONTRACT keys are oversized gives a line (hard truncation, not an assert that kills rank 0 without one)
+    full["config"]["workload"] = "w" * 3000
+    full["roofline"]["kernel"] = "k" * 3000
+    for k in bench.CPU_KEYS:
+        full["cpu_baseline"][k] = "c" * 500
+    text = bench.emit(full, os.open(os.devnull, os.O_WRONLY), str(tmp_path / "f.json"))
+    line = json.loads(text)
+    assert len(text) < 4096 and line["metric"] and "frac" in line["roofline"] and "value" in line["cpu_baseline"]
+
+
+def test_traffic_is_reported_only_for_the_library_it_was_measured_on(tmp_path, monkeypatch):
+    """roofline.traffic comes from PMC passes stored in profiles/traffic.json; round 6: the file carries the sha256 of the library the counters were
+    taken on and bench.py hands the figure out only when the loaded library is that one -- else null and the reason."""
+    monkeypatch.setattr(bench, "library_sha256", lambda: "a" * 64)
+    rows = {"sad_multiref_4 64x64": {"blocks_per_launch": 524288, "hbm_bytes_per_launch": 4507486016}}
+    def write(meta):
+        p = tmp_path / "t.json"
+        p.write_text(json.dumps(dict(rows, **({"_measured_on": meta} if meta is not None else {}))))
+        return str(p)
+    assert bench.traffic_for("sad_multiref_4 64x64", 524288, write({"library_sha256": "a" * 64, "git_head": "x"})) == (4507486016, None)
+    t, why = bench.traffic_for("sad_multiref_4 64x64", 524288, write({"library_sha256": "b" * 64, "git_head": "deadbeef"}))
+    assert t is None and "bbbbbbbbbbbb" in why and "deadbeef" in why
+    t, why = bench.traffic_for("sad_multiref_4 64x64", 524288, write(None))
+    assert t is None and "no library hash" in why
+    t, why = bench.traffic_for("sad_multiref_4 64x64", 1048576, write({"library_sha256": "a" * 64}))
+    assert t is None and "blocks per launch" in why
+    t, why = bench.traffic_for("sad 8x8", 1, write({"library_sha256": "a" * 64}))
+    assert t is None and "no PMC pass" in why
+    assert bench.traffic_for("sad 8x8", 1, str(tmp_path / "missing.json"))[0] is None
 
 
 def _run_bench(argv, tmp_path, env=None):
@@ -245,7 +274,7 @@ def test_bench_main_prints_one_line_last_and_alone(tmp_path):
     assert len(lines) == 1 and out.stdout.endswith("\n")
     line = _check_line(lines[0])
     assert line["steps"] == 3 and line["warmup"] == 1 and "not a measurement" in line["data"]
-    assert "WARNING" in out.stderr and "bare print()" in out.stderr          # a print() to sys.stdout lands on stderr
+    assert "WARNING" in out.stderr          # the warning is a print() to sys.stdout: it lands on stderr, not beside the line
 
 
 def test_bench_gpus_2_without_a_launcher_starts_its_own_ranks(tmp_path):

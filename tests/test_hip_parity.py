@@ -650,6 +650,18 @@ def test_error_codes_not_fallbacks():
     assert L.hevcasm_hip_pred_intra_batch(p, p, 144, 26, (8 << 8) | (5 << 1) | 1, 1, None) == capi.EINVAL
     assert L.hevcasm_hip_pred_intra_modes_batch(p, p, 144, None, (8 << 8) | (3 << 1), 1, None) == capi.EINVAL
     assert L.hevcasm_hip_intra_filter_neighbours_batch(p, 144, p + 2048, 144, 6, 0, 1, None) == capi.EINVAL
+    # round 6 (ADVICE): output records closer together than they are long are refused; a mode byte above 34 is mode 34, not an index past the tables
+    assert L.hevcasm_hip_intra_filter_neighbours_batch(p, 100, p + 2048, 144, 3, 0, 2, None) == capi.EINVAL
+    assert L.hevcasm_hip_intra_filter_neighbours_batch(p, 33, p + 2048, 33, 3 | 0x10000, 0, 2, None) == 0       # compact 8x8 records: 4N + 1 = 33
+    nb = torch.randint(0, 256, (144,), dtype=torch.uint8, device="cuda")
+    for log2 in (2, 3, 4, 5):
+        outs = []
+        for mode in (34, 200):
+            m = torch.tensor([mode], dtype=torch.uint8, device="cuda")
+            d = torch.zeros(1 << (2 * log2), dtype=torch.uint8, device="cuda")
+            assert L.hevcasm_hip_pred_intra_modes_batch(d.data_ptr(), nb.data_ptr(), 144, m.data_ptr(), (8 << 8) | (log2 << 1), 1, None) == 0
+            outs.append(d.cpu())
+        assert torch.equal(outs[0], outs[1]), log2
     # empty batches are legal no-ops
     assert L.hevcasm_hip_sad_batch(p, 64, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), capi.rect(16, 16), 0, None) == 0
     assert L.hevcasm_hip_pred_bi_8to8_batch_2planes(p, p, 64, p, p, p, p, 64, o.data_ptr(), o.data_ptr(), o.data_ptr(), p, p, 8, 16, 16, 0, None) == 0

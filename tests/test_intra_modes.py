@@ -101,11 +101,21 @@ def test_neighbour_filter_oracle_equals_the_second_restatement(oracle_lib):
             assert (plain[:10] != got[:10]).any() and np.array_equal(plain[10:], got[10:])
 
 
-def test_host_table_fills_every_mode_and_its_c_entries_equal_the_oracle(oracle_lib):
-    """hevcasm_populate_pred_intra under the C bits: p[log2 - 2][mode] for all 35 modes (a superset of the reference's table, which wires DC only), each equal to the oracle."""
+def test_plain_populate_keeps_the_reference_table_dc_only():
+    """hevcasm_populate_pred_intra fills exactly what the reference fills (pred_intra.c:113-139): mode 1 of every size, plain and edge-filtered; every other
+    slot NULL -- a non-NULL slot means "the reference's function" (round 6)."""
     L = capi.lib()
     table = (C.c_void_p * (4 * 35 + 3))()
     L.hevcasm_populate_pred_intra(table, capi.C_REF)
+    filled = {i for i in range(4 * 35 + 3) if table[i]}
+    assert filled == {k * 35 + 1 for k in range(4)} | {4 * 35 + k for k in range(3)}
+
+
+def test_host_table_fills_every_mode_and_its_c_entries_equal_the_oracle(oracle_lib):
+    """hevcasm_populate_pred_intra_all_modes (the opt-in) under the C bits: p[log2 - 2][mode] for all 35 modes, each equal to the oracle."""
+    L = capi.lib()
+    table = (C.c_void_p * (4 * 35 + 3))()
+    L.hevcasm_populate_pred_intra_all_modes(table, capi.C_REF)
     assert all(table[i] for i in range(4 * 35 + 3))
     fn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
     rng = np.random.default_rng(3)
@@ -132,7 +142,7 @@ def test_hip_per_block_table_entry_for_an_angular_mode():
     """The HIP bit's table entry for a non-DC mode (per-block call through the staging arena) equals the oracle."""
     L = capi.lib()
     table = (C.c_void_p * (4 * 35 + 3))()
-    L.hevcasm_populate_pred_intra(table, capi.HIP)
+    L.hevcasm_populate_pred_intra_all_modes(table, capi.HIP)
     fn = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
     nb = np.ascontiguousarray(wl.fill_u8(144, 5))
     for log2, mode in ((2, 0), (3, 7), (4, 26), (5, 19)):

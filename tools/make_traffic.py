@@ -4,12 +4,22 @@
 HBM bytes per launch = 2 * FETCH_SIZE KiB + WRITE_SIZE KiB, the gfx950 correction of
 MI355X_MICROARCH.md (FETCH_SIZE counts 128-byte requests as 64 bytes on wide streaming reads),
 calibrated here on the aligned SAD case: 2 * 269.3 MB = 539 MB against 545 MB algorithmic.
-usage: make_traffic.py <gpurun_out/prof_rNN> <blocks_per_launch for 64x64> <blocks_per_launch for 16x16>
+usage: make_traffic.py <gpurun_out/prof_rNN> [<output.json>, default profiles/traffic.json]
 """
-import csv, glob, json, os, re, sys
+import csv, glob, hashlib, json, os, re, subprocess, sys
 
 prof = sys.argv[1]
-out = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the identity of what was measured: bench.py reports roofline.traffic only when the library it has loaded hashes to this (round 6).
+# Run this script where the PMC passes ran (the same tree, the same .so), e.g. as the last step of tools/profile_round.sh.
+LIB = os.environ.get("HEVCASM_HIP_LIB") or os.path.join(ROOT, "hevcasm_amd", "lib", "libhevcasm_hip.so")
+try:
+    head = subprocess.run(["git", "-C", ROOT, "rev-parse", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+except OSError:
+    head = None
+if not head and os.path.exists(os.path.join(ROOT, "gpurun_out", "git_head.txt")):      # the GPU box has no .git: the caller leaves the hash there
+    head = open(os.path.join(ROOT, "gpurun_out", "git_head.txt")).read().strip()
+out = {"_measured_on": dict(library_sha256=hashlib.sha256(open(LIB, "rb").read()).hexdigest(), git_head=head, profile_dir=os.path.basename(os.path.normpath(prof)))}
 for size in ("64x64", "16x16", "64x48", "48x64"):
     vals = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -31,5 +41,6 @@ for size in ("64x64", "16x16", "64x48", "48x64"):
             hbm_bytes_per_launch=int(2 * fetch + write), fetch_size_kib=round(sum(f) / len(f), 1), write_size_kib=round(sum(w) / len(w), 1),
             blocks_per_launch=blocks, algorithmic_bytes_per_launch=row["bytes_per_block"] * blocks,
             formula="2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), separate --pmc passes", dispatches=len(f))
-json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json"), "w"), indent=1, sort_keys=True)
+dest = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "traffic.json")
+json.dump(out, open(dest, "w"), indent=1, sort_keys=True)
 print(json.dumps(out, indent=1))

@@ -15,4 +15,6 @@ for s in 64x64 16x16 64x48 48x64; do
     rocprofv3 --pmc $g --output-format csv -d $d -- python3 bench.py --steps 2 --warmup 0 --cpu-seconds 0 --no-families --sizes $s --full-out /dev/null > $d.json 2> $d.err || echo "FAILED pmc $s $g"
   done
 done
+# traffic.json with the identity (sha256) of the library these passes ran on; copy it to profiles/traffic.json after the call
+python3 tools/make_traffic.py $O $O/traffic.json > $O/traffic.log 2>&1 || echo "FAILED make_traffic"
 echo profile_round done
