@@ -266,3 +266,50 @@ def frame_sse(a, stride_a, b, stride_b, a_off, b_off, width, height, out=None):
     check(lib().hevcasm_hip_frame_sse_batch(a.data_ptr(), stride_a, b.data_ptr(), stride_b, a_off.data_ptr(), b_off.data_ptr(), out.data_ptr(),
                                             width, height, n, _stream()), "frame_sse_batch")
     return out
+
+
+class IntraFrames:
+    """hevcasm_hip_intra_reconstruct_frames on torch tensors: n_frames planes of frame_w x frame_h (row stride `stride`, frames `stride * frame_h` apart),
+    a TU list per frame (hevcasm_amd.workload.intra_tu_map: tus + ctu_first), quantiser parameters int32 [4][5].  Device buffers and the workspace are made
+    once; run() only enqueues (memset + two launches), so it can be captured into a HIP graph.  encode: src -> levels, cbf, recon; decode: levels -> recon."""
+
+    def __init__(self, frame_w, frame_h, ctu, tus_per_frame, firsts_per_frame, qp, c_idx=0, strong=0, stride=None, device="cuda", want_pred=False):
+        self.w, self.h, self.ctu, self.c_idx, self.strong = frame_w, frame_h, ctu, c_idx, strong
+        self.stride = stride or frame_w
+        self.n_frames = len(tus_per_frame)
+        self.cols, self.rows = -(-frame_w // ctu), -(-frame_h // ctu)
+        n_ctus = self.cols * self.rows
+        base, firsts = 0, []
+        for t, f in zip(tus_per_frame, firsts_per_frame):
+            assert len(f) == n_ctus + 1 and int(f[-1]) == len(t)
+            firsts.append(np.asarray(f[:-1], dtype=np.int64) + base)
+            base += len(t)
+        firsts.append(np.array([base], dtype=np.int64))
+        self.n_tus = base
+        tus = np.concatenate([np.ascontiguousarray(t).view(np.uint8).reshape(-1, 8) for t in tus_per_frame])
+        self.tus = torch.from_numpy(tus).to(device)
+        self.ctu_first = torch.from_numpy(np.concatenate(firsts).astype(np.int32)).to(device)
+        self.qp = np.ascontiguousarray(qp, dtype=np.int32).reshape(4, 5)
+        plane = self.stride * frame_h
+        self.recon = torch.zeros(self.n_frames * plane, dtype=torch.uint8, device=device)
+        self.pred = torch.zeros(self.n_frames * plane, dtype=torch.uint8, device=device) if want_pred else None
+        self.levels = torch.zeros(self.n_frames * n_ctus * ctu * ctu, dtype=torch.int16, device=device)
+        self.cbf = torch.zeros(self.n_tus, dtype=torch.int32, device=device)
+        nbytes = lib().hevcasm_hip_intra_frames_workspace_bytes(frame_w, frame_h, ctu, self.n_frames)
+        if nbytes == 0:
+            raise capi.HevcasmError("intra frames: " + capi.last_error())
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+
+    def run(self, src=None, stride_src=None):
+        """src: uint8 tensor holding the n_frames source planes (encoder) or None (decoder: self.levels is the input)."""
+        plane = self.stride * self.h
+        s_stride = stride_src or self.stride
+        check(lib().hevcasm_hip_intra_reconstruct_frames(
+            self.recon.data_ptr(), self.stride, plane,
+            src.data_ptr() if src is not None else None, s_stride, s_stride * self.h,
+            self.levels.data_ptr(), self.cbf.data_ptr() if src is not None else None, self.pred.data_ptr() if self.pred is not None else None,
+            self.tus.data_ptr(), self.ctu_first.data_ptr(), self.qp.ctypes.data,
+            self.w, self.h, self.ctu, self.c_idx, 1 if self.strong else 0, self.n_frames, self.workspace.data_ptr(), _stream()), "intra_reconstruct_frames")
+
+    def status(self):
+        check(lib().hevcasm_hip_intra_frames_status(self.workspace.data_ptr(), _stream()), "intra_frames_status")

@@ -50,6 +50,9 @@ HIP_API = {
     "hevcasm_hip_pred_intra_batch": (_i, [_vp, _vp, _pd, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_intra_modes_batch": (_i, [_vp, _vp, _pd, _vp, _i, _sz, _vp]),
     "hevcasm_hip_intra_filter_neighbours_batch": (_i, [_vp, _pd, _vp, _pd, _i, _i, _sz, _vp]),
+    "hevcasm_hip_intra_frames_workspace_bytes": (_sz, [_i, _i, _i, _sz]),
+    "hevcasm_hip_intra_reconstruct_frames": (_i, [_vp, _pd, _sz, _vp, _pd, _sz, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _sz, _vp, _vp]),
+    "hevcasm_hip_intra_frames_status": (_i, [_vp, _vp]),
     "hevcasm_hip_ssd_linear_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_frame_sse_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
 }

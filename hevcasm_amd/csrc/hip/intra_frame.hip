@@ -1,0 +1,658 @@
+// intra_frame.hip -- whole intra planes reconstructed on the device in wavefront order (second half; include/hevcasm_hip.h,
+// hevcasm_hip_intra_reconstruct_frames).
+//
+// Per transform unit, in decoding order: neighbour record from the reconstructed samples (reference layout pred_intra.c:59-65, corner as
+// f265/intra.asm:126-131) -> substitution of unavailable samples (H.265 8.4.4.2.2) -> smoothing decision + filter (8.4.4.2.3) -> prediction
+// (intra_predict.hpp: INTRA_DC = pred_intra.c:68-103) -> residual -> forward transform (residual_decode.c:592-892) -> quantise (quantize.c:160-186)
+// -> dequantise (quantize.c:53-62) -> inverse transform + add (residual_decode.c:69-413).  The arithmetic of every step the reference has is
+// restated exactly (32-bit sums, the reference's rounding, truncating forward stores, int16 clips of the inverse passes, the int16 narrowing of
+// hevcasm_clip); pinned for all-DC frames against the composition of the reference's own functions (oracle/refdrv.c OP_INTRA_FRAME).
+//
+// Structure (MI355X): ONE persistent launch of single-wavefront workgroups.  A workgroup draws a ticket (atomic counter), looks the ticket up in a table
+// that lists every (frame, CTU) in wavefront order -- key cx + 2 cy, the two-CTU lag of HEVC's wavefront parallel processing, frames interleaved inside
+// a step -- waits until the up to four neighbouring CTUs it reads from have published their edges, then runs the CTU's TUs in list order with the CTU's
+// reconstruction, its source pixels and all scratch in LDS (the intra-CTU dependencies are then just program order of one wave: LDS operations of a wave
+// complete in order, so no barrier is needed, only compiler fences).  Tickets are a topological order of the dependency graph, so a workgroup only waits
+// for CTUs that are held by workgroups already running: no co-residency requirement, no deadlock, any grid size.
+// Hand-off between workgroups (guide: cdna_hip_programming.md section 6, Guideline 16, form R2 "the data IS the flag"): a finished CTU stores its bottom
+// row and right column as 8-byte granules { tag = 1, four samples } with agent-scope atomic stores (write-through, no fence); a consumer's wave re-reads its
+// (at most 41) granules with agent-scope atomic loads until every tag is set.  A granule is written once, by one store, and is never read before its CTU's
+// ticket was drawn; the granule area is zeroed by a memset node in front of every launch.  Every spin is bounded (wall clock) and checks an abort word.
+// The neighbour records never exist in HBM: the 4.9x record traffic of the flat intra batch (profiles/r05_new_kernel_traffic.txt) is gone by construction.
+
+#include "common.hpp"
+#include "dct_matrix.hpp"
+#include "intra_predict.hpp"
+
+#include <algorithm>
+
+namespace hevc {
+
+constexpr int kLanes = 64;            // one wavefront per workgroup
+constexpr int kTileStride = 112;      // LDS reconstruction tile: row y at (y + 1), sample x at column (x + 16): x = -1 .. 95, rows -1 .. 63
+constexpr int kTileRows = 65;
+constexpr int kMaxCtuTus = 256;       // a 64x64 CTU of 4x4 TUs
+constexpr uint32_t kStatusBadTu = 1u, kStatusTimeout = 2u;
+constexpr unsigned long long kSpinLimitTicks = 200000000ull;      // s_memrealtime runs at 100 MHz: 2 s
+
+struct IntraFramesArgs
+{
+	uint8_t *recon; const uint8_t *src; uint8_t *pred_out;
+	ptrdiff_t stride_recon, stride_src;
+	size_t pitch_recon, pitch_src;
+	int16_t *levels; int *cbf;
+	const hevcasm_hip_intra_tu *tus; const uint32_t *ctu_first;
+	hevcasm_hip_intra_qp qp[4];
+	int frame_w, frame_h, ctu, cols, rows, cIdx, strong;
+	uint32_t n_frames, n_items;
+	uint32_t *head;                    // [0] ticket counter, [1] status, [2] abort
+	uint32_t *order;                   // ticket -> frame << 20 | cy << 10 | cx
+	unsigned long long *granules;      // per (frame, CTU): ctu / 4 bottom-row granules, then ctu / 4 right-column granules
+};
+
+__constant__ Matrix32 kDctDevice = make_matrix32();
+// DST-VII of 4x4 luma blocks as a matrix: residual_decode.c:592-610 (forward: row k of this times the input), :69-88 (inverse: its transpose)
+__constant__ signed char kDst4[4][4] = { { 29, 55, 74, 84 }, { 74, 74, 0, -74 }, { 84, -29, -74, 55 }, { 55, -84, 74, -29 } };
+
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ uint32_t pack16(int lo, int hi) { return ((uint32_t)lo & 0xffffu) | ((uint32_t)hi << 16); }
+
+// ---- coefficient tables in LDS: pairs (W[b][2k], W[b][2k + 1]) for v_dot2_i32_i16, one row per output index b -----------------------------------
+// forward: W[b][i] = M_N[b][i] = M32[b * 32 / N][i]: rows of ONE table serve every size.  inverse: W[b][i] = M_N[i][b]: a table per size.
+struct Tables
+{
+	uint32_t wf[32 * 17];       // row pitch 17 dwords: rows on different banks
+	uint32_t wi32[32 * 17];
+	uint32_t wi16[16 * 9];
+	uint32_t wi8[8 * 5];
+	uint32_t wi4[4 * 3];
+	uint32_t df[4 * 3], di[4 * 3];
+};
+
+__device__ __forceinline__ void build_tables(Tables &t, int lane)
+{
+	for (int e = lane; e < 32 * 16; e += kLanes)
+	{
+		const int b = e / 16, k = e % 16;
+		t.wf[b * 17 + k] = pack16(kDctDevice.m[b][2 * k], kDctDevice.m[b][2 * k + 1]);
+		t.wi32[b * 17 + k] = pack16(kDctDevice.m[2 * k][b], kDctDevice.m[2 * k + 1][b]);
+	}
+	for (int e = lane; e < 16 * 8; e += kLanes)
+	{
+		const int b = e / 8, k = e % 8;
+		t.wi16[b * 9 + k] = pack16(kDctDevice.m[2 * (2 * k)][b], kDctDevice.m[2 * (2 * k + 1)][b]);
+	}
+	if (lane < 8 * 4)
+	{
+		const int b = lane / 4, k = lane % 4;
+		t.wi8[b * 5 + k] = pack16(kDctDevice.m[4 * (2 * k)][b], kDctDevice.m[4 * (2 * k + 1)][b]);
+	}
+	if (lane < 4 * 2)
+	{
+		const int b = lane / 2, k = lane % 2;
+		t.wi4[b * 3 + k] = pack16(kDctDevice.m[8 * (2 * k)][b], kDctDevice.m[8 * (2 * k + 1)][b]);
+		t.df[b * 3 + k] = pack16(kDst4[b][2 * k], kDst4[b][2 * k + 1]);
+		t.di[b * 3 + k] = pack16(kDst4[2 * k][b], kDst4[2 * k + 1][b]);
+	}
+}
+
+template <int N> __device__ __forceinline__ void load_weights(const Tables &t, bool inverse, bool dst, int b, uint32_t (&w)[N / 2])
+{
+	const uint32_t *row;
+	if (N == 4 && dst) row = (inverse ? t.di : t.df) + b * 3;
+	else if (!inverse) row = t.wf + b * (32 / N) * 17;
+	else row = N == 32 ? t.wi32 + b * 17 : N == 16 ? t.wi16 + b * 9 : N == 8 ? t.wi8 + b * 5 : t.wi4 + b * 3;
+#pragma unroll
+	for (int k = 0; k < N / 2; ++k) w[k] = row[k];
+}
+
+// One 1-D pass over an N x N int16 tile in LDS (row pitch N + 4): out(a, b) = (sum_i W[b][i] * in[a][i] + round) >> shift for every row a, stored at
+// [b][a] (TRANSPOSE_OUT) or [a][b].  Forward passes store the low 16 bits (residual_decode.c:631-634), inverse passes clip to int16 (:113-116).
+// Lane = (b, a group): the lane's weight row stays in registers; the rows it reads are the same address in every lane of the group (LDS broadcast).
+template <int N, bool INVERSE, bool TRANSPOSE_OUT>
+__device__ __forceinline__ void transform_pass(const int16_t *in, int16_t *out, const uint32_t (&w)[N / 2], int shift, int lane)
+{
+	constexpr int P = N + 4;
+	constexpr int G = (kLanes / N) < N ? (kLanes / N) : N;      // row groups: 4x4: 4 (16 lanes busy), 8x8: 8, 16x16: 4, 32x32: 2
+	constexpr int PER = N / G;                                  // rows per lane: 1, 1, 4, 16
+	const int b = lane % N, g = lane / N;
+	if (g < G)
+	{
+		const int add = 1 << (shift - 1);
+#pragma unroll
+		for (int i = 0; i < PER; ++i)
+		{
+			const int a = g * PER + i;
+			const uint32_t *row = reinterpret_cast<const uint32_t *>(in + a * P);
+			int acc = add;
+#pragma unroll
+			for (int k = 0; k < N / 2; ++k)
+				acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, row[k]), __builtin_bit_cast(i16x2, w[k]), acc, false);
+			acc >>= shift;
+			if (INVERSE) acc = clip3(-32768, 32767, acc);
+			if (TRANSPOSE_OUT) out[b * P + a] = (int16_t)acc;
+			else out[a * P + b] = (int16_t)acc;
+		}
+	}
+}
+
+// ---- one CTU's state in LDS ------------------------------------------------------------------------------------------------------------------------
+
+struct CtuLds
+{
+	Tables tables;
+	uint8_t tile[kTileRows * kTileStride];     // reconstruction of this CTU + the row above (x = -1 .. 95) + the column to the left
+	uint8_t srcs[64 * 64];                     // source pixels of the CTU (encoder)
+	uint8_t done[16 * 16];                     // per 4x4 cell: reconstructed
+	hevcasm_hip_intra_tu tus[kMaxCtuTus];
+	uint8_t raw[144], flt[144];                // compact neighbour record, and its smoothed form: [2N - 1 - y] left, [2N + x] top, [4N] corner
+	uint8_t ref[128];                          // predictor scratch (intra_predict.hpp)
+	uint8_t ptile[32 * 32];
+	int16_t buf_a[32 * 36], buf_b[32 * 36];    // residual / coefficients, row pitch N + 4
+};
+
+struct CtuView
+{
+	int x0, y0, ctu, frame_w, frame_h;         // CTU origin in the plane
+};
+
+// H.265 6.4.1 / 8.4.4.2.2 for a sample at CTU-local (px, py) as the TU now being predicted sees it
+__device__ __forceinline__ bool sample_available(const CtuLds &L, const CtuView &v, int px, int py)
+{
+	const int gx = v.x0 + px, gy = v.y0 + py;
+	if (gx < 0 || gy < 0 || gx >= v.frame_w || gy >= v.frame_h) return false;
+	if (py < 0) return true;                      // the CTU row above: the three CTUs a TU can reach into precede in the wavefront
+	if (px < 0) return py < v.ctu;                // the CTU to the left; the one below it comes later
+	if (px >= v.ctu || py >= v.ctu) return false; // to the right / below: later
+	return L.done[(py >> 2) * 16 + (px >> 2)] != 0;
+}
+
+__device__ __forceinline__ uint8_t &tile_at(CtuLds &L, int px, int py) { return L.tile[(py + 1) * kTileStride + px + 16]; }
+
+// The 4N + 1 neighbouring samples of the N x N TU at CTU-local (tx, ty) into L.raw, unavailable ones substituted.  A lane takes one UNIT in the text's search
+// order -- lanes 0 .. N/2 - 1: four samples of the left column, bottom-up; lane N/2: the corner; lanes N/2 + 1 .. N: four samples of the top row --
+// because availability is a property of 4x4 cells.  Substitution: an unavailable unit repeats the LAST sample of the nearest available unit before it in
+// search order; the units before the first available one repeat its FIRST sample; nothing available: 128.
+template <int N> __device__ __forceinline__ void build_neighbours(CtuLds &L, const CtuView &v, int tx, int ty, int lane)
+{
+	constexpr int U = N / 2;
+	bool have = false;
+	uint32_t val = 0;
+	if (lane <= 2 * U)
+	{
+		int px, py;
+		if (lane < U) { px = tx - 1; py = ty + 2 * N - 4 - 4 * lane; }
+		else if (lane == U) { px = tx - 1; py = ty - 1; }
+		else { px = tx + 4 * (lane - U - 1); py = ty - 1; }
+		have = sample_available(L, v, px, py);
+		if (have)
+		{
+			if (lane < U)            // memory order of the record = search order: the lowest byte is the bottom-most row
+				val = (uint32_t)tile_at(L, px, py + 3) | ((uint32_t)tile_at(L, px, py + 2) << 8) | ((uint32_t)tile_at(L, px, py + 1) << 16) | ((uint32_t)tile_at(L, px, py) << 24);
+			else if (lane == U) val = tile_at(L, px, py);
+			else val = *reinterpret_cast<const uint32_t *>(&tile_at(L, px, py));
+		}
+	}
+	const unsigned long long mask = __ballot(have);
+	const unsigned long long below = mask & ((1ull << lane) - 1ull);
+	const int from = mask == 0 ? 0 : below ? 63 - __clzll((long long)below) : __ffsll((long long)mask) - 1;
+	const uint32_t theirs = (uint32_t)__shfl((int)val, from, kLanes);
+	if (!have)
+	{
+		uint32_t s = 128;
+		if (mask != 0) s = from == U ? (theirs & 0xffu) : below ? (theirs >> 24) : (theirs & 0xffu);
+		val = s * 0x01010101u;
+	}
+	uint32_t *raw32 = reinterpret_cast<uint32_t *>(L.raw);
+	if (lane < U) raw32[lane] = val;
+	else if (lane == U) L.raw[4 * N] = (uint8_t)val;
+	else if (lane <= 2 * U) raw32[lane - 1] = val;
+}
+
+// H.265 8.4.4.2.3 on the record: [1 2 1] / 4 along the run left column (bottom-up) - corner - top row, end samples kept; 32x32 with strong smoothing and two
+// flat edges: the bi-linear form
+template <int N> __device__ __forceinline__ void smooth_neighbours(CtuLds &L, int strong, int lane)
+{
+	const int corner = L.raw[4 * N];
+	bool bi = false;
+	if (N == 32 && strong)
+	{
+		const int a = corner + L.raw[2 * N + 63] - 2 * L.raw[2 * N + 31], b = corner + L.raw[2 * N - 1 - 63] - 2 * L.raw[2 * N - 1 - 31];
+		bi = abs(a) < 8 && abs(b) < 8;
+	}
+	auto s_at = [&](int i) { return (int)(i < 2 * N ? L.raw[i] : i == 2 * N ? L.raw[4 * N] : L.raw[i - 1]); };      // the run: 4N + 1 samples
+	for (int i = lane; i <= 4 * N; i += kLanes)
+	{
+		int r;
+		if (i == 0 || i == 4 * N) r = s_at(i);
+		else if (bi)
+		{
+			if (i == 2 * N) r = corner;
+			else
+			{
+				const int k = i < 2 * N ? 2 * N - 1 - i : i - 2 * N - 1;      // distance from the corner along the edge: 0 .. 62 here
+				const int end = i < 2 * N ? L.raw[0] : L.raw[4 * N - 1];
+				r = ((63 - k) * corner + (k + 1) * end + 32) >> 6;
+			}
+		}
+		else r = (s_at(i - 1) + 2 * s_at(i) + s_at(i + 1) + 2) >> 2;
+		if (i < 2 * N) L.flt[i] = (uint8_t)r;
+		else if (i == 2 * N) L.flt[4 * N] = (uint8_t)r;
+		else L.flt[i - 1] = (uint8_t)r;
+	}
+}
+
+__device__ __forceinline__ int wave_or(int v)
+{
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, kLanes);
+	return v;
+}
+
+// One TU, start to finish.  (tx, ty): position inside the CTU.
+template <int N>
+__device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, const IntraFramesArgs &A, uint8_t *recon, uint8_t *pred_out, bool encode,
+	int tx, int ty, int mode, int16_t *lev, int *cbf_out, int lane)
+{
+	constexpr int PX = IntraGeom<N>::PX, LPB = IntraGeom<N>::LPB, LOG2 = IntraGeom<N>::LOG2, P = N + 4;
+	const bool luma = A.cIdx == 0;
+
+	build_neighbours<N>(L, v, tx, ty, lane);
+	wave_sync();
+	// filterFlag (8.4.4.2.3): luma, not DC, not 4x4, and far enough from the horizontal / vertical modes for the size
+	bool filter = false;
+	if (N > 4 && luma && mode != 1)
+	{
+		const int dist = min(abs(mode - 26), abs(mode - 10));
+		filter = dist > (N == 8 ? 7 : N == 16 ? 1 : 0);
+	}
+	if (filter)
+	{
+		smooth_neighbours<N>(L, A.strong, lane);
+		wave_sync();
+	}
+	Chunk<PX> pred;
+	intra_predict_block<N, kLanes>(filter ? L.flt : L.raw, L.ref, L.ptile, lane, mode, luma && N < 32, wave_sync, pred);
+
+	// the lane's PX bytes sit at row r, columns c0 .. of the block (row-major position PX * lane)
+	const bool owner = lane < LPB;
+	const int r = owner ? PX * lane / N : 0, c0 = owner ? PX * lane % N : 0;
+	const bool dst = luma && N == 4;                 // trType 1: DST-VII for 4x4 luma blocks of intra CUs
+	const hevcasm_hip_intra_qp q = A.qp[LOG2 - 2];
+	uint32_t w[N / 2];
+
+	if (encode)
+	{
+		if (owner)
+		{
+			const uint32_t *s32 = reinterpret_cast<const uint32_t *>(L.srcs + (ty + r) * 64 + tx + c0);
+			uint32_t *a32 = reinterpret_cast<uint32_t *>(L.buf_a + r * P + c0);
+#pragma unroll
+			for (int k = 0; k < PX / 4; ++k)
+			{
+				const uint32_t s = s32[k], p = pred.d[k];
+				a32[2 * k] = pack16((int)(s & 0xff) - (int)(p & 0xff), (int)((s >> 8) & 0xff) - (int)((p >> 8) & 0xff));
+				a32[2 * k + 1] = pack16((int)((s >> 16) & 0xff) - (int)((p >> 16) & 0xff), (int)(s >> 24) - (int)(p >> 24));
+			}
+		}
+		load_weights<N>(L.tables, false, dst, lane % N, w);
+		wave_sync();
+		// residual_decode.c:855-892: rows of the residual with shift log2 - 1, then the transposed intermediate with shift log2 + 6
+		transform_pass<N, false, true>(L.buf_a, L.buf_b, w, LOG2 - 1, lane);
+		wave_sync();
+		transform_pass<N, false, true>(L.buf_b, L.buf_a, w, LOG2 + 6, lane);
+		wave_sync();
+	}
+
+	// quantise (encoder) or fetch (decoder) the lane's PX levels; dequantise; the dequantised coefficients go to buf_b TRANSPOSED (the inverse passes sum along rows)
+	int cbf = 0;
+	if (owner)
+	{
+		int level[PX];
+		if (encode)
+		{
+			const uint32_t *a32 = reinterpret_cast<const uint32_t *>(L.buf_a + r * P + c0);
+			const int offset = q.q_offset << (q.q_shift - 16);
+#pragma unroll
+			for (int b = 0; b < PX; ++b)
+			{
+				const uint32_t pair = a32[b / 2];
+				int x = (b & 1) ? (int)pair >> 16 : (int)(int16_t)(pair & 0xffff);
+				const bool neg = x < 0;
+				x = neg ? -x : x;                                           // abs(-32768) = 32768 in int (quantize.c:176)
+				x = (x * q.q_scale + offset) >> q.q_shift;
+				x = neg ? -x : x;
+				x = clip3(-32768, 32767, x);
+				cbf |= x;
+				level[b] = x;
+			}
+			Chunk<PX> lo, hi;      // 2 PX bytes of levels: two stores of PX bytes
+#pragma unroll
+			for (int k = 0; k < PX / 4; ++k)
+			{
+				lo.d[k] = pack16(level[2 * k], level[2 * k + 1]);
+				hi.d[k] = pack16(level[PX / 2 + 2 * k], level[PX / 2 + 2 * k + 1]);
+			}
+			lo.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
+			hi.store(reinterpret_cast<uint8_t *>(lev + r * N + c0 + PX / 2));
+		}
+		else
+		{
+			Chunk<PX> lo, hi;
+			lo.load(reinterpret_cast<const uint8_t *>(lev + r * N + c0));
+			hi.load(reinterpret_cast<const uint8_t *>(lev + r * N + c0 + PX / 2));
+#pragma unroll
+			for (int k = 0; k < PX / 4; ++k)
+			{
+				level[2 * k] = (int)(int16_t)(lo.d[k] & 0xffff); level[2 * k + 1] = (int)lo.d[k] >> 16;
+				level[PX / 2 + 2 * k] = (int)(int16_t)(hi.d[k] & 0xffff); level[PX / 2 + 2 * k + 1] = (int)hi.d[k] >> 16;
+			}
+		}
+		const int dq_add = 1 << (q.dq_shift - 1);
+#pragma unroll
+		for (int b = 0; b < PX; ++b)
+			L.buf_b[(c0 + b) * P + r] = (int16_t)clip3(-32768, 32767, (level[b] * q.dq_scale + dq_add) >> q.dq_shift);
+	}
+	if (encode && cbf_out)
+	{
+		cbf = wave_or(cbf);
+		if (lane == 0) *cbf_out = cbf;
+	}
+	load_weights<N>(L.tables, true, dst, lane % N, w);
+	wave_sync();
+	// residual_decode.c:371-413: columns of the coefficients with shift 7 (clipped, stored transposed), then the same with shift 12
+	transform_pass<N, true, true>(L.buf_b, L.buf_a, w, 7, lane);
+	wave_sync();
+	transform_pass<N, true, false>(L.buf_a, L.buf_b, w, 12, lane);
+	wave_sync();
+
+	if (owner)
+	{
+		const uint32_t *b32 = reinterpret_cast<const uint32_t *>(L.buf_b + r * P + c0);
+		Chunk<PX> rec;
+#pragma unroll
+		for (int k = 0; k < PX / 4; ++k)
+		{
+			uint32_t outw = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b)
+			{
+				const uint32_t pair = b32[2 * k + b / 2];
+				const int res = (b & 1) ? (int)pair >> 16 : (int)(int16_t)(pair & 0xffff);
+				const int sum = (int)(int16_t)(((pred.d[k] >> (8 * b)) & 0xff) + res);      // hevcasm_clip(int16_t x, ...) narrows first (residual_decode.c:350-356, :365)
+				outw |= (uint32_t)clip3(0, 255, sum) << (8 * b);
+			}
+			rec.d[k] = outw;
+		}
+		uint32_t *t32 = reinterpret_cast<uint32_t *>(&tile_at(L, tx + c0, ty + r));
+#pragma unroll
+		for (int k = 0; k < PX / 4; ++k) t32[k] = rec.d[k];
+		const ptrdiff_t at = (ptrdiff_t)(v.y0 + ty + r) * A.stride_recon + v.x0 + tx + c0;
+		rec.store(recon + at);
+		if (pred_out) pred.store(pred_out + at);
+	}
+	if (lane < (N / 4) * (N / 4)) L.done[((ty >> 2) + lane / (N / 4)) * 16 + (tx >> 2) + lane % (N / 4)] = 1;
+	wave_sync();
+}
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+
+__device__ __forceinline__ unsigned long long granule_load(const unsigned long long *p)
+{
+	return __hip_atomic_load((const gu64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void granule_store(unsigned long long *p, uint32_t value)
+{
+	__hip_atomic_store((gu64 *)p, (1ull << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ticket -> (frame, CTU): the wavefront order.  Step s = cx + 2 cy holds the CTUs (s - 2j, j), j = jmin(s) .. ; steps in order, inside a step frame after frame.
+__global__ __launch_bounds__(256) void intra_frames_order_kernel(uint32_t *order, int cols, int rows, uint32_t n_frames)
+{
+	const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+	const uint32_t per_frame = (uint32_t)cols * rows;
+	if (t >= per_frame * n_frames) return;
+	const uint32_t f = t / per_frame, c = t % per_frame;
+	const int cx = (int)(c % cols), cy = (int)(c / cols), s = cx + 2 * cy;
+	uint32_t before = 0;                                           // CTUs of one frame in earlier steps: row j holds min(max(s - 2j, 0), cols) of them
+	for (int j = 0; j < rows; ++j) before += (uint32_t)min(max(s - 2 * j, 0), cols);
+	const int jmin = max(0, (s - cols + 2) / 2), jmax = min(rows - 1, s / 2);
+	const uint32_t in_step = (uint32_t)(jmax - jmin + 1);
+	order[before * n_frames + f * in_step + (uint32_t)(cy - jmin)] = (f << 20) | ((uint32_t)cy << 10) | (uint32_t)cx;
+}
+
+__global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesArgs A)
+{
+	__shared__ __attribute__((aligned(16))) CtuLds L;
+	const int lane = (int)threadIdx.x;
+	const int ctu = A.ctu, per_edge = ctu / 4;
+	const uint32_t n_ctus = (uint32_t)A.cols * A.rows;
+	const bool encode = A.src != nullptr;
+	build_tables(L.tables, lane);
+	wave_sync();
+
+	for (;;)
+	{
+		uint32_t ticket = 0;
+		if (lane == 0) ticket = __hip_atomic_fetch_add((gu32 *)A.head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+		if (ticket >= A.n_items) return;
+		const uint32_t item = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.order[ticket]);
+		const int cx = (int)(item & 1023u), cy = (int)((item >> 10) & 1023u);
+		const uint32_t f = item >> 20, c = (uint32_t)cy * A.cols + cx;
+		CtuView v = { cx * ctu, cy * ctu, ctu, A.frame_w, A.frame_h };
+		uint8_t *recon = A.recon + f * A.pitch_recon;
+		uint8_t *pred_out = A.pred_out ? A.pred_out + f * A.pitch_recon : nullptr;
+		const uint32_t first = A.ctu_first[f * n_ctus + c], last = A.ctu_first[f * n_ctus + c + 1];
+		const uint32_t n_tus = min(last - first, (uint32_t)kMaxCtuTus);
+
+		// the CTU's TU list and source pixels: requested before the wait for the neighbours, they land meanwhile
+		for (uint32_t i = lane; i < n_tus; i += kLanes) L.tus[i] = A.tus[first + i];
+		if (encode)
+		{
+			const uint8_t *src = A.src + f * A.pitch_src;
+			for (int e = lane; e < ctu * ctu / 4; e += kLanes)      // dword pieces (the picture edge is a multiple of 4, rows need not be 16-byte multiples)
+			{
+				const int y = e / (ctu / 4), x = 4 * (e % (ctu / 4));
+				if (v.x0 + x < A.frame_w && v.y0 + y < A.frame_h)
+					*reinterpret_cast<uint32_t *>(L.srcs + y * 64 + x) = reinterpret_cast<const U1 *>(src + (ptrdiff_t)(v.y0 + y) * A.stride_src + v.x0 + x)->v;
+			}
+		}
+		for (int e = lane; e < 256 / 4; e += kLanes) reinterpret_cast<uint32_t *>(L.done)[e] = 0;
+
+		// the edges this CTU reads: right column of the CTU to the left, bottom row of the one above (+ the first 32 samples of the one above-right), the corner
+		// sample of the one above-left.  One granule per lane; a lane without one is done at once.
+		{
+			const int reach = min(32, ctu) / 4;
+			const unsigned long long *g = nullptr;
+			int kind = -1, k = 0;      // 0 left column, 1 top row, 2 top-right row, 3 corner
+			if (lane < per_edge) { kind = 0; k = lane; if (cx > 0) g = A.granules + ((size_t)f * n_ctus + c - 1) * 2 * per_edge + per_edge + k; }
+			else if (lane < 2 * per_edge) { kind = 1; k = lane - per_edge; if (cy > 0) g = A.granules + ((size_t)f * n_ctus + c - A.cols) * 2 * per_edge + k; }
+			else if (lane < 2 * per_edge + reach) { kind = 2; k = lane - 2 * per_edge; if (cy > 0 && cx + 1 < A.cols) g = A.granules + ((size_t)f * n_ctus + c - A.cols + 1) * 2 * per_edge + k; }
+			else if (lane == 2 * per_edge + reach) { kind = 3; if (cy > 0 && cx > 0) g = A.granules + ((size_t)f * n_ctus + c - A.cols - 1) * 2 * per_edge + per_edge - 1; }
+			unsigned long long got = 0;
+			const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+			for (uint32_t spins = 0;; ++spins)
+			{
+				if (g) got = granule_load(g);
+				if (__all(!g || (got >> 32) == 1ull)) break;
+				__builtin_amdgcn_s_sleep(2);
+				if ((spins & 255u) == 255u)
+				{
+					const bool late = __builtin_amdgcn_s_memrealtime() - t0 > kSpinLimitTicks;
+					const uint32_t aborted = __hip_atomic_load((const gu32 *)(A.head + 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (late || aborted)
+					{
+						if (lane == 0)
+						{
+							__hip_atomic_fetch_or((gu32 *)(A.head + 1), kStatusTimeout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							__hip_atomic_store((gu32 *)(A.head + 2), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+						return;      // every wave that sees the abort word leaves: the grid drains
+					}
+				}
+			}
+			if (g)
+			{
+				const uint32_t val = (uint32_t)got;
+				if (kind == 0)
+				{
+#pragma unroll
+					for (int b = 0; b < 4; ++b) tile_at(L, -1, 4 * k + b) = (uint8_t)(val >> (8 * b));
+				}
+				else if (kind == 1) *reinterpret_cast<uint32_t *>(&tile_at(L, 4 * k, -1)) = val;
+				else if (kind == 2) *reinterpret_cast<uint32_t *>(&tile_at(L, ctu + 4 * k, -1)) = val;
+				else tile_at(L, -1, -1) = (uint8_t)(val >> 24);
+			}
+		}
+		wave_sync();
+
+		int16_t *ctu_levels = A.levels + ((size_t)f * n_ctus + c) * (size_t)(ctu * ctu);
+		for (uint32_t i = 0; i < n_tus; ++i)
+		{
+			const hevcasm_hip_intra_tu d = L.tus[i];
+			const int log2n = __builtin_amdgcn_readfirstlane((int)d.log2TrafoSize), mode = __builtin_amdgcn_readfirstlane((int)d.intraPredMode);
+			const int tx = __builtin_amdgcn_readfirstlane((int)d.x) - v.x0, ty = __builtin_amdgcn_readfirstlane((int)d.y) - v.y0;
+			const int n = 1 << (log2n & 7);
+			const bool good = log2n >= 2 && log2n <= 5 && n <= ctu && mode <= 34 && tx >= 0 && ty >= 0 && tx + n <= ctu && ty + n <= ctu && tx % n == 0 && ty % n == 0 &&
+				v.x0 + tx + n <= A.frame_w && v.y0 + ty + n <= A.frame_h;
+			if (!good)
+			{
+				if (lane == 0) __hip_atomic_fetch_or((gu32 *)(A.head + 1), kStatusBadTu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				continue;
+			}
+			// z-scan index of the TU's first 4x4 cell inside the CTU
+			const uint32_t ux = (uint32_t)tx >> 2, uy = (uint32_t)ty >> 2;
+			uint32_t z = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) z |= ((ux >> b) & 1u) << (2 * b) | ((uy >> b) & 1u) << (2 * b + 1);
+			int16_t *lev = ctu_levels + 16u * z;
+			int *cbf_out = A.cbf ? A.cbf + first + i : nullptr;
+			switch (log2n)
+			{
+			case 2: reconstruct_tu<4>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
+			case 3: reconstruct_tu<8>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
+			case 4: reconstruct_tu<16>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
+			default: reconstruct_tu<32>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
+			}
+		}
+
+		// publish: bottom row, then right column; four samples + the tag in one 8-byte store each (written once, by this lane only)
+		{
+			unsigned long long *mine = A.granules + ((size_t)f * n_ctus + c) * 2 * per_edge;
+			if (lane < per_edge) granule_store(mine + lane, *reinterpret_cast<const uint32_t *>(&tile_at(L, 4 * lane, ctu - 1)));
+			else if (lane < 2 * per_edge)
+			{
+				const int k = lane - per_edge;
+				granule_store(mine + lane, (uint32_t)tile_at(L, ctu - 1, 4 * k) | ((uint32_t)tile_at(L, ctu - 1, 4 * k + 1) << 8) |
+					((uint32_t)tile_at(L, ctu - 1, 4 * k + 2) << 16) | ((uint32_t)tile_at(L, ctu - 1, 4 * k + 3) << 24));
+			}
+		}
+		wave_sync();
+	}
+}
+
+}  // namespace hevc
+
+using namespace hevc;
+
+static size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+struct WorkspaceLayout { size_t head, order, granules, total; uint32_t n_items; int cols, rows; };
+
+static WorkspaceLayout workspace_layout(int frame_w, int frame_h, int ctu, size_t n_frames)
+{
+	WorkspaceLayout w = {};
+	w.cols = (frame_w + ctu - 1) / ctu; w.rows = (frame_h + ctu - 1) / ctu;
+	const size_t items = (size_t)w.cols * w.rows * n_frames;
+	w.n_items = (uint32_t)items;
+	// the zeroed part first (head + granules, one memset from the start of the allocation, a multiple of 16 bytes), then the order table
+	w.head = 0;
+	w.granules = 64;
+	w.order = round_up(w.granules + items * 2 * (ctu / 4) * 8, 64);
+	w.total = round_up(w.order + 4 * items, 64);
+	return w;
+}
+
+static int check_geometry(int frame_w, int frame_h, int ctu, size_t n_frames)
+{
+	if (ctu != 16 && ctu != 32 && ctu != 64) return set_error(HEVCASM_HIP_EINVAL, "ctu must be 16, 32 or 64");
+	if (frame_w <= 0 || frame_h <= 0 || (frame_w & 3) || (frame_h & 3) || frame_w > 65532 || frame_h > 65532) return set_error(HEVCASM_HIP_EINVAL, "frame dimensions must be multiples of 4 below 65536");
+	if ((frame_w + ctu - 1) / ctu > 1023 || (frame_h + ctu - 1) / ctu > 1023) return set_error(HEVCASM_HIP_EINVAL, "more than 1023 CTUs in a row or column");
+	if (n_frames > 4096) return set_error(HEVCASM_HIP_EINVAL, "at most 4096 frames per call");
+	return 0;
+}
+
+extern "C" size_t hevcasm_hip_intra_frames_workspace_bytes(int frame_w, int frame_h, int ctu, size_t n_frames)
+{
+	if (check_geometry(frame_w, frame_h, ctu, n_frames)) return 0;
+	return workspace_layout(frame_w, frame_h, ctu, n_frames).total;
+}
+
+extern "C" int hevcasm_hip_intra_reconstruct_frames(
+	uint8_t *recon, ptrdiff_t stride_recon, size_t frame_pitch_recon,
+	const uint8_t *src, ptrdiff_t stride_src, size_t frame_pitch_src,
+	int16_t *levels, int *cbf, uint8_t *pred_out,
+	const hevcasm_hip_intra_tu *tus, const uint32_t *ctu_first, const hevcasm_hip_intra_qp *qp,
+	int frame_w, int frame_h, int ctu, int cIdx, int flags, size_t n_frames,
+	void *workspace, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (int e = check_geometry(frame_w, frame_h, ctu, n_frames)) return e;
+	if (n_frames == 0) return 0;
+	if (!recon || !levels || !tus || !ctu_first || !qp || !workspace) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	if (reinterpret_cast<uintptr_t>(workspace) & 15) return set_error(HEVCASM_HIP_EINVAL, "workspace must be 16-byte aligned");
+	if (reinterpret_cast<uintptr_t>(levels) & 3) return set_error(HEVCASM_HIP_EINVAL, "levels must be 4-byte aligned");
+	if (stride_recon < frame_w || (src && stride_src < frame_w)) return set_error(HEVCASM_HIP_EINVAL, "strides must be at least the frame width");
+	for (int k = 0; k < 4; ++k)
+	{
+		// the reference's own preconditions (quantize.c:162-168) and the int16 scale of its dequantiser's SIMD form
+		if (src && (qp[k].q_scale < 0 || qp[k].q_scale >= 0x8000 || qp[k].q_offset < 0 || qp[k].q_offset >= 0x8000 || qp[k].q_shift < 16 || qp[k].q_shift > 27))
+			return set_error(HEVCASM_HIP_EINVAL, "quantiser parameters outside 0 <= scale, offset < 0x8000, 16 <= shift <= 27");
+		if (qp[k].dq_scale < -32768 || qp[k].dq_scale > 32767 || qp[k].dq_shift < 1 || qp[k].dq_shift > 31)
+			return set_error(HEVCASM_HIP_EINVAL, "dequantiser parameters outside int16 scale, 1 <= shift <= 31");
+	}
+	const WorkspaceLayout w = workspace_layout(frame_w, frame_h, ctu, n_frames);
+	hipStream_t st = as_stream(stream);
+	uint8_t *ws = static_cast<uint8_t *>(workspace);
+
+	IntraFramesArgs a = {};
+	a.recon = recon; a.src = src; a.pred_out = pred_out;
+	a.stride_recon = stride_recon; a.stride_src = stride_src; a.pitch_recon = frame_pitch_recon; a.pitch_src = frame_pitch_src;
+	a.levels = levels; a.cbf = cbf; a.tus = tus; a.ctu_first = ctu_first;
+	for (int k = 0; k < 4; ++k) a.qp[k] = qp[k];
+	a.frame_w = frame_w; a.frame_h = frame_h; a.ctu = ctu; a.cols = w.cols; a.rows = w.rows; a.cIdx = cIdx; a.strong = (flags & HEVCASM_HIP_INTRA_STRONG_SMOOTHING) ? 1 : 0;
+	a.n_frames = (uint32_t)n_frames; a.n_items = w.n_items;
+	a.head = reinterpret_cast<uint32_t *>(ws + w.head);
+	a.order = reinterpret_cast<uint32_t *>(ws + w.order);
+	a.granules = reinterpret_cast<unsigned long long *>(ws + w.granules);
+
+	HEVC_HIP_TRY(hipMemsetAsync(ws, 0, w.order, st));      // ticket counter, status, abort word and every granule's tag: zero before every launch
+	hipLaunchKernelGGL(intra_frames_order_kernel, dim3(ceil_div(w.n_items, 256)), dim3(256), 0, st, a.order, w.cols, w.rows, a.n_frames);
+	if (int e = launch_status("intra_frames_order_kernel")) return e;
+	// single-wave workgroups, ~27 KiB of LDS each: up to five per CU; any grid size is correct (tickets), more than the work is pointless
+	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * 5);
+	hipLaunchKernelGGL(intra_frames_kernel, dim3(grid), dim3(kLanes), 0, st, a);
+	return launch_status("intra_frames_kernel");
+}
+
+extern "C" int hevcasm_hip_intra_frames_status(const void *workspace, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (!workspace) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	uint32_t head[4] = { 0, 0, 0, 0 };
+	HEVC_HIP_TRY(hipMemcpyAsync(head, workspace, sizeof(head), hipMemcpyDeviceToHost, as_stream(stream)));
+	HEVC_HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+	if (head[1] & kStatusTimeout) return set_error(HEVCASM_HIP_EINVAL, "intra frames: a wait for a neighbouring CTU timed out (TU list not in decoding order, or the device was lost)");
+	if (head[1] & kStatusBadTu) return set_error(HEVCASM_HIP_EINVAL, "intra frames: a malformed TU descriptor was skipped (size, mode, alignment or position)");
+	return 0;
+}

@@ -14,6 +14,7 @@
 // algorithmic bytes per block = N * N + 2 N.
 
 #include "common.hpp"
+#include "intra_predict.hpp"
 
 namespace hevc {
 
@@ -124,23 +125,6 @@ __global__ __launch_bounds__(kThreads) void pred_intra_dc_kernel(
 // row 0..N and the left column 0..N; DC: both edges -- and then every pixel is two LDS bytes and a blend.  Modes may differ from block to block
 // (`modes`), so everything below is per-block data; a batch with ONE mode takes the same kernel with the mode in an SGPR.
 // HBM-bound in principle (N^2 + 4N + 1 bytes per block); in this first form the per-pixel index arithmetic makes it VALU-bound.
-__constant__ int8_t kIntraAngle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
-__constant__ int16_t kIntraInvAngle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
-
-typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
-{
-	uint32_t r;
-	asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-	return r;
-}
-__device__ __forceinline__ uint32_t pk_lshr_u16(uint32_t a, uint32_t sh)
-{
-	uint32_t r;
-	asm("v_pk_lshrrev_b16 %0, %1, %2" : "=v"(r) : "v"(sh | (sh << 16)), "v"(a));     // the shift count is packed too: one per half
-	return r;
-}
-
 // Second form (round 5).  Everything angular is computed in FAMILY space: a horizontal mode m is the transpose of the vertical mode 36 - m on swapped
 // edges, so the staging step puts the edge the mode runs along ("main": top for modes 18..34, left for 2..17) into ref[] and the kernel always filters
 // along it; a lane owns 16 family-space bytes = R rows of L = min(N, 16) pixels, each row one (iIdx, iFact): L + 1 consecutive ref bytes come out of LDS
@@ -157,9 +141,7 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	                                           // same: small blocks are bound by their RECORDS, >= 129 bytes fetched per 16 / 64 bytes written: 4x4 moves
 	                                           // 5.0 TB/s of real traffic at "0.13" of algorithmic bytes, profiles/r05_intra_modes.txt)
 	constexpr int BPWG = kThreads / LPB;
-	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
 	constexpr int REF = 3 * N + 12;            // entries i = -N .. 2N + 1 at [N + i]; the dword reads of a row may run 8 bytes past the last entry
-	constexpr int L = PX;
 	constexpr int RAW = 4 * N + 4;
 	constexpr int LOADS = (N + LPB - 1) / LPB; // record dwords per lane: 1 (the first 32 lanes at 32x32)
 	__shared__ __attribute__((aligned(16))) uint8_t refs[BPWG * REF];
@@ -182,8 +164,6 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	uint8_t *ref = refs + (threadIdx.x / LPB) * REF;
 	uint8_t *tile = tiles + (threadIdx.x / LPB) * (N * N);
 	uint8_t *raw = raws + (threadIdx.x / LPB) * RAW;
-	auto top_at = [&](int x) { return (int)raw[2 * N + x]; };          // p[x][-1]
-	auto left_at = [&](int y) { return (int)raw[2 * N - 1 - y]; };     // p[-1][y]
 
 	uint32_t rec[LOADS], rec_corner = 0;
 	int rec_mode = uniform_mode;
@@ -212,152 +192,8 @@ __global__ __launch_bounds__(kThreads) void pred_intra_modes_kernel(
 	if (it + 1 < iterations) request(first_group + it + 1);
 	block_sync();
 
-	const int angle = kIntraAngle[mode];
-	const bool vertical = mode >= 18;
-	if (mode >= 2)
-	{
-		// ref[N + i], i >= 0: the corner, then the edge the mode runs along -- whole dwords at a time: the top row lies in raw[] in this order one byte
-		// off a dword boundary (v_alignbyte), the left column in the opposite order (v_alignbyte + a byte reversal); entries past 2N are never used by a
-		// sample that matters (they meet a zero weight) and take whatever the guard leaves
-		const uint32_t *raw32 = reinterpret_cast<const uint32_t *>(raw);
-		uint32_t *ref32w = reinterpret_cast<uint32_t *>(ref);
-		for (int q = j; q < (2 * N + 12) / 4; q += LPB)
-		{
-			uint32_t w = 0;
-			if (q <= 2 * N / 4)
-			{
-				if (vertical)
-				{
-					const uint32_t hi = q < 2 * N / 4 ? raw32[2 * N / 4 + q] : 0u;
-					w = __builtin_amdgcn_alignbyte(hi, raw32[2 * N / 4 + q - 1], 3);      // bytes raw[2N - 1 + 4q ...]
-				}
-				else
-				{
-					const uint32_t lo = q < 2 * N / 4 ? raw32[2 * N / 4 - q - 1] : 0u;
-					w = __builtin_amdgcn_perm(0u, __builtin_amdgcn_alignbyte(raw32[2 * N / 4 - q], lo, 1), 0x00010203u);   // bytes raw[2N - 4q], raw[2N - 4q - 1], ...
-				}
-				if (q == 0) w = (w & 0xffffff00u) | raw[4 * N];
-			}
-			ref32w[N / 4 + q] = w;
-		}
-		if (angle < 0)
-		{
-			// i < 0: the other edge projected by the inverse angle (8.4.4.2.6); entries below (N * angle) >> 5 are never read
-			const int inv = (int)kIntraInvAngle[mode - 11];
-			for (int e = j; e < N; e += LPB)
-			{
-				const int i = e - N;
-				const int k = min((i * inv + 128) >> 8, 2 * N);
-				ref[e] = (uint8_t)(vertical ? left_at(k - 1) : top_at(k - 1));
-			}
-		}
-	}
-	else if (mode == 0)
-	{
-		for (int e = j; e < 2 * N + 2; e += LPB) ref[e] = (uint8_t)(e <= N ? top_at(e) : left_at(e - N - 1));      // top 0..N, then left 0..N
-	}
-	else
-	{
-		for (int e = j; e < 2 * N; e += LPB) ref[e] = (uint8_t)(e < N ? top_at(e) : left_at(e - N));               // top 0..N-1, then left 0..N-1
-	}
-	block_sync();
-
 	Chunk<PX> out;
-	if (mode >= 2)
-	{
-		const uint32_t *ref32 = reinterpret_cast<const uint32_t *>(ref);
-		const int corner = ref[N], first = ref[N + 1];
-		{
-			const int v = PX * j / N, u0 = PX * j % N;
-			const int tt = (v + 1) * angle, idx = tt >> 5;
-			const uint32_t f = (uint32_t)tt & 31u;
-			const int s = N + u0 + idx + 1;
-			const uint32_t sh = (uint32_t)s & 3u;
-			uint32_t d[L / 4 + 2], a[L / 4 + 1];
-#pragma unroll
-			for (int k = 0; k < L / 4 + 2; ++k) d[k] = ref32[(s >> 2) + k];
-#pragma unroll
-			for (int k = 0; k < L / 4 + 1; ++k) a[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
-			const uint32_t w1 = f | (f << 16), w0 = 0x00200020u - w1;
-#pragma unroll
-			for (int k = 0; k < L / 4; ++k)
-			{
-				const uint32_t b = __builtin_amdgcn_alignbyte(a[k + 1], a[k], 1);
-				const uint32_t ae = a[k] & 0x00ff00ffu, ao = (a[k] >> 8) & 0x00ff00ffu, be = b & 0x00ff00ffu, bo = (b >> 8) & 0x00ff00ffu;
-				const uint32_t re = pk_lshr_u16(pk_mad_u16(ae, w0, pk_mad_u16(be, w1, 0x00100010u)), 5);
-				const uint32_t ro = pk_lshr_u16(pk_mad_u16(ao, w0, pk_mad_u16(bo, w1, 0x00100010u)), 5);
-				out.d[k] = re | (ro << 8);
-			}
-			if (edge && angle == 0 && u0 == 0)
-			{
-				// modes 26 / 10 with the boundary smoothing: the pixel next to the main edge takes half the gradient along the other edge
-				const int other = vertical ? left_at(v) : top_at(v);
-				out.d[0] = (out.d[0] & 0xffffff00u) | (uint32_t)clip3(0, 255, first + ((other - corner) >> 1));
-			}
-		}
-	}
-	else if (mode == 0)
-	{
-		const int tn = ref[N], ln = ref[2 * N + 1];
-		const uint32_t *top32 = reinterpret_cast<const uint32_t *>(ref);
-		{
-			const int y = PX * j / N, x0 = PX * j % N;
-			const int ly = ref[N + 1 + y];
-			const int row = (y + 1) * ln + N, step = tn - ly;
-			int across = (N - 1 - x0) * ly + (x0 + 1) * tn + row;
-#pragma unroll
-			for (int k = 0; k < L / 4; ++k)
-			{
-				const uint32_t tw = top32[x0 / 4 + k];
-				uint32_t px = 0;
-#pragma unroll
-				for (int b = 0; b < 4; ++b)
-				{
-					px |= (uint32_t)(((int)((tw >> (8 * b)) & 0xff) * (N - 1 - y) + across) >> (LOG2 + 1)) << (8 * b);
-					across += step;
-				}
-				out.d[k] = px;
-			}
-		}
-	}
-	else
-	{
-		uint32_t sum = 0;
-#pragma unroll
-		for (int q = 0; q < 2 * N / 4; ++q) sum = __builtin_amdgcn_sad_u8(reinterpret_cast<const uint32_t *>(ref)[q], 0, sum);
-		const int dc = (int)(sum + N) >> (LOG2 + 1);
-		uint8_t px[PX];
-#pragma unroll
-		for (int b = 0; b < PX; ++b)
-		{
-			const int o = PX * j + b, y = o / N, x = o % N;
-			int val = dc;
-			if (edge)
-			{
-				if (x == 0 && y == 0) val = (ref[N] + 2 * dc + ref[0] + 2) >> 2;
-				else if (y == 0) val = (ref[x] + 3 * dc + 2) >> 2;
-				else if (x == 0) val = (ref[N + y] + 3 * dc + 2) >> 2;
-			}
-			px[b] = (uint8_t)val;
-		}
-#pragma unroll
-		for (int k = 0; k < PX / 4; ++k)
-			out.d[k] = px[4 * k] | ((uint32_t)px[4 * k + 1] << 8) | ((uint32_t)px[4 * k + 2] << 16) | ((uint32_t)px[4 * k + 3] << 24);
-	}
-	// horizontal modes: the lane holds family row v (output COLUMN v), positions u0 .. u0 + L - 1 (output rows): through the tile, transposed
-	const bool transposed = mode >= 2 && !vertical;
-	if (transposed)
-	{
-		const int v = PX * j / N, u0 = PX * j % N;
-#pragma unroll
-		for (int b = 0; b < L; ++b) tile[(u0 + b) * N + v] = (uint8_t)(out.d[b / 4] >> (8 * (b % 4)));
-	}
-	block_sync();
-	if (transposed)
-	{
-#pragma unroll
-		for (int k = 0; k < PX / 4; ++k) out.d[k] = reinterpret_cast<const uint32_t *>(tile + PX * j)[k];
-	}
+	intra_predict_block<N, LPB>(raw, ref, tile, j, mode, edge, block_sync, out);
 	if (live) out.store(dst + (size_t)blk * (N * N) + PX * j);
 	}
 }

@@ -18,30 +18,11 @@
 // Algorithmic bytes per block: 4 N^2 (2 N^2 coefficients + N^2 prediction + N^2 output).
 
 #include "common.hpp"
+#include "dct_matrix.hpp"
 
 namespace hevc {
 
 // ---- coefficients ------------------------------------------------------------------------
-
-struct Matrix32 { signed char m[32][32]; };
-
-constexpr Matrix32 make_matrix32()
-{
-	// 64 * sqrt(2) * cos(a * pi / 64) as HEVC rounds it; row 0 of the matrix is the constant 64
-	constexpr int mag[33] = { 64, 90, 90, 90, 89, 88, 87, 85, 83, 82, 80, 78, 75, 73, 70, 67, 64,
-		61, 57, 54, 50, 46, 43, 38, 36, 31, 25, 22, 18, 13, 9, 4, 0 };
-	Matrix32 t = {};
-	for (int k = 0; k < 32; ++k)
-		for (int i = 0; i < 32; ++i)
-		{
-			int a = (k * (2 * i + 1)) & 127;
-			if (a > 64) a = 128 - a;
-			t.m[k][i] = (signed char)(k == 0 ? 64 : (a > 32 ? -mag[64 - a] : mag[a]));
-		}
-	return t;
-}
-
-static constexpr Matrix32 kDct = make_matrix32();
 
 // entry (k, i) of the N-point matrix = row k * 32 / N of the 32-point one
 template <int N> __device__ __forceinline__ constexpr int dct(int k, int i) { return kDct.m[k * (32 / N)][i]; }

@@ -211,3 +211,89 @@ def forward_case(tr_type, log2n, n, seed, kind="residual9", frame=(SMALL_W, SMAL
     p = Plane(fw, fh, frames)
     return dict(tr_type=tr_type, log2n=log2n, n=n, src=fill_i16(p.size, seed, kind, device), src_stride=p.stride,
                 src_off=p.tile_offsets(n, size, size).astype(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------
+# intra frames: a TU map in decoding order + quantiser parameters, for hevcasm_hip_intra_reconstruct_frames
+
+INTRA_TU_DTYPE = np.dtype([("x", "<u2"), ("y", "<u2"), ("log2", "u1"), ("mode", "u1"), ("reserved", "<u2")])      # = hevcasm_hip_intra_tu, 8 bytes
+
+
+def frame_2d(w, h, stride, seed, kind="video"):
+    """An h x stride plane (bytes beyond w in a row are zero).  'video': smooth two-dimensional shading + a few straight edges + noise of sigma ~4 --
+    directional structure, so that intra modes and block sizes matter; 'noise': uniform bytes; 'flat': 128; 'max' / 'zeros'."""
+    out = np.zeros((h, stride), dtype=np.uint8)
+    rng = np.random.default_rng(seed)
+    if kind == "noise":
+        out[:, :w] = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    elif kind == "flat":
+        out[:, :w] = 128
+    elif kind == "max":
+        out[:, :w] = 255
+    elif kind == "zeros":
+        pass
+    else:
+        y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+        img = 128 + 60 * np.sin(x / 37.0 + y / 91.0) + 40 * np.cos(y / 23.0 - x / 150.0)
+        for k in range(6):      # straight edges at assorted angles
+            a, b, c = rng.normal(size=3)
+            img += 35 * np.tanh((a * (x - w / 2) + b * (y - h / 2) + 40 * c) / 2.0) * (1 if k & 1 else -1)
+        img += rng.normal(0.0, 4.0, size=(h, w))
+        out[:, :w] = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    return out.reshape(-1)
+
+
+def intra_tu_map(w, h, ctu, seed, modes="mixed", split=(1.0, 0.7, 0.5, 0.35), min_log2=2, max_log2=5):
+    """A random quad-tree partition of a w x h plane (multiples of 4) into TUs of 4x4 ... 32x32, CTU after CTU in raster order and in z-scan order inside a
+    CTU -- the decoding order the availability rules of H.265 6.4.1 / 8.4.4.2.2 presume.  split[d]: probability that a square at depth d (0 = the CTU) is
+    split further (squares larger than 32, or crossing the picture boundary, always are).  modes: 'dc' (all INTRA_DC: the pinned subset), 'mixed' (uniform
+    0..34), 'planar', 'angular' (2..34), or an int.  Returns (tus: INTRA_TU_DTYPE array, ctu_first: uint32 [n_ctus + 1])."""
+    assert w % 4 == 0 and h % 4 == 0 and ctu in (16, 32, 64)
+    rng = np.random.default_rng(seed)
+    tus, first = [], [0]
+
+    def mode():
+        if isinstance(modes, int):
+            return modes
+        if modes == "dc":
+            return 1
+        if modes == "planar":
+            return 0
+        if modes == "angular":
+            return int(rng.integers(2, 35))
+        return int(rng.integers(0, 35))
+
+    def walk(x, y, s, depth):
+        if x >= w or y >= h:
+            return
+        log2 = s.bit_length() - 1
+        must = log2 > max_log2 or x + s > w or y + s > h
+        p = split[min(depth, len(split) - 1)]
+        if log2 > min_log2 and (must or rng.random() < p):
+            half = s // 2
+            for (dx, dy) in ((0, 0), (half, 0), (0, half), (half, half)):      # z-scan
+                walk(x + dx, y + dy, half, depth + 1)
+        else:
+            tus.append((x, y, log2, mode(), 0))
+
+    for cy in range(0, h, ctu):
+        for cx in range(0, w, ctu):
+            walk(cx, cy, ctu, 0)
+            first.append(len(tus))
+    return np.array(tus, dtype=INTRA_TU_DTYPE), np.array(first, dtype=np.uint32)
+
+
+def intra_qp(qp=27):
+    """The five arguments of hevcasm_quantize / hevcasm_quantize_inverse per TU size (rows: log2 - 2) that an HEVC encoder uses at this QP for 8-bit
+    video with flat scaling lists, int32 [4][5] = { q_scale, q_shift, q_offset, dq_scale, dq_shift }:
+    forward: quantScales[qp % 6], shift 14 + qp / 6 + (15 - 8 - log2N), rounding 171 / 512 (intra) -- as the reference's offset << (shift - 16)
+    (quantize.c:160-186) that is offset 171 << 7; inverse: levelScale[qp % 6] << (qp / 6), shift 6 - (15 - 8 - log2N) = log2N - 1 (H.265 8.6.4.2 with
+    m = 16 folded into the shift).  All within the reference's asserts (quantize.c:162-168).  The reference's self-test parameters (quantize.c:149-150,
+    :277-279) are INTRA_QP_REFERENCE."""
+    assert 0 <= qp <= 51
+    quant_scales = (26214, 23302, 20560, 18396, 16384, 14564)
+    level_scale = (40, 45, 51, 57, 64, 72)
+    return np.array([(quant_scales[qp % 6], 21 - log2 + qp // 6, 171 << 7, level_scale[qp % 6] << (qp // 6), log2 - 1) for log2 in (2, 3, 4, 5)], dtype=np.int32)
+
+
+INTRA_QP_REFERENCE = np.array([[51, 20, 14, 51, 14]] * 4, dtype=np.int32)

@@ -187,6 +187,73 @@ int hevcasm_hip_intra_filter_neighbours_batch(
 	uint8_t *filtered, ptrdiff_t filtered_stride, const uint8_t *neighbours, ptrdiff_t neighbour_stride,
 	int log2TrafoSize, int strong_intra_smoothing, size_t n_blocks, void *stream);
 
+/* ---- intra frames: on-device reconstruction in wavefront order (second half) ----------------------------------------
+ *
+ * A whole intra-coded plane, TU after TU, without leaving the device: for every transform unit the kernel builds the neighbour record from the
+ * RECONSTRUCTED plane (the reference's layout, pred_intra.c:59-65: left at [63 - y], top at [64 + x]; corner as f265/intra.asm:126-131), substitutes
+ * unavailable samples (H.265 8.4.4.2.2), decides on and applies the neighbour smoothing (8.4.4.2.3), predicts (hevcasm_pred_intra, pred_intra.h:55),
+ * and then runs the reconstruction loop of an encoder --
+ *     residual = src - prediction -> hevcasm_transform (residual_decode.h:82) -> hevcasm_quantize (quantize.h:78)
+ *              -> hevcasm_quantize_inverse (quantize.h:57) -> hevcasm_inverse_transform_add (residual_decode.h:54)
+ * -- or, with src == NULL, of a decoder (levels in, the last two steps only).  4x4 luma TUs take the DST (trType 1), as intra CUs do.
+ * Every arithmetic step is bit-identical to the reference's C function named; the steps the reference does not have (record construction,
+ * substitution, the smoothing decision) follow the text.  PINNED: frames whose TUs all use INTRA_DC (the one mode the reference wires,
+ * pred_intra.c:113-139) equal the composition of the reference's own C functions (oracle/refdrv.c OP_INTRA_FRAME; tests/golden).  Other modes:
+ * UNPINNED, as hevcasm_hip_pred_intra_modes_batch.
+ *
+ * Scheduling.  A TU needs the reconstructed samples left of, above and above-right of it, so the frame cannot be one flat batch.  CTUs are handed out
+ * in wavefront order -- CTU (cx, cy) after (cx - 1, cy) and (cx + 1, cy - 1), the two-CTU lag of HEVC's wavefront parallel processing -- by ONE
+ * persistent launch: workgroups draw tickets from a counter in `workspace`; ticket order is a topological order of the dependencies, so a workgroup
+ * only ever waits for CTUs that are already held by running workgroups (no co-residency assumption, no deadlock); a finished CTU publishes its bottom
+ * row and right column as self-tagged 8-byte granules in `workspace`, which its neighbours poll.  Inside a CTU the TUs run in list order on one
+ * wavefront.  One frame has at most min(rows, cols / 2) CTUs in flight; n_frames independent frames (an all-intra sequence, or the intra pictures of
+ * several streams) fill the device: frames are interleaved inside every wavefront step.
+ *
+ * Geometry.  frame_w, frame_h: multiples of 4 (partial CTUs at the right / bottom edge are fine).  ctu: 16, 32 or 64 (a 4:2:0 chroma plane of a 64x64-CTU
+ * stream is a plane with ctu = 32, cIdx = 1).  Frame f's planes start at recon + f * frame_pitch_recon, src + f * frame_pitch_src (bytes).
+ * TU list: tus[ctu_first[f * n_ctus + c] .. ctu_first[f * n_ctus + c + 1]) are the TUs of CTU c (raster order) of frame f, in decoding order (z-scan);
+ * x, y in plane samples; every TU aligned to its size and inside the picture; the TUs of a frame must TILE it (a sample of a neighbouring CTU counts as
+ * available whenever that CTU precedes in the wavefront).  Levels: frame f at levels + f * n_ctus * ctu * ctu; inside, CTU c at c * ctu * ctu, and the
+ * TU at (x, y) at 16 * z, z = the z-scan index of its first 4x4 cell in the CTU (bits of (x % ctu) / 4 and (y % ctu) / 4 interleaved, x lowest) -- a TU's
+ * N * N coefficients are contiguous, row-major, as the reference's coeffs[N * N] (residual_decode.h:54); how HM keeps a CTU's coefficients.
+ * cbf[i] (optional; encoder only) = hevcasm_quantize's return value for TU i of `tus` (the OR of its levels: zero / non-zero is what it means).
+ * qp: HOST pointer to 4 parameter sets, indexed log2TrafoSize - 2 (read during the call).  cIdx: 0 = luma (edge filters below 32x32, neighbour
+ * smoothing, DST at 4x4), else chroma.  flags: bit 0 = strong_intra_smoothing_enabled_flag.
+ * pred_out (optional): the prediction of every TU, same geometry as recon (what an encoder's mode decision wants to look at).
+ * workspace: hevcasm_hip_intra_frames_workspace_bytes(...) bytes of device memory, 16-byte aligned, owned by the call until `stream` has passed it; the
+ * call enqueues a memset of it, a small set-up launch and the persistent launch (graph-capturable).  Status: word 1 of the workspace is 0 after a good
+ * run; hevcasm_hip_intra_frames_status() waits for the stream and reports it (a malformed TU is skipped and flagged; a wait that times out -- only
+ * possible on a malformed list or a lost device -- makes every workgroup leave). */
+typedef struct
+{
+	uint16_t x, y;             /* top-left sample of the TU in its plane */
+	uint8_t log2TrafoSize;     /* 2..5 */
+	uint8_t intraPredMode;     /* 0..34 */
+	uint16_t reserved;         /* 0 */
+} hevcasm_hip_intra_tu;
+
+typedef struct
+{
+	int q_scale, q_shift, q_offset;      /* hevcasm_quantize's scale, shift, offset (quantize.c:160-186: 0 <= scale, offset < 0x8000, 16 <= shift <= 27) */
+	int dq_scale, dq_shift;              /* hevcasm_quantize_inverse's scale, shift (quantize.c:53-62; scale fits int16, 1 <= shift <= 31) */
+} hevcasm_hip_intra_qp;
+
+#define HEVCASM_HIP_INTRA_STRONG_SMOOTHING 1
+
+size_t hevcasm_hip_intra_frames_workspace_bytes(int frame_w, int frame_h, int ctu, size_t n_frames);
+
+int hevcasm_hip_intra_reconstruct_frames(
+	uint8_t *recon, ptrdiff_t stride_recon, size_t frame_pitch_recon,
+	const uint8_t *src, ptrdiff_t stride_src, size_t frame_pitch_src,
+	int16_t *levels, int *cbf, uint8_t *pred_out,
+	const hevcasm_hip_intra_tu *tus, const uint32_t *ctu_first, const hevcasm_hip_intra_qp *qp,
+	int frame_w, int frame_h, int ctu, int cIdx, int flags, size_t n_frames,
+	void *workspace, void *stream);
+
+/* Synchronises `stream` and returns 0 when the last hevcasm_hip_intra_reconstruct_frames on `workspace` ran clean, else HEVCASM_HIP_EINVAL with the reason
+ * in hevcasm_hip_last_error() (bit 0 of the status word: a malformed TU descriptor was skipped; bit 1: a dependency wait timed out). */
+int hevcasm_hip_intra_frames_status(const void *workspace, void *stream);
+
 /* ---- inter prediction ----------------------------------------------------------------- */
 
 /* Batched hevcasm_pred_uni_8to8 (reference pred_inter.h:56; C bodies pred_inter.c:141-228).

@@ -779,3 +779,111 @@ void orc_frame_sse_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b,
 		sse[i] = sum;
 	}
 }
+
+/* ------------------------------------------------------------------ a whole intra frame */
+
+/* H.265 8.4.4.2.2, sample by sample.  Search order: p[-1][2 nTbS - 1] up to p[-1][-1], then p[0][-1] to p[2 nTbS - 1][-1]. */
+void orc_intra_build_neighbours(uint8_t *nb, const uint8_t *recon, ptrdiff_t stride, int frame_w, int frame_h, const int32_t *order, int cur, int x, int y, int n)
+{
+	const int cells_w = (frame_w + 3) / 4, total = 4 * n + 1;
+	int val[129], ok[129];
+	for (int s = 0; s < total; ++s)
+	{
+		/* s < 2n: left column bottom-up; s == 2n: corner; s > 2n: top row left to right */
+		const int px = s <= 2 * n ? x - 1 : x + (s - 2 * n - 1);
+		const int py = s < 2 * n ? y + 2 * n - 1 - s : y - 1;
+		ok[s] = 0;
+		if (px >= 0 && py >= 0 && px < frame_w && py < frame_h)
+		{
+			const int32_t o = order[(py >> 2) * cells_w + (px >> 2)];
+			ok[s] = o >= 0 && o < cur;
+		}
+		val[s] = ok[s] ? recon[px + (ptrdiff_t)py * stride] : 0;
+	}
+	int first = -1;
+	for (int s = 0; s < total && first < 0; ++s) if (ok[s]) first = s;
+	if (first < 0)
+		for (int s = 0; s < total; ++s) val[s] = 1 << (8 - 1);        /* nothing available: 1 << (BitDepth - 1) */
+	else
+	{
+		for (int s = 0; s < first; ++s) val[s] = val[first];           /* p[-1][2 nTbS - 1] takes the first available sample in search order ... */
+		for (int s = first + 1; s < total; ++s) if (!ok[s]) val[s] = val[s - 1];      /* ... every other unavailable sample the one before it */
+	}
+	for (int s = 0; s < 2 * n; ++s) nb[63 - (2 * n - 1 - s)] = (uint8_t)val[s];
+	nb[128] = (uint8_t)val[2 * n];
+	for (int s = 2 * n + 1; s < total; ++s) nb[64 + (s - 2 * n - 1)] = (uint8_t)val[s];
+}
+
+int orc_intra_filter_flag(int cIdx, int mode, int n)
+{
+	if (cIdx != 0 || mode == 1 || n == 4) return 0;
+	const int dv = abs(mode - 26), dh = abs(mode - 10), dist = dv < dh ? dv : dh;
+	const int thres = n == 8 ? 7 : n == 16 ? 1 : 0;                       /* intraHorVerDistThres[nTbS] */
+	return dist > thres;
+}
+
+size_t orc_intra_level_offset(int x, int y, int frame_w, int ctu)
+{
+	const int cols = (frame_w + ctu - 1) / ctu;
+	const size_t base = ((size_t)(y / ctu) * cols + (size_t)(x / ctu)) * ctu * ctu;
+	const unsigned cx = (unsigned)(x % ctu) >> 2, cy = (unsigned)(y % ctu) >> 2;
+	unsigned z = 0;
+	for (int b = 0; b < 4; ++b) z |= ((cx >> b) & 1u) << (2 * b) | ((cy >> b) & 1u) << (2 * b + 1);
+	return base + 16u * z;
+}
+
+int orc_intra_reconstruct_frame(uint8_t *recon, ptrdiff_t stride_recon, const uint8_t *src, ptrdiff_t stride_src, int16_t *levels, int *cbf,
+		uint8_t *pred_out, const orc_intra_tu *tus, size_t n_tus, const orc_intra_qp *qp, int frame_w, int frame_h, int ctu, int cIdx, int strong)
+{
+	const int cells_w = (frame_w + 3) / 4, cells_h = (frame_h + 3) / 4;
+	int32_t *order = (int32_t *)malloc(sizeof(int32_t) * (size_t)cells_w * cells_h);
+	if (!order) return -1;
+	for (int i = 0; i < cells_w * cells_h; ++i) order[i] = -1;
+	int rc = 0;
+	for (size_t i = 0; i < n_tus && !rc; ++i)
+	{
+		const int n = 1 << tus[i].log2, x = tus[i].x, y = tus[i].y;
+		if (tus[i].log2 < 2 || tus[i].log2 > 5 || n > ctu || tus[i].mode > 34 || x % n || y % n || x + n > frame_w || y + n > frame_h) { rc = -1; break; }
+		for (int cy = y / 4; cy < (y + n) / 4; ++cy)
+			for (int cx = x / 4; cx < (x + n) / 4; ++cx)
+			{
+				if (order[cy * cells_w + cx] >= 0) rc = -1;
+				order[cy * cells_w + cx] = (int32_t)i;
+			}
+	}
+	for (int i = 0; i < cells_w * cells_h && !rc; ++i) if (order[i] < 0) rc = -1;
+	for (size_t i = 0; i < n_tus && !rc; ++i)
+	{
+		const int log2n = tus[i].log2, n = 1 << log2n, x = tus[i].x, y = tus[i].y, mode = tus[i].mode;
+		const orc_intra_qp *q = &qp[log2n - 2];
+		uint8_t rec[160], flt[160], pred[32 * 32];
+		int16_t res[32 * 32], coef[32 * 32], deq[32 * 32];
+		int16_t *lev = levels + orc_intra_level_offset(x, y, frame_w, ctu);
+		uint8_t *nb = rec + 16;
+		memset(rec, 0, sizeof(rec)); memset(flt, 0, sizeof(flt));
+		orc_intra_build_neighbours(nb, recon, stride_recon, frame_w, frame_h, order, (int)i, x, y, n);
+		if (orc_intra_filter_flag(cIdx, mode, n))
+		{
+			orc_intra_filter_neighbours(flt + 16, nb, log2n, strong);
+			nb = flt + 16;
+		}
+		/* the packed argument of the reference's function type: bit 0 = edge filters, luma below 32x32 (pred_intra.h:58-63) */
+		const int packed = (8 << 8) | (log2n << 1) | ((cIdx == 0 && log2n < 5) ? 1 : 0);
+		orc_pred_intra(pred, nb, mode, packed);
+		if (pred_out)
+			for (int r = 0; r < n; ++r) memcpy(pred_out + x + (ptrdiff_t)(y + r) * stride_recon, pred + r * n, (size_t)n);
+		const int trType = cIdx == 0 && log2n == 2;                          /* DST-VII for 4x4 luma blocks of intra CUs */
+		if (src)
+		{
+			for (int r = 0; r < n; ++r)
+				for (int c = 0; c < n; ++c) res[r * n + c] = (int16_t)(src[x + c + (ptrdiff_t)(y + r) * stride_src] - pred[r * n + c]);
+			orc_transform(trType, log2n, coef, res, n);
+			const int c = orc_quantize(lev, coef, q->q_scale, q->q_shift, q->q_offset, n * n);
+			if (cbf) cbf[i] = c;
+		}
+		orc_quantize_inverse(deq, lev, q->dq_scale, q->dq_shift, n * n);
+		orc_inverse_transform_add(trType, log2n, recon + x + (ptrdiff_t)y * stride_recon, stride_recon, pred, n, deq);
+	}
+	free(order);
+	return rc;
+}

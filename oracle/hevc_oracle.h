@@ -125,6 +125,30 @@ void orc_ssd_linear_batch(const uint8_t *src0, const uint8_t *src1, const uint32
 void orc_frame_sse_batch(const uint8_t *a, ptrdiff_t stride_a, const uint8_t *b, ptrdiff_t stride_b, const uint32_t *a_off, const uint32_t *b_off,
                          uint64_t *sse, int width, int height, size_t n);
 
+/* ---- a whole intra frame: neighbour construction + substitution (H.265 8.4.4.2.2), smoothing decision (8.4.4.2.3),
+ * prediction, and the reconstruction loop residual -> hevcasm_transform (residual_decode.h:82) -> hevcasm_quantize (quantize.h:78) ->
+ * hevcasm_quantize_inverse (quantize.h:57) -> hevcasm_inverse_transform_add (residual_decode.h:54), TU after TU in decoding order.
+ * The reference has none of the frame-level steps (its self-test feeds hevcasm_pred_intra random neighbours, pred_intra.c:196-227): they follow
+ * the text.  Pinned part: a frame whose TUs all use INTRA_DC -- every arithmetic step is then one of the reference's own C functions, composed by
+ * oracle/refdrv.c OP_INTRA_FRAME.  Frames with other modes: UNPINNED, like orc_pred_intra beyond mode 1.
+ * Same descriptors as include/hevcasm_hip.h (hevcasm_hip_intra_tu / _qp). */
+typedef struct { uint16_t x, y; uint8_t log2, mode; uint16_t reserved; } orc_intra_tu;
+typedef struct { int q_scale, q_shift, q_offset, dq_scale, dq_shift; } orc_intra_qp;
+
+/* the 4 nTbS + 1 neighbouring samples of the nTbS x nTbS block at (x, y) of `recon`, in the reference's record layout around nb (left column
+ * upwards ending at nb[63], top row from nb[64], corner at nb[128]); `order` holds, per 4 x 4 cell of the frame (row-major, (frame_w + 3) / 4 per row),
+ * the decoding index of the TU that covers it or -1; a sample is available when it lies inside the picture in a cell whose index is below `cur`. */
+void orc_intra_build_neighbours(uint8_t *nb, const uint8_t *recon, ptrdiff_t stride, int frame_w, int frame_h, const int32_t *order, int cur, int x, int y, int n);
+/* 8.4.4.2.3's filterFlag for a luma block (0 for chroma planes of 4:2:0) */
+int orc_intra_filter_flag(int cIdx, int mode, int n);
+/* offset (in coefficients) of the TU at (x, y) in the frame's level buffer: CTUs in raster order, ctu * ctu coefficients each, 4 x 4 cells in z-scan order inside */
+size_t orc_intra_level_offset(int x, int y, int frame_w, int ctu);
+/* returns 0, or -1 when the TU list is not a decodable tiling (a TU outside the picture / misaligned / overlapping another, or cells left uncovered).
+ * src == NULL: decoder -- `levels` is input, cbf is not written.  pred_out (optional): the prediction of every TU, same geometry as recon. */
+int orc_intra_reconstruct_frame(uint8_t *recon, ptrdiff_t stride_recon, const uint8_t *src, ptrdiff_t stride_src, int16_t *levels, int *cbf,
+		uint8_t *pred_out, const orc_intra_tu *tus, size_t n_tus, const orc_intra_qp *qp /* [4], by log2 - 2 */,
+		int frame_w, int frame_h, int ctu, int cIdx, int strong);
+
 #ifdef __cplusplus
 }
 #endif

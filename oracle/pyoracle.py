@@ -227,3 +227,32 @@ def frame_sse_batch(a, stride_a, b, stride_b, a_off, b_off, width, height):
 def dct_matrix(n):
     f = lib().orc_dct_matrix
     return np.array([[f(n, k, i) for i in range(n)] for k in range(n)], dtype=np.int32)
+
+
+def intra_reconstruct_frame(src, stride_src, levels_in, tus, qp, w, h, stride_recon, ctu, cidx, strong, want_pred=False):
+    """One intra frame, TU after TU (orc_intra_reconstruct_frame).  src = None: decoder, levels_in is input.  tus: structured array / (n, 8) uint8 of
+    hevcasm_hip_intra_tu; qp: int32 [4][5].  -> (recon [h * stride_recon], levels, cbf[, pred]).  PINNED only for all-DC maps."""
+    tus = np.ascontiguousarray(tus).view(np.uint8).reshape(-1, 8)
+    qp = np.ascontiguousarray(qp, dtype=np.int32).reshape(4, 5)
+    cols, rows = -(-w // ctu), -(-h // ctu)
+    levels = np.zeros(cols * rows * ctu * ctu, dtype=np.int16) if src is not None else _i16(levels_in).copy()
+    recon = np.zeros(h * stride_recon, dtype=np.uint8)
+    pred = np.zeros(h * stride_recon, dtype=np.uint8) if want_pred else None
+    cbf = np.zeros(len(tus), dtype=np.int32)
+    s = _u8(src) if src is not None else None
+    f = lib().orc_intra_reconstruct_frame
+    f.restype = C.c_int
+    rc = f(_p(recon), C.c_ssize_t(stride_recon), _p(s) if s is not None else None, C.c_ssize_t(stride_src), _p(levels), _p(cbf),
+           _p(pred) if want_pred else None, _p(tus), C.c_size_t(len(tus)), _p(qp), C.c_int(w), C.c_int(h), C.c_int(ctu), C.c_int(cidx), C.c_int(strong))
+    if rc != 0:
+        raise ValueError("orc_intra_reconstruct_frame: the TU list is not a decodable tiling of the %d x %d plane" % (w, h))
+    return (recon, levels, cbf, pred) if want_pred else (recon, levels, cbf)
+
+
+def intra_build_neighbours(recon, stride, w, h, order, cur, x, y, n):
+    """The 129-byte record (layout: left [63 - y], top [64 + x], corner [128]) of one block: H.265 8.4.4.2.2 (orc_intra_build_neighbours)."""
+    rec = np.zeros(160, dtype=np.uint8)
+    order = np.ascontiguousarray(order, dtype=np.int32)
+    r = _u8(recon)
+    lib().orc_intra_build_neighbours(C.c_void_p(rec.ctypes.data), _p(r), C.c_ssize_t(stride), C.c_int(w), C.c_int(h), _p(order), C.c_int(cur), C.c_int(x), C.c_int(y), C.c_int(n))
+    return rec

@@ -17,6 +17,7 @@ BINARY = os.path.join(_HERE, "_ref", "refdrv")
 
 OP_SAD, OP_SAD4, OP_SSD, OP_PRED_UNI, OP_PRED_BI, OP_INV, OP_FWD = 1, 2, 3, 4, 5, 6, 7
 OP_DEQUANT, OP_QUANT, OP_RECON, OP_DEQ_INV, OP_ME, OP_SATD, OP_SUBPEL, OP_INTRA, OP_SSD_LINEAR, OP_FRAME_SSE = 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
+OP_INTRA_FRAME = 18
 OP_SELFTEST, OP_BENCH_SAD, OP_BENCH_PRED, OP_BENCH_INV = 20, 30, 31, 32
 
 
@@ -155,6 +156,16 @@ class RefProc:
     def frame_sse_batch(self, a, stride_a, b, stride_b, a_off, b_off, width, height):
         o = self.call(OP_FRAME_SSE, [stride_a, stride_b, width, height, len(a_off)], [_u8(a), _u8(b), _u32(a_off), _u32(b_off)])
         return np.frombuffer(o[0], dtype=np.uint64).astype(np.int64)
+
+    def intra_reconstruct_frame(self, src, stride_src, levels_in, tus, qp, w, h, stride_recon, ctu, cidx, strong=0, want_pred=False):
+        """The reference's own functions composed over a frame (refdrv OP_INTRA_FRAME); only modes its table holds (INTRA_DC) -- any other raises."""
+        assert not want_pred
+        tus = np.ascontiguousarray(tus).view(np.uint8).reshape(-1, 8)
+        qp = np.ascontiguousarray(qp, dtype=np.int32).reshape(-1)
+        encode = src is not None
+        o = self.call(OP_INTRA_FRAME, [stride_recon, stride_src, w, h, ctu, cidx, len(tus), int(encode)] + [int(v) for v in qp],
+                      [_u8(src) if encode else _i16(levels_in), tus])
+        return np.frombuffer(o[0], dtype=np.uint8).copy(), np.frombuffer(o[1], dtype=np.int16).copy(), np.frombuffer(o[2], dtype=np.int32).copy()
 
     def selftest(self, family_mask, out_path):
         o = self.call(OP_SELFTEST, [family_mask], [out_path.encode()])

@@ -34,7 +34,7 @@
 #include <time.h>
 
 #define MAXBUF 8
-#define MAXPAR 16
+#define MAXPAR 40
 
 typedef struct { uint64_t bytes; uint8_t *p; } buf_t;
 
@@ -83,8 +83,42 @@ static double now_s(void)
 enum {
 	OP_SAD = 1, OP_SAD4 = 2, OP_SSD = 3, OP_PRED_UNI = 4, OP_PRED_BI = 5, OP_INV = 6, OP_FWD = 7,
 	OP_DEQUANT = 8, OP_QUANT = 9, OP_RECON = 10, OP_DEQ_INV = 11, OP_ME = 12, OP_SATD = 13, OP_SUBPEL = 14, OP_INTRA = 15, OP_SSD_LINEAR = 16, OP_FRAME_SSE = 17,
+	OP_INTRA_FRAME = 18,
 	OP_SELFTEST = 20, OP_BENCH_SAD = 30, OP_BENCH_PRED = 31, OP_BENCH_INV = 32
 };
+
+/* OP_INTRA_FRAME's own plumbing (ours, not the reference's: the reference never builds a neighbour record -- its self-test feeds random bytes,
+ * pred_intra.c:196-227).  H.265 8.4.4.2.2 by the letter: a sample is available when it lies in the picture in a 4x4 cell that has been reconstructed;
+ * if none is, everything is 1 << (BitDepth - 1); else the scan runs from p[-1][2N-1] up the left column, over the corner and along the top row, and every
+ * unavailable sample takes the value of the one before it (the first one: of the first available sample found by that scan). */
+static uint8_t frame_sample_or_flag(const uint8_t *recon, ptrdiff_t stride, const uint8_t *decoded, int cells_w, int w, int h, int px, int py, int *available)
+{
+	*available = px >= 0 && py >= 0 && px < w && py < h && decoded[(py / 4) * cells_w + px / 4];
+	return *available ? recon[px + py * stride] : 0;
+}
+
+static void frame_neighbours(uint8_t *nb, const uint8_t *recon, ptrdiff_t stride, const uint8_t *decoded, int cells_w, int w, int h, int x0, int y0, int n)
+{
+	int found = 0, available;
+	uint8_t last = 0;
+	/* pass 1: is anything available, and what does the scan meet first */
+	for (int y = 2 * n - 1; y >= -1 && !found; --y) { last = frame_sample_or_flag(recon, stride, decoded, cells_w, w, h, x0 - 1, y0 + y, &available); found = available; }
+	for (int x = 0; x < 2 * n && !found; ++x) { last = frame_sample_or_flag(recon, stride, decoded, cells_w, w, h, x0 + x, y0 - 1, &available); found = available; }
+	if (!found) last = 128;
+	/* pass 2: the scan itself */
+	for (int y = 2 * n - 1; y >= -1; --y)
+	{
+		const uint8_t v = frame_sample_or_flag(recon, stride, decoded, cells_w, w, h, x0 - 1, y0 + y, &available);
+		if (available) last = v;
+		nb[y < 0 ? 128 : 63 - y] = last;        /* pred_intra.c:59-65: left at [63 - y]; the corner p[-1][-1] at [128] (f265/intra.asm:126-131) */
+	}
+	for (int x = 0; x < 2 * n; ++x)
+	{
+		const uint8_t v = frame_sample_or_flag(recon, stride, decoded, cells_w, w, h, x0 + x, y0 - 1, &available);
+		if (available) last = v;
+		nb[64 + x] = last;
+	}
+}
 
 int main(void)
 {
@@ -95,7 +129,7 @@ int main(void)
 		uint32_t magic, op, npar, nbuf;
 		int64_t par[MAXPAR] = { 0 };
 		buf_t in[MAXBUF] = { { 0, 0 } };
-		buf_t out[2] = { { 0, 0 }, { 0, 0 } };
+		buf_t out[3] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
 		uint32_t nout = 0, status = 0;
 
 		if (!rd(&magic, 4)) return 0; /* EOF: done */
@@ -351,6 +385,63 @@ int main(void)
 				r[i] = sum;
 			}
 			out[0].p = (uint8_t *)r; out[0].bytes = 8 * n; nout = 1;
+			break;
+		}
+		case OP_INTRA_FRAME: /* one intra frame reconstructed TU by TU with the reference's own functions wherever it has one:
+		                        hevcasm_pred_intra (table; pred_intra.c:113-139 wires INTRA_DC only -> status 4 for any other mode),
+		                        hevcasm_transform, hevcasm_quantize, hevcasm_quantize_inverse, hevcasm_inverse_transform_add.
+		                        par: stride_recon, stride_src, frame_w, frame_h, ctu, cIdx, n_tus, encode(1|0), then 4 x { q_scale, q_shift, q_offset, dq_scale, dq_shift };
+		                        bufs: src plane (encode) or levels (decode), tus (8 bytes each: u16 x, u16 y, u8 log2, u8 mode, u16 0)
+		                        -> recon plane [frame_h * stride_recon], levels, cbf[n_tus] */
+		{
+			const ptrdiff_t sr = par[0], ss = par[1];
+			const int w = (int)par[2], h = (int)par[3], ctu = (int)par[4], cIdx = (int)par[5], encode = (int)par[7];
+			const size_t n_tus = (size_t)par[6];
+			const int cells_w = (w + 3) / 4, cells_h = (h + 3) / 4, cols = (w + ctu - 1) / ctu, rows = (h + ctu - 1) / ctu;
+			const size_t n_levels = (size_t)cols * rows * ctu * ctu;
+			uint8_t *recon = (uint8_t *)calloc((size_t)h * sr + 64, 1);
+			uint8_t *decoded = (uint8_t *)calloc((size_t)cells_w * cells_h + 1, 1);
+			int16_t *levels = (int16_t *)calloc(n_levels + 32, 2);
+			int *cbf = (int *)calloc(n_tus + 1, 4);
+			if (!encode) memcpy(levels, in[0].p, in[0].bytes < 2 * n_levels ? in[0].bytes : 2 * n_levels);
+			for (size_t i = 0; i < n_tus && !status; ++i)
+			{
+				const uint8_t *d = in[1].p + 8 * i;
+				const int x = d[0] | (d[1] << 8), y = d[2] | (d[3] << 8), log2n = d[4], mode = d[5], n = 1 << log2n;
+				const int packed = hevcasm_pred_intra_pack(cIdx, log2n);
+				hevcasm_pred_intra *predict = (mode >= 0 && mode < 35 && log2n >= 2 && log2n <= 5) ? *hevcasm_get_pred_intra(&t_intra, mode, packed) : 0;
+				if (!predict) { status = 4; break; }
+				HEVCASM_ALIGN(32, uint8_t, record[192]);
+				HEVCASM_ALIGN(32, uint8_t, pred[32 * 32]);
+				HEVCASM_ALIGN(32, int16_t, res[32 * 32]);
+				HEVCASM_ALIGN(32, int16_t, coef[32 * 32]);
+				HEVCASM_ALIGN(32, int16_t, deq[32 * 32]);
+				memset(record, 0, sizeof(record));
+				frame_neighbours(record + 32, recon, sr, decoded, cells_w, w, h, x, y, n);
+				predict(pred, record + 32, mode, packed);
+				const int trType = cIdx == 0 && log2n == 2;
+				/* level buffer: CTUs in raster order, 4x4 cells in z-scan order inside (include/hevcasm_hip.h) */
+				unsigned z = 0;
+				for (int b = 0; b < 4; ++b) z |= ((((unsigned)(x % ctu) >> 2) >> b) & 1u) << (2 * b) | ((((unsigned)(y % ctu) >> 2) >> b) & 1u) << (2 * b + 1);
+				int16_t *lev = levels + ((size_t)(y / ctu) * cols + x / ctu) * ctu * ctu + 16u * z;
+				const int64_t *q = par + 8 + 5 * (log2n - 2);
+				if (encode)
+				{
+					for (int r = 0; r < n; ++r)
+						for (int c = 0; c < n; ++c) res[r * n + c] = (int16_t)(in[0].p[x + c + (y + r) * ss] - pred[r * n + c]);
+					(*hevcasm_get_transform(&t_fwd, trType, log2n))(coef, res, n);
+					cbf[i] = (*hevcasm_get_quantize(&t_q))(lev, coef, (int)q[0], (int)q[1], (int)q[2], n * n);
+				}
+				(*hevcasm_get_quantize_inverse(&t_deq))(deq, lev, (int)q[3], (int)q[4], n * n);
+				(*hevcasm_get_inverse_transform_add(&t_inv, trType, log2n))(recon + x + y * sr, sr, pred, n, deq);
+				for (int cy = y / 4; cy < (y + n) / 4; ++cy)
+					for (int cx = x / 4; cx < (x + n) / 4; ++cx) decoded[cy * cells_w + cx] = 1;
+			}
+			free(decoded);
+			out[0].p = recon; out[0].bytes = (uint64_t)h * sr;
+			out[1].p = (uint8_t *)levels; out[1].bytes = 2 * n_levels;
+			out[2].p = (uint8_t *)cbf; out[2].bytes = 4 * n_tus;
+			nout = 3;
 			break;
 		}
 		case OP_SELFTEST: /* par[0] = bit mask of families; runs the reference's own self-tests on its C path. Output on stderr-free stdout is

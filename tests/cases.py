@@ -495,11 +495,65 @@ def intra_filter_cases(seed=1600):
 
 
 # families the reference has no C for: checked against the oracle's restatement of H.265 only (tests/test_intra_modes.py), never part of the golden fixtures
-UNPINNED_CASE_LISTS = dict(intra_modes=intra_modes_cases, intra_filter=intra_filter_cases)
+def _intra_frame_case(w, h, ctu, seed, modes, qp=27, cidx=0, strong=0, kind="video", split=(1.0, 0.7, 0.5, 0.35), decode=False, stride=None, min_log2=2):
+    """One intra frame for hevcasm_hip_intra_reconstruct_frames: a random quad-tree TU map in decoding order over synthetic content.  decode: the levels an
+    encoder pass of the ORACLE produced are the input instead of the source plane (the decoder's half of the loop)."""
+    stride = stride or (w + 15) // 16 * 16
+    tus, first = wl.intra_tu_map(w, h, ctu, seed, modes=modes, split=split, min_log2=min_log2)
+    c = dict(w=w, h=h, ctu=ctu, cidx=cidx, strong=strong, stride=stride, tus=tus.view(np.uint8).reshape(-1, 8), ctu_first=first,
+             qp=wl.intra_qp(qp) if isinstance(qp, int) else np.asarray(qp, dtype=np.int32), src=wl.frame_2d(w, h, stride, seed + 1, kind))
+    if decode:
+        from oracle import pyoracle
+        c["levels"] = pyoracle.intra_reconstruct_frame(c["src"], stride, None, c["tus"], c["qp"], w, h, stride, ctu, cidx, strong)[1]
+        c["src"] = np.zeros(0, dtype=np.uint8)
+    return c
+
+
+def intra_frame_cases(seed=1700):
+    """PINNED: every TU is INTRA_DC, the one mode the reference wires (pred_intra.c:113-139): each step is then one of the reference's own C functions,
+    composed by refdrv (OP_INTRA_FRAME).  Geometries: whole and partial CTUs at both picture edges, the three CTU sizes, luma (DST at 4x4, DC edge filter
+    below 32x32) and chroma, QPs from near-lossless to coarse, noise / flat / extreme content, all-4x4 and all-32x32 partitions, the decoder's half."""
+    out = []
+    out.append(("iframe_dc_200x136_ctu64", "intra_frame", _intra_frame_case(200, 136, 64, seed + 1, "dc")))
+    out.append(("iframe_dc_128x128_ctu64_qp10", "intra_frame", _intra_frame_case(128, 128, 64, seed + 2, "dc", qp=10)))
+    out.append(("iframe_dc_192x64_ctu32_qp40", "intra_frame", _intra_frame_case(192, 64, 32, seed + 3, "dc", qp=40)))
+    out.append(("iframe_dc_100x52_ctu16", "intra_frame", _intra_frame_case(100, 52, 16, seed + 4, "dc", qp=22)))
+    out.append(("iframe_dc_chroma_96x72_ctu32", "intra_frame", _intra_frame_case(96, 72, 32, seed + 5, "dc", cidx=1)))
+    out.append(("iframe_dc_noise_136x72", "intra_frame", _intra_frame_case(136, 72, 64, seed + 6, "dc", kind="noise", qp=33)))
+    out.append(("iframe_dc_flat_64x64", "intra_frame", _intra_frame_case(64, 64, 64, seed + 7, "dc", kind="flat")))
+    out.append(("iframe_dc_max_72x40_qp0", "intra_frame", _intra_frame_case(72, 40, 64, seed + 8, "dc", kind="max", qp=0)))
+    out.append(("iframe_dc_all4x4_128x64", "intra_frame", _intra_frame_case(128, 64, 64, seed + 9, "dc", split=(1.0, 1.0, 1.0, 1.0))))
+    out.append(("iframe_dc_all32_192x128", "intra_frame", _intra_frame_case(192, 128, 64, seed + 10, "dc", split=(1.0, 0.0))))
+    out.append(("iframe_dc_refqp_160x96", "intra_frame", _intra_frame_case(160, 96, 64, seed + 11, "dc", qp=wl.INTRA_QP_REFERENCE)))
+    out.append(("iframe_dc_decode_200x136", "intra_frame", _intra_frame_case(200, 136, 64, seed + 12, "dc", decode=True)))
+    out.append(("iframe_dc_decode_chroma_104x56", "intra_frame", _intra_frame_case(104, 56, 32, seed + 13, "dc", cidx=1, decode=True, qp=35)))
+    out.append(("iframe_dc_1row_of_ctus_448x32", "intra_frame", _intra_frame_case(448, 32, 32, seed + 14, "dc")))
+    out.append(("iframe_dc_1col_of_ctus_64x320", "intra_frame", _intra_frame_case(64, 320, 64, seed + 15, "dc")))
+    return out
+
+
+def intra_frame_mixed_cases(seed=1800):
+    """UNPINNED (as the modes themselves): the same pipeline with planar / angular modes, the smoothing decision and the bi-linear form in play."""
+    out = []
+    out.append(("iframe_mixed_200x136_ctu64", "intra_frame", _intra_frame_case(200, 136, 64, seed + 1, "mixed")))
+    out.append(("iframe_mixed_strong_256x128", "intra_frame", _intra_frame_case(256, 128, 64, seed + 2, "mixed", strong=1, split=(1.0, 0.3, 0.3, 0.3), kind="flat")))
+    out.append(("iframe_mixed_strong_video_192x192", "intra_frame", _intra_frame_case(192, 192, 64, seed + 3, "mixed", strong=1, split=(1.0, 0.2, 0.5, 0.5), qp=37)))
+    out.append(("iframe_angular_chroma_96x72_ctu32", "intra_frame", _intra_frame_case(96, 72, 32, seed + 4, "angular", cidx=1)))
+    out.append(("iframe_planar_136x72", "intra_frame", _intra_frame_case(136, 72, 64, seed + 5, "planar", qp=30)))
+    out.append(("iframe_mixed_100x52_ctu16", "intra_frame", _intra_frame_case(100, 52, 16, seed + 6, "mixed", qp=18)))
+    out.append(("iframe_mixed_all4x4_128x64", "intra_frame", _intra_frame_case(128, 64, 64, seed + 7, "mixed", split=(1.0, 1.0, 1.0, 1.0))))
+    out.append(("iframe_mixed_noise_128x128_qp45", "intra_frame", _intra_frame_case(128, 128, 64, seed + 8, "mixed", kind="noise", qp=45)))
+    out.append(("iframe_mixed_decode_200x136", "intra_frame", _intra_frame_case(200, 136, 64, seed + 9, "mixed", decode=True, strong=1)))
+    for m in (2, 10, 18, 26, 34):
+        out.append(("iframe_mode%d_128x64" % m, "intra_frame", _intra_frame_case(128, 64, 64, seed + 10 + m, m, qp=24)))
+    return out
+
+
+UNPINNED_CASE_LISTS = dict(intra_modes=intra_modes_cases, intra_filter=intra_filter_cases, intra_frame_mixed=intra_frame_mixed_cases)
 
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
-                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases)
+                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases, intra_frame=intra_frame_cases)
 
 
 # ------------------------------------------------------------------------------------- runners
@@ -552,6 +606,11 @@ def _run_cpu(api, family, c):
         return (api.frame_sse_batch(c["a"], c["stride_a"], c["b"], c["stride_b"], c["a_off"], c["b_off"], c["width"], c["height"]),)
     if family == "intra_modes":
         return (api.pred_intra_modes_batch(c["neighbours"], c["neighbour_stride"], c["modes"], c["packed"]),)
+    if family == "intra_frame":
+        enc = c["src"].size > 0
+        rec, lev, cbf = api.intra_reconstruct_frame(c["src"] if enc else None, c["stride"], None if enc else c["levels"], c["tus"], c["qp"], c["w"], c["h"], c["stride"],
+                                                    c["ctu"], c["cidx"], c["strong"])
+        return _intra_frame_outputs(rec, lev, cbf, c, enc)
     if family == "intra_filter":
         return (_filter_samples(api.intra_filter_neighbours_batch(c["neighbours"], c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=136), 136, c["log2"], c["n"]),)
     raise ValueError(family)
@@ -627,6 +686,15 @@ def run_hip(family, c):
     if family == "intra_modes":
         size = 1 << ((c["packed"] >> 1) & 0x7f)
         return (cpu(B.pred_intra_modes(plane(c["modes"].size * size * size), u8(c["neighbours"]), c["neighbour_stride"], u8(c["modes"]), c["packed"])),)
+    if family == "intra_frame":
+        enc = c["src"].size > 0
+        tus = c["tus"].view(wl.INTRA_TU_DTYPE).reshape(-1)
+        job = B.IntraFrames(c["w"], c["h"], c["ctu"], [tus], [c["ctu_first"]], c["qp"], c_idx=c["cidx"], strong=c["strong"], stride=c["stride"])
+        if not enc:
+            job.levels.copy_(i16(c["levels"]))
+        job.run(u8(c["src"]) if enc else None)
+        job.status()
+        return _intra_frame_outputs(cpu(job.recon), cpu(job.levels), cpu(job.cbf), c, enc)
     if family == "intra_filter":
         full = cpu(B.intra_filter_neighbours(u8(c["neighbours"]), c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=136))
         kept = _filter_samples(full, 136, c["log2"], c["n"])
@@ -635,6 +703,16 @@ def run_hip(family, c):
         assert not full[mask].any(), "the filter kernel wrote outside the 4N + 1 samples of its records"
         return (kept,)
     raise ValueError(family)
+
+
+def _intra_frame_outputs(recon, levels, cbf, c, enc):
+    """(picture w x h, the whole level buffer, cbf) -- and nothing outside the picture may have been written (the plane started as zeros)."""
+    plane = np.asarray(recon).reshape(c["h"], c["stride"])
+    assert not plane[:, c["w"]:].any(), "intra frame: bytes right of the picture were written"
+    outs = [plane[:, :c["w"]].copy(), np.asarray(levels).copy()]
+    if enc:
+        outs.append(np.asarray(cbf).copy())
+    return tuple(outs)
 
 
 def _filter_sample_index(stride, log2, n):
