@@ -529,6 +529,8 @@ def intra_frame_cases(seed=1700):
     out.append(("iframe_dc_decode_chroma_104x56", "intra_frame", _intra_frame_case(104, 56, 32, seed + 13, "dc", cidx=1, decode=True, qp=35)))
     out.append(("iframe_dc_1row_of_ctus_448x32", "intra_frame", _intra_frame_case(448, 32, 32, seed + 14, "dc")))
     out.append(("iframe_dc_1col_of_ctus_64x320", "intra_frame", _intra_frame_case(64, 320, 64, seed + 15, "dc")))
+    # the size VERDICT round 5 asks for: a whole 1080p picture (510 CTUs, the bottom row 56 samples tall), every TU INTRA_DC
+    out.append(("iframe_dc_1920x1080_ctu64", "intra_frame", _intra_frame_case(1920, 1080, 64, seed + 16, "dc", qp=27)))
     return out
 
 
