@@ -6,7 +6,7 @@
 // (intra_predict.hpp: INTRA_DC = pred_intra.c:68-103) -> residual -> forward transform (residual_decode.c:592-892) -> quantise (quantize.c:160-186)
 // -> dequantise (quantize.c:53-62) -> inverse transform + add (residual_decode.c:69-413).  The arithmetic of every step the reference has is
 // restated exactly (32-bit sums, the reference's rounding, truncating forward stores, int16 clips of the inverse passes, the int16 narrowing of
-// hevcasm_clip); pinned for all-DC frames against the composition of the reference's own functions (oracle/refdrv.c OP_INTRA_FRAME).
+// hevcasm_clip); pinned for all-DC frames against the composition of the reference's own functions (tests/golden: iframe_dc_*).
 //
 // Structure (MI355X): ONE persistent launch of single-wavefront workgroups.  A workgroup draws a ticket (atomic counter), looks the ticket up in a table
 // that lists every (frame, CTU) in wavefront order -- key cx + 2 cy, the two-CTU lag of HEVC's wavefront parallel processing, frames interleaved inside

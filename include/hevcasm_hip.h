@@ -198,7 +198,7 @@ int hevcasm_hip_intra_filter_neighbours_batch(
  * -- or, with src == NULL, of a decoder (levels in, the last two steps only).  4x4 luma TUs take the DST (trType 1), as intra CUs do.
  * Every arithmetic step is bit-identical to the reference's C function named; the steps the reference does not have (record construction,
  * substitution, the smoothing decision) follow the text.  PINNED: frames whose TUs all use INTRA_DC (the one mode the reference wires,
- * pred_intra.c:113-139) equal the composition of the reference's own C functions (oracle/refdrv.c OP_INTRA_FRAME; tests/golden).  Other modes:
+ * pred_intra.c:113-139) equal the composition of the reference's own C functions (tests/golden: iframe_dc_*).  Other modes:
  * UNPINNED, as hevcasm_hip_pred_intra_modes_batch.
  *
  * Scheduling.  A TU needs the reconstructed samples left of, above and above-right of it, so the frame cannot be one flat batch.  CTUs are handed out
