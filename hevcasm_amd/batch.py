@@ -268,6 +268,27 @@ def frame_sse(a, stride_a, b, stride_b, a_off, b_off, width, height, out=None):
     return out
 
 
+class PredPlane(capi.C.Structure):
+    """= hevcasm_hip_pred_plane"""
+    _fields_ = [("dst", capi.C.c_void_p), ("stride_dst", capi.C.c_ssize_t), ("ref0", capi.C.c_void_p), ("ref1", capi.C.c_void_p), ("stride_ref", capi.C.c_ssize_t)]
+
+
+def pred_runs(planes, runs, dst_off, ref0_off, frac0, ref1_off=None, frac1=None):
+    """hevcasm_hip_pred_uni_8to8_runs (ref1_off is None) / hevcasm_hip_pred_bi_8to8_runs: ONE launch for a frame's whole partition.
+    planes: list of (dst tensor, stride_dst, ref0 tensor, ref1 tensor or None, stride_ref); runs: numpy array of workload.PRED_RUN_DTYPE (host)."""
+    table = (PredPlane * len(planes))()
+    for i, (dst, sd, r0, r1, sr) in enumerate(planes):
+        table[i] = PredPlane(dst.data_ptr(), sd, r0.data_ptr(), r1.data_ptr() if r1 is not None else None, sr)
+    runs = np.ascontiguousarray(runs)
+    assert runs.dtype.itemsize == 12
+    L = lib()
+    if ref1_off is None:
+        check(L.hevcasm_hip_pred_uni_8to8_runs(table, len(planes), runs.ctypes.data, len(runs), dst_off.data_ptr(), ref0_off.data_ptr(), frac0.data_ptr(), _stream()), "pred_uni_runs")
+    else:
+        check(L.hevcasm_hip_pred_bi_8to8_runs(table, len(planes), runs.ctypes.data, len(runs), dst_off.data_ptr(), ref0_off.data_ptr(), ref1_off.data_ptr(),
+                                              frac0.data_ptr(), frac1.data_ptr(), _stream()), "pred_bi_runs")
+
+
 class IntraFrames:
     """hevcasm_hip_intra_reconstruct_frames on torch tensors: n_frames planes of frame_w x frame_h (row stride `stride`, frames `stride * frame_h` apart),
     a TU list per frame (hevcasm_amd.workload.intra_tu_map: tus + ctu_first), quantiser parameters int32 [4][5].  Device buffers and the workspace are made

@@ -37,6 +37,8 @@ HIP_API = {
     "hevcasm_hip_pred_bi_8to8_batch": (_i, [_vp, _pd, _vp, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_uni_8to8_batch_2planes": (_i, [_vp, _vp, _pd, _vp, _vp, _pd, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_bi_8to8_batch_2planes": (_i, [_vp, _vp, _pd, _vp, _vp, _vp, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
+    "hevcasm_hip_pred_uni_8to8_runs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "hevcasm_hip_pred_bi_8to8_runs": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hevcasm_hip_inverse_transform_add_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
     "hevcasm_hip_dequant_inverse_transform_add_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_transform_batch": (_i, [_vp, _vp, _pd, _vp, _i, _i, _sz, _vp]),

@@ -35,7 +35,9 @@
 // Algorithmic bytes per PU: refs * (W + T - 1)(H + T - 1) + W * H (+ 4 (1 + refs) + refs descriptor bytes).
 
 #include "common.hpp"
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace hevc {
 
@@ -304,23 +306,16 @@ static ptrdiff_t plane_distance(const void *b, const void *a) { return (ptrdiff_
 // FAST: W % 4 == 0 and (rows per wave) % TAPS == 0 -- the row loop then has no branch around any load or store (see the loop).
 // (Round 4: holding the uni 16-rows-in-flight variant to 96 registers for a fifth wave per SIMD (5 dwords of scratch) costs 4-9 %, and a third wave for
 // the bi strip kernel (168 registers, 10 dwords of scratch) changes nothing: profiles/r04_pred_occupancy_ab.txt.  The compiler's own allocation stays.)
+// (the body of pred_stream_kernel as a device function: the same code serves the one-size launches below and, per run of equally sized PUs, the one-launch
+// frame entry points hevcasm_hip_pred_*_runs; `wg` = the workgroup's index within its launch or run)
 template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW, bool FAST>
-__global__ __launch_bounds__(kThreads) void pred_stream_kernel(
+__device__ __forceinline__ void pred_stream_body(
 	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
 	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
 	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
-	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments,
-	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
+	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments, const uint32_t wg)
 {
-	// gridDim.y = 2: the same PU list on a second set of planes (Cb and Cr share motion vectors and geometry); the second
-	// set is given as byte distances from the first (blockIdx.y is wave-uniform: scalar adds)
-	if (blockIdx.y)
-	{
-		dst += plane2_dst;
-		ref0 += plane2_ref0;
-		ref1 += plane2_ref1;
-	}
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
 	constexpr int CPL = 4 * NDW;            // window / output columns per lane
@@ -328,7 +323,6 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	static_assert(TAPS % AHEAD == 0 || AHEAD % TAPS == 0, "the look-ahead ring and the unroll must divide one another");
 	constexpr int UNROLL = AHEAD > TAPS ? AHEAD : TAPS;     // slot indices (i % TAPS, i % AHEAD) are static after unrolling by this
 
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
 	const int lane = threadIdx.x & 63;
 	int sub = lane / LW;
@@ -559,6 +553,75 @@ __global__ __launch_bounds__(kThreads) void pred_stream_kernel(
 	}
 }
 
+
+template <int TAPS, int NDW, bool BI, int AHEAD, bool NARROW, bool FAST>
+__global__ __launch_bounds__(kThreads) void pred_stream_kernel(
+	uint8_t *__restrict__ dst, ptrdiff_t stride_dst,
+	const uint8_t *__restrict__ ref0, const uint8_t *__restrict__ ref1, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ ref0_off, const uint32_t *__restrict__ ref1_off,
+	const uint8_t *__restrict__ frac0, const uint8_t *__restrict__ frac1,
+	int W, int H, int LW /* lanes per PU */, int PPW /* PUs per wave */, uint32_t n_blocks, int log2_segments,
+	ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
+{
+	// gridDim.y = 2: the same PU list on a second set of planes (Cb and Cr share motion vectors and geometry); the second
+	// set is given as byte distances from the first (blockIdx.y is wave-uniform: scalar adds)
+	if (blockIdx.y)
+	{
+		dst += plane2_dst;
+		ref0 += plane2_ref0;
+		ref1 += plane2_ref1;
+	}
+	pred_stream_body<TAPS, NDW, BI, AHEAD, NARROW, FAST>(dst, stride_dst, ref0, ref1, stride_ref, dst_off, ref0_off, ref1_off, frac0, frac1,
+		W, H, LW, PPW, n_blocks, log2_segments, xcd_contiguous(blockIdx.x, gridDim.x));
+}
+
+// ---- one launch for a frame's partition: runs of equally sized PUs, any sizes, several planes (round 6) -----------------------------------------
+//
+// A codec's frame is never one PU size: HEVC has 24 (pred_inter.c:438-444) on three planes, and one launch per (size, plane) is up to 72 launches of
+// 11 - 21 us for a 1080p frame whose whole data moves in ~3 us (profiles/r05 bench rows inter_pred_latency).  Here the host lists the frame as RUNS --
+// `count` consecutive descriptors of one size on one plane -- and ONE launch serves them all: a workgroup finds its run by binary search over the runs'
+// first workgroups (the table travels in the kernel arguments) and then runs the general form of the stream kernel for that run's geometry (4 lane
+// widths x tap counts; the size-specialised variants of the one-size launches are a throughput matter, a single frame is latency).
+constexpr int kMaxPredRuns = 96;
+struct PredRunDev { uint32_t wg_count, first, count; uint8_t variant, W, H, lw, ppw, log2_segments, plane, pad; };
+struct PredPlaneDev { uint8_t *dst; const uint8_t *ref0, *ref1; ptrdiff_t stride_dst, stride_ref; };
+struct PredRunsArgs
+{
+	PredPlaneDev planes[4];
+	const uint32_t *dst_off, *ref0_off, *ref1_off;
+	const uint8_t *frac0, *frac1;
+	uint32_t n_runs, total_wgs;
+	uint32_t wg_start[kMaxPredRuns];      // first workgroup of run i; unused entries hold 0xffffffff.  Dense, so that the lookup is a handful of wide scalar loads
+	PredRunDev runs[kMaxPredRuns];
+};
+
+template <bool BI>
+__global__ __launch_bounds__(kThreads) void pred_runs_kernel(const PredRunsArgs a)
+{
+	// the run this workgroup belongs to = the number of runs that start at or before it, minus one: all 96 starts are compared (independent scalar loads and
+	// compares; a binary search would be seven DEPENDENT loads from the kernel-argument segment before the first descriptor load can be issued)
+	uint32_t at_or_before = 0, start = 0;
+#pragma unroll
+	for (int i = 0; i < kMaxPredRuns; ++i)
+	{
+		const bool in = a.wg_start[i] <= blockIdx.x;
+		at_or_before += in ? 1u : 0u;
+		start = in ? a.wg_start[i] : start;      // starts ascend: the last one taken is the run's
+	}
+	const PredRunDev r = a.runs[at_or_before - 1];
+	const PredPlaneDev p = a.planes[r.plane];
+	const uint32_t wg = xcd_contiguous(blockIdx.x - start, r.wg_count);
+#define HEVC_RUN(T, NDW) pred_stream_body<T, NDW, BI, T, NDW == 1, false>(p.dst, p.stride_dst, p.ref0, p.ref1, p.stride_ref, a.dst_off + r.first, a.ref0_off + r.first, \
+		a.ref1_off + r.first, a.frac0 + r.first, a.frac1 + r.first, r.W, r.H, r.lw, r.ppw, r.count, r.log2_segments, wg)
+	switch (r.variant)
+	{
+	case 0: HEVC_RUN(8, 2); break;
+	case 1: HEVC_RUN(8, 1); break;
+	case 2: HEVC_RUN(4, 2); break;
+	default: HEVC_RUN(4, 1); break;
+	}
+#undef HEVC_RUN
+}
 
 template <int TAPS, int NDW, bool BI>
 static int launch_pred_ndw(uint8_t *dst, ptrdiff_t sd, const uint8_t *ref0, const uint8_t *ref1, ptrdiff_t sr,
@@ -1159,9 +1222,92 @@ static int check_pred_args(int taps, int W, int H, size_t n)
 	return 0;
 }
 
+// host side of the runs entry points: the run table, validated like a one-size call each
+template <bool BI>
+static int launch_pred_runs(const hevcasm_hip_pred_plane *planes, int n_planes, const hevcasm_hip_pred_run *runs, int n_runs,
+		const uint32_t *dof, const uint32_t *r0, const uint32_t *r1, const uint8_t *f0, const uint8_t *f1, hipStream_t st)
+{
+	if (n_planes < 1 || n_planes > 4) return set_error(HEVCASM_HIP_EINVAL, "1 to 4 planes");
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!planes || !runs || !dof || !r0 || !f0 || (BI && (!r1 || !f1))) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	for (int p = 0; p < n_planes; ++p)
+		if (!planes[p].dst || !planes[p].ref0 || (BI && !planes[p].ref1)) return set_error(HEVCASM_HIP_EINVAL, "null plane pointer");
+	size_t launch_waves = 0;      // the whole launch's waves decide whether tall PUs are cut into row segments (launch_pred_ndw's rule)
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const hevcasm_hip_pred_run &r = runs[i];
+		if (int e = check_pred_args(r.taps, r.nPbW, r.nPbH, r.count)) return e;
+		if (r.plane >= n_planes) return set_error(HEVCASM_HIP_EINVAL, "run names a plane that was not given");
+		const int ndw = r.nPbW >= 8 ? 2 : 1, lw = (r.nPbW + r.taps - 1 + 4 * ndw - 1) / (4 * ndw);
+		launch_waves += ceil_div(r.count, (size_t)(kWave / lw));
+	}
+	// Each run's geometry; then the runs are dealt to the grid LONGEST WAVES FIRST (rows per wave, descending): the launch ends when its last wave does, and a
+	// 64-row PU that starts in the last generation of workgroups would be the whole tail.
+	std::vector<PredRunDev> table;
+	table.reserve((size_t)n_runs);
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const hevcasm_hip_pred_run &r = runs[i];
+		if (r.count == 0) continue;
+		const int T = r.taps, W = r.nPbW, H = r.nPbH;
+		const int ndw = W >= 8 ? 2 : 1, lw = (W + T - 1 + 4 * ndw - 1) / (4 * ndw), ppw = kWave / lw;
+		size_t all = launch_waves;
+		int log2_segments = 0;
+		while (log2_segments < 2 && all < 16384 && H % (2 << log2_segments) == 0 && (H >> (log2_segments + 1)) >= 2 * T)
+		{
+			++log2_segments;
+			all *= 2;
+		}
+		PredRunDev d = {};
+		d.first = r.first; d.count = r.count;
+		d.variant = (uint8_t)((T == 8 ? 0 : 2) + (ndw == 2 ? 0 : 1));
+		d.W = (uint8_t)W; d.H = (uint8_t)H; d.lw = (uint8_t)lw; d.ppw = (uint8_t)ppw; d.log2_segments = (uint8_t)log2_segments; d.plane = r.plane;
+		table.push_back(d);
+	}
+	std::stable_sort(table.begin(), table.end(), [](const PredRunDev &x, const PredRunDev &y) { return (x.H >> x.log2_segments) > (y.H >> y.log2_segments); });
+	for (size_t base = 0; base < table.size(); base += kMaxPredRuns)      // more runs than one table holds: the next launch
+	{
+		PredRunsArgs a = {};
+		for (int p = 0; p < n_planes; ++p) a.planes[p] = PredPlaneDev{ planes[p].dst, planes[p].ref0, BI ? planes[p].ref1 : planes[p].ref0, planes[p].stride_dst, planes[p].stride_ref };
+		a.dst_off = dof; a.ref0_off = r0; a.ref1_off = BI ? r1 : r0; a.frac0 = f0; a.frac1 = BI ? f1 : f0;
+		uint32_t wgs = 0, used = 0;
+		for (int i = 0; i < kMaxPredRuns; ++i) a.wg_start[i] = 0xffffffffu;
+		for (size_t i = base; i < table.size() && i < base + kMaxPredRuns; ++i)
+		{
+			PredRunDev &d = a.runs[used];
+			d = table[i];
+			a.wg_start[used++] = wgs;
+			const size_t waves = ceil_div(d.count, (size_t)d.ppw) << d.log2_segments;
+			d.wg_count = ceil_div(waves, (size_t)(kThreads / kWave));
+			wgs += d.wg_count;
+		}
+		a.n_runs = used; a.total_wgs = wgs;
+		hipLaunchKernelGGL(pred_runs_kernel<BI>, dim3(wgs), dim3(kThreads), 0, st, a);
+		if (int e = launch_status("pred_runs_kernel")) return e;
+	}
+	return 0;
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_pred_uni_8to8_runs(
+	const hevcasm_hip_pred_plane *planes, int n_planes, const hevcasm_hip_pred_run *runs, int n_runs,
+	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac, void *stream)
+{
+	if (int e = check_device()) return e;
+	return launch_pred_runs<false>(planes, n_planes, runs, n_runs, dst_off, ref_off, ref_off, frac, frac, as_stream(stream));
+}
+
+extern "C" int hevcasm_hip_pred_bi_8to8_runs(
+	const hevcasm_hip_pred_plane *planes, int n_planes, const hevcasm_hip_pred_run *runs, int n_runs,
+	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off, const uint8_t *frac0, const uint8_t *frac1, void *stream)
+{
+	if (int e = check_device()) return e;
+	return launch_pred_runs<true>(planes, n_planes, runs, n_runs, dst_off, ref0_off, ref1_off, frac0, frac1, as_stream(stream));
+}
 
 #ifdef PRED_STAMPS
 extern "C" int hevcasm_hip_debug_pred_stamps(unsigned long long *buf)

@@ -297,3 +297,94 @@ def intra_qp(qp=27):
 
 
 INTRA_QP_REFERENCE = np.array([[51, 20, 14, 51, 14]] * 4, dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# a frame's inter partition: every PU size of the reference's list (pred_inter.c:438-444), three planes, one launch (hevcasm_hip_pred_*_runs)
+
+PRED_RUN_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("taps", "u1"), ("w", "u1"), ("h", "u1"), ("plane", "u1")])      # = hevcasm_hip_pred_run, 12 bytes
+
+
+def inter_partition(w, h, seed, bi=False, split=(0.75, 0.6, 0.5, 0.4)):
+    """Cuts a w x h luma plane (multiples of 8) into coding units by a random quad-tree (64 ... 8) and every CU into prediction units by a random HEVC part
+    mode: 2Nx2N, 2NxN, Nx2N, and the asymmetric 2NxnU / 2NxnD / nLx2N / nRx2N (CUs of 16 and up) -- which between them produce exactly the 24 sizes of
+    pred_inter.c:438-444.  8x4 / 4x8 are uni-prediction only (HEVC forbids them for bi; the reference lists 22 sizes for bi, pred_inter.c:687-693).
+    -> list of (x, y, pw, ph) in coding order."""
+    rng = np.random.default_rng(seed)
+    pus = []
+
+    def cu(x, y, s):
+        modes = ["2Nx2N", "2NxN", "Nx2N"]
+        if s >= 16:
+            modes += ["2NxnU", "2NxnD", "nLx2N", "nRx2N"]
+        if s == 8 and bi:
+            modes = ["2Nx2N"]
+        m = modes[int(rng.integers(0, len(modes)))]
+        q = s // 4
+        parts = {"2Nx2N": [(0, 0, s, s)], "2NxN": [(0, 0, s, s // 2), (0, s // 2, s, s // 2)], "Nx2N": [(0, 0, s // 2, s), (s // 2, 0, s // 2, s)],
+                 "2NxnU": [(0, 0, s, q), (0, q, s, s - q)], "2NxnD": [(0, 0, s, s - q), (0, s - q, s, q)],
+                 "nLx2N": [(0, 0, q, s), (q, 0, s - q, s)], "nRx2N": [(0, 0, s - q, s), (s - q, 0, q, s)]}[m]
+        for (dx, dy, pw, ph) in parts:
+            pus.append((x + dx, y + dy, pw, ph))
+
+    def walk(x, y, s, depth):
+        if x >= w or y >= h:
+            return
+        must = x + s > w or y + s > h
+        if s > 8 and (must or rng.random() < split[min(depth, len(split) - 1)]):
+            for (dx, dy) in ((0, 0), (s // 2, 0), (0, s // 2), (s // 2, s // 2)):
+                walk(x + dx, y + dy, s // 2, depth + 1)
+        else:
+            cu(x, y, s)
+
+    for cy in range(0, h, 64):
+        for cx in range(0, w, 64):
+            walk(cx, cy, 64, 0)
+    return pus
+
+
+def pred_frame_case(w, h, seed, bi=False, border=80, kind="noise", chroma=True):
+    """One 4:2:0 frame's motion compensation as RUNS for hevcasm_hip_pred_uni_8to8_runs / _bi_: luma (8 taps, quarter-pel) on plane 0, Cb and Cr (4 taps,
+    eighth-pel, the same entries) on planes 1 and 2; PUs sorted by (plane, size).  Integer vectors in +-8 luma samples, all fractional phases.
+    Keys: planes = [dict(stride_dst, dst_bytes, stride_ref, ref0, ref1)], runs (PRED_RUN_DTYPE), dst_off, ref0_off, ref1_off, frac0, frac1."""
+    assert w % 8 == 0 and h % 8 == 0
+    rng = np.random.default_rng(seed + 1)
+    pus = np.array(inter_partition(w, h, seed, bi=bi), dtype=np.int64)
+    nref = 2 if bi else 1
+    mv = rng.integers(-32, 33, size=(len(pus), nref, 2))      # quarter-pel units, +-8 integer samples
+    planes, runs = [], []
+    arrays = dict(dst_off=[], ref0_off=[], ref1_off=[], frac0=[], frac1=[])
+    at = 0
+    for chroma_pass in ((False, True) if chroma else (False,)):
+        sh = 1 if chroma_pass else 0
+        pw_, ph_ = w >> sh, h >> sh
+        b = border >> sh
+        stride_dst, stride_ref = pw_, pw_ + 2 * b
+        x, y, bw, bh = pus[:, 0] >> sh, pus[:, 1] >> sh, pus[:, 2] >> sh, pus[:, 3] >> sh
+        order = np.lexsort((np.arange(len(pus)), bh, bw))      # by (width, height), coding order inside a size
+        plane_ids = (1, 2) if chroma_pass else (0,)
+        for pid in plane_ids:
+            planes.append(dict(stride_dst=stride_dst, dst_bytes=stride_dst * ph_, stride_ref=stride_ref,
+                               ref0=fill_u8(stride_ref * (ph_ + 2 * b), seed + 10 + 2 * pid, kind), ref1=fill_u8(stride_ref * (ph_ + 2 * b), seed + 11 + 2 * pid, kind)))
+        arrays["dst_off"].append((y * stride_dst + x)[order])
+        for r in range(2):
+            m = mv[:, min(r, nref - 1)]
+            # luma: quarter-pel vector -> integer part m >> 2, fraction m & 3; chroma (4:2:0): the same vector in eighth-pel units of the half-size plane
+            ix, iy = (m[:, 0] >> (2 + sh)), (m[:, 1] >> (2 + sh))
+            fx, fy = (m[:, 0] & (3 if not sh else 7)), (m[:, 1] & (3 if not sh else 7))
+            arrays["ref%d_off" % r].append(((y + b + iy) * stride_ref + x + b + ix)[order])
+            arrays["frac%d" % r].append((fx | (fy << 4))[order])
+        sizes = np.stack([bw[order], bh[order]], axis=1)
+        start = 0
+        for i in range(1, len(order) + 1):
+            if i == len(order) or (sizes[i] != sizes[start]).any():
+                for pid in plane_ids:
+                    runs.append((at + start, i - start, 4 if chroma_pass else 8, sizes[start][0], sizes[start][1], pid))
+                start = i
+        at += len(order)
+    out = dict(w=w, h=h, bi=bi, planes=planes, runs=np.array(runs, dtype=PRED_RUN_DTYPE), n_pus=len(pus))
+    out["dst_off"] = np.concatenate(arrays["dst_off"]).astype(np.uint32)
+    for r in range(2):
+        out["ref%d_off" % r] = np.concatenate(arrays["ref%d_off" % r]).astype(np.uint32)
+        out["frac%d" % r] = np.concatenate(arrays["frac%d" % r]).astype(np.uint8)
+    return out

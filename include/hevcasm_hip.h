@@ -283,6 +283,32 @@ int hevcasm_hip_pred_bi_8to8_batch(
 	const uint8_t *frac0, const uint8_t *frac1,
 	int taps, int nPbW, int nPbH, size_t n_blocks, void *stream);
 
+/* ONE launch for a frame's whole partition (round 6).  A frame is never one PU size -- HEVC has 24 (pred_inter.c:438-444) on three planes -- and a launch per
+ * (size, plane) is latency, not bandwidth, at one frame per launch.  The caller lists the frame as RUNS: run i = `count` consecutive entries, from `first`, of
+ * the descriptor arrays (dst_off / ref_off / frac, as above), all of one size nPbW x nPbH, one filter (taps 8 or 4) and one plane set planes[plane]; sort the
+ * frame's PUs by (plane, size) and there are at most 72 runs.  Cb and Cr of a 4:2:0 frame are two runs over the SAME entries with different `plane`.
+ * `planes` and `runs` are HOST arrays, read during the call (they travel in the kernel arguments, 96 runs per launch; more runs = more launches, made by the
+ * call).  Per PU exactly the result of hevcasm_hip_pred_uni_8to8_batch / _bi_ with the run's geometry; memory read: the stream kernel's footprint (exactly
+ * the reference's, see above -- the 4-tap word-aligned strip form is not used here).  offsets of a run are relative to ITS plane's dst / ref pointers. */
+typedef struct
+{
+	uint8_t *dst; ptrdiff_t stride_dst;
+	const uint8_t *ref0, *ref1; ptrdiff_t stride_ref;      /* uni-prediction reads ref0 only */
+} hevcasm_hip_pred_plane;
+
+typedef struct
+{
+	uint32_t first, count;               /* descriptor entries [first, first + count) */
+	uint8_t taps, nPbW, nPbH, plane;     /* 8 | 4; PU size; index into planes[] */
+} hevcasm_hip_pred_run;
+
+int hevcasm_hip_pred_uni_8to8_runs(
+	const hevcasm_hip_pred_plane *planes, int n_planes, const hevcasm_hip_pred_run *runs, int n_runs,
+	const uint32_t *dst_off, const uint32_t *ref_off, const uint8_t *frac, void *stream);
+int hevcasm_hip_pred_bi_8to8_runs(
+	const hevcasm_hip_pred_plane *planes, int n_planes, const hevcasm_hip_pred_run *runs, int n_runs,
+	const uint32_t *dst_off, const uint32_t *ref0_off, const uint32_t *ref1_off, const uint8_t *frac0, const uint8_t *frac1, void *stream);
+
 /* ---- transforms ------------------------------------------------------------------------ */
 
 /* Batched hevcasm_inverse_transform_add (reference residual_decode.h:54; C path

@@ -162,9 +162,69 @@ def bench_pred_latency(reps=30):
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         n_all = sum(d["n"] for d in sets[0])
+        # (b') the same uniform frame through the one-launch entry point (3 runs: luma 16x16, Cb 8x8, Cr 8x8): what the run lookup and the general kernel form cost
+        def uniform_runs(i):
+            one = sets[i % 3]
+            lp, cp = one[0], one[1]
+            n_l, n_c = lp["n"], cp["n"]
+            key = "runs_arrays"
+            if key not in lp:
+                cat = lambda k: torch.cat([lp[k], cp[k]])
+                lp[key] = dict(dst_off=cat("dst_off"), ref0_off=cat("ref0_off"), frac0=cat("frac0"))
+                if bi:
+                    lp[key].update(ref1_off=cat("ref1_off"), frac1=cat("frac1"))
+                lp["runs"] = np.array([(0, n_l, 8, 16, 16, 0), (n_l, n_c, 4, 8, 8, 1), (n_l, n_c, 4, 8, 8, 2)], dtype=wl.PRED_RUN_DTYPE)
+            a = lp[key]
+            pl = [(d["dst"], d["c"]["stride_dst"], d["ref0"], d["ref1"] if bi else None, d["c"]["stride_ref"]) for d in one]
+            if bi:
+                B.pred_runs(pl, lp["runs"], a["dst_off"], a["ref0_off"], a["frac0"], ref1_off=a["ref1_off"], frac1=a["frac1"])
+            else:
+                B.pred_runs(pl, lp["runs"], a["dst_off"], a["ref0_off"], a["frac0"])
+        for i in range(3):
+            uniform_runs(i)
+        torch.cuda.synchronize()
+        report("pred_%s uniform frame, one launch" % ("bi" if bi else "uni"), n_all, sum(bytes_of(d) * d["n"] for d in sets[0]) // n_all, timed(uniform_runs, reps), size="16x16 luma + 2 x 8x8 chroma",
+               frames=1, launches=1, note="the frame of the graph row as 3 runs of hevcasm_hip_pred_*_runs: one launch, HIP events around it")
         report("pred_%s frame graph" % ("bi" if bi else "uni"), n_all, sum(bytes_of(d) * d["n"] for d in sets[0]) // n_all, ms, size="16x16 luma + 2 x 8x8 chroma", frames=1, launches=2,
                note="one 1080p 4:2:0 frame = 2 launches (luma; Cb + Cr together) captured in one HIP graph, %d replays back to back; %.0f frames/s" % (reps, 1e3 / ms))
         del sets, graphs
+        torch.cuda.empty_cache()
+        # (c) round 6: a REAL partition -- a quad-tree over every PU size of pred_inter.c:438-444, luma + Cb + Cr -- as ONE launch (hevcasm_hip_pred_*_runs),
+        # next to what it replaces: one launch per (size, plane), issued back to back.  Three frames rotate, as above.
+        frames3 = []
+        for k in range(3):
+            c = wl.pred_frame_case(1920, 1080, 900 + k, bi=bi)
+            dev_planes = [(torch.zeros(p["dst_bytes"], dtype=torch.uint8, device="cuda"), p["stride_dst"], B.u8(p["ref0"]), B.u8(p["ref1"]) if bi else None, p["stride_ref"]) for p in c["planes"]]
+            arrays = dict(dst_off=B.off32(c["dst_off"]), ref0_off=B.off32(c["ref0_off"]), frac0=B.u8(c["frac0"]), ref1_off=B.off32(c["ref1_off"]), frac1=B.u8(c["frac1"]))
+            frames3.append((c, dev_planes, arrays))
+
+        def one_launch(i):
+            c, dev_planes, a = frames3[i % 3]
+            if bi:
+                B.pred_runs(dev_planes, c["runs"], a["dst_off"], a["ref0_off"], a["frac0"], ref1_off=a["ref1_off"], frac1=a["frac1"])
+            else:
+                B.pred_runs(dev_planes, c["runs"], a["dst_off"], a["ref0_off"], a["frac0"])
+
+        def per_run_launches(i):
+            c, dev_planes, a = frames3[i % 3]
+            for r in c["runs"]:
+                dst, sd, r0, r1, sr = dev_planes[int(r["plane"])]
+                s = slice(int(r["first"]), int(r["first"]) + int(r["count"]))
+                if bi:
+                    B.pred_bi(dst, sd, r0, r1, sr, a["dst_off"][s], a["ref0_off"][s], a["ref1_off"][s], a["frac0"][s], a["frac1"][s], int(r["taps"]), int(r["w"]), int(r["h"]))
+                else:
+                    B.pred_uni(dst, sd, r0, sr, a["dst_off"][s], a["ref0_off"][s], a["frac0"][s], int(r["taps"]), int(r["w"]), int(r["h"]))
+
+        c0 = frames3[0][0]
+        bytes_frame = sum(int(r["count"]) * (refs * (int(r["w"]) + int(r["taps"]) - 1) * (int(r["h"]) + int(r["taps"]) - 1) + int(r["w"]) * int(r["h"]) + 4 * (1 + refs) + refs) for r in c0["runs"])
+        n_pus = int(sum(int(r["count"]) for r in c0["runs"]))
+        for name, fn, launches in (("frame partition, one launch", one_launch, 1), ("frame partition, a launch per (size, plane)", per_run_launches, len(c0["runs"]))):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            report("pred_%s %s" % ("bi" if bi else "uni", name), n_pus, bytes_frame // n_pus, timed(fn, reps), size="%d sizes x 3 planes" % (len(c0["runs"]) // 3), frames=1, launches=launches,
+                   note="one 1080p 4:2:0 frame cut by a random quad-tree into PUs of every size, all three planes; HIP events around the frame")
+        del frames3
         torch.cuda.empty_cache()
 
 
