@@ -801,32 +801,48 @@ def qsad_peak():
         return NOMINAL_QSAD_TBYTEDIFFS, "nominal quarter rate: 16 byte differences per lane per 16 cycles, 256 CUs x 4 SIMDs x 64 lanes at 2.4 GHz"
 
 
-PATTERN_KEYS = {"luma16_uni": "pred_uni_luma16", "luma16_bi": "pred_bi_luma16", "chroma8_uni": "pred_uni_chroma8", "chroma8_bi": "pred_bi_chroma8",
-                "idct16_2p28": "idct16_2p28", "idct32_2p28": "idct32_2p28"}
-PATTERN_PROBES = ("ubench_pred_mix", "ubench_transform_mix")
+PATTERN_KEYS = {"idct16_2p28": "idct16_2p28", "idct32_2p28": "idct32_2p28"}
+PATTERN_PROBES = ("ubench_transform_mix",)
+
+
+PATTERN_ROWS = {("pred_uni_8tap", "16x16"): "pred_uni_luma16", ("pred_bi_8tap", "16x16"): "pred_bi_luma16",
+                ("pred_uni_4tap Cb+Cr", "8x8"): "pred_uni_chroma8", ("pred_bi_4tap Cb+Cr", "8x8"): "pred_bi_chroma8"}
 
 
 def pred_pattern_ms():
-    """{family key: ms} -- the loads and stores of the four 64-frame prediction rows and of the two 2^28-coefficient inverse-transform rows WITHOUT
-    arithmetic (hevcasm_amd/lib/ubench_pred_mix live, ubench_transform_mix live = tools/ubench/pred_mix.hip, transform_mix.hip: same tilings, one motion
-    vector per PU, cold buffers), run NOW on this box.  The prediction kernels take about the time
-    of their access pattern alone (profiles/r04_pred_access_mix.txt): <key>_pattern_ms / <key>_vs_pattern put that next to every HBM fraction.
-    {} when the probe is absent or fails (the figures are a comment on the measurement, never part of it)."""
+    """{family key: ms} -- what the ACCESS PATTERN of a kernel alone takes, run NOW on this box.
+    Prediction (round 6): the shipped kernels themselves with their arithmetic taken out -- hevcasm_amd/lib/pattern/libhevcasm_hip.so =
+    pred_inter.hip built with -DHEVCASM_PRED_PATTERN_ONLY: every load, every point where a row is first used, every store as shipped, held to the
+    shipped kernels' occupancy -- timed by tools/bench_families.py pred16 (the same rows, the same inputs) in a child process that loads that library.
+    Such a build does strictly less than the kernel, so <key>_vs_pattern = kernel / pattern >= 1 by construction (round 5's stand-alone probe, which the
+    kernels beat by 11-26 %, was not a floor).  Inverse transforms: tools/ubench/transform_mix.hip as before.
+    {} when a probe is absent or fails (the figures are a comment on the measurement, never part of it)."""
     import subprocess
+    got = {}
     try:
         from hevcasm_amd import capi
-        got = {}
+        lib_dir = os.path.dirname(capi.LIB_PATH)
+        pattern_lib = os.path.join(lib_dir, "pattern", "libhevcasm_hip.so")
+        if os.path.exists(pattern_lib) and not os.environ.get("HEVCASM_HIP_LIB"):
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_families.py"), "pred16"], capture_output=True, text=True, timeout=300,
+                                 env=dict(os.environ, HEVCASM_HIP_LIB=pattern_lib))
+            for l in out.stdout.splitlines():
+                if l.startswith("{"):
+                    r = json.loads(l)
+                    key = PATTERN_ROWS.get((r.get("kernel"), r.get("size")))
+                    if key and 0.0 < r["ms"] < 100.0:
+                        got[key] = float(r["ms"])
         for probe in PATTERN_PROBES:
-            out = subprocess.run([os.path.join(os.path.dirname(capi.LIB_PATH), probe), "live"], capture_output=True, text=True, timeout=120)
+            out = subprocess.run([os.path.join(lib_dir, probe), "live"], capture_output=True, text=True, timeout=120)
             if out.returncode != 0:
                 continue
             for l in out.stdout.splitlines():
                 name, _, v = l.partition(" ")
-                if name in PATTERN_KEYS and 0.0 < float(v) < 100.0:
+                if name in PATTERN_KEYS and PATTERN_KEYS[name] not in got and 0.0 < float(v) < 100.0:
                     got[PATTERN_KEYS[name]] = float(v)
-        return got
     except Exception:   # noqa: BLE001 -- no probe, no GPU, nonsense output
-        return {}
+        pass
+    return got
 
 
 def measure_families():

@@ -51,6 +51,23 @@ __device__ unsigned long long *g_pred_stamps = nullptr;
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
+// -DHEVCASM_PRED_PATTERN_ONLY (make pattern -> lib/pattern/libhevcasm_hip.so; bench.py's <key>_pattern_ms): the SAME kernels with the arithmetic taken out --
+// every load (address, width, order, rows in flight), every point where a loaded row is first touched, every store (address, width) stays; the filters, the
+// cross-lane exchanges and the packing are replaced by an XOR that keeps the loaded registers alive.  What such a build takes is a floor of the shipped
+// kernel BY CONSTRUCTION (it does strictly less per wave), provided it runs at the shipped kernel's occupancy: without the filters it needs fewer registers,
+// so the four kernels the bench rows use are held to their real waves per SIMD by a dummy LDS allocation (occupancy_pad: 4 workgroups of 4 waves per CU, or 2).
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+template <int WAVES_PER_SIMD> __device__ __forceinline__ void occupancy_pad(uint32_t never_true)
+{
+	if constexpr (WAVES_PER_SIMD < 8)
+	{
+		constexpr int BYTES = 163840 / WAVES_PER_SIMD < 65536 ? 163840 / WAVES_PER_SIMD : 65536;      // floor(160 KiB / BYTES) == WAVES_PER_SIMD workgroups per CU
+		__shared__ uint8_t pad[BYTES];
+		if (never_true == 0xffffffffu) pad[threadIdx.x] = 1;      // (n_blocks is never 2^32 - 1: the allocation must stay referenced)
+	}
+}
+#endif
+
 // Filter taps (HEVC 8.5.3.3.3: luma quarter-pel, chroma eighth-pel).  Every tap fits a signed byte, so tap k of all phases is one
 // packed literal -- luma: 4 phases in a dword; chroma: 8 phases in two -- and a lane picks its phase with one v_bfe_i32: no table
 // in memory, no load (the coefficient loads used to be a second dependent memory round trip in every wave's prologue, behind the
@@ -199,6 +216,9 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	// the last lane's load was moved left to stay inside the window: move its bytes back
 	__device__ __forceinline__ void realign(uint32_t (&d)[NDW]) const
 	{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+		(void)d; return;
+#endif
 		if (NDW == 1)
 		{
 			d[0] >>= shift;
@@ -220,8 +240,12 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 #pragma unroll
 		for (int m = 0; m < NDW; ++m)
 		{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+			e[slot][m] = d[m]; o[slot][m] = d[m];
+#else
 			e[slot][m] = __builtin_amdgcn_perm(0, d[m], 0x0c020c00);   // (byte 0, byte 2) zero-extended
 			o[slot][m] = __builtin_amdgcn_perm(0, d[m], 0x0c030c01);   // (byte 1, byte 3)
+#endif
 		}
 	}
 	// vertical filter for the output row whose oldest window row sits in slot `first`
@@ -230,6 +254,11 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	// horizontal sums themselves costs a register move per output column (v_dot2c accumulates in place).  |sum| <= 88 * 255 + 32 < 2^15.
 	template <bool SEEDED> __device__ __forceinline__ void vertical(int first, uint32_t seed, uint32_t (&ve)[NX], uint32_t (&vo)[NX]) const
 	{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+#pragma unroll
+		for (int m = 0; m < NX; ++m) { ve[m] = m < NDW ? e[first % TAPS][m] ^ e[(first + TAPS - 1) % TAPS][m] : 0u; vo[m] = ve[m]; }      // oldest and newest window row: every loaded row is used
+		(void)seed; return;
+#endif
 #pragma unroll
 		for (int m = 0; m < NDW; ++m)
 		{
@@ -256,6 +285,11 @@ template <int TAPS, int NDW, int AHEAD> struct RefStream
 	// already inside: vertical()'s seed.)
 	template <bool LEAN> __device__ __forceinline__ void horizontal(uint32_t (&ve)[NX], uint32_t (&vo)[NX], int (&s)[4 * NDW]) const
 	{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+#pragma unroll
+		for (int m = 0; m < 4 * NDW; ++m) s[m] = (int)ve[m / 4];
+		(void)vo; return;
+#endif
 #pragma unroll
 		for (int m = NDW; m < NX; ++m)
 		{
@@ -319,6 +353,9 @@ __device__ __forceinline__ void pred_stream_body(
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int BEFORE = TAPS / 2 - 1;
 	constexpr int CPL = 4 * NDW;            // window / output columns per lane
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+	occupancy_pad<(TAPS == 8 && NDW == 2 && !BI && AHEAD == 16 && FAST) ? 4 : 8>(n_blocks);      // luma uni 16x16's kernel runs 4 waves per SIMD (99 registers)
+#endif
 	typedef RefStream<TAPS, NDW, AHEAD> Stream;
 	static_assert(TAPS % AHEAD == 0 || AHEAD % TAPS == 0, "the look-ahead ring and the unroll must divide one another");
 	constexpr int UNROLL = AHEAD > TAPS ? AHEAD : TAPS;     // slot indices (i % TAPS, i % AHEAD) are static after unrolling by this
@@ -467,6 +504,9 @@ __device__ __forceinline__ void pred_stream_body(
 #pragma unroll
 		for (int m = 0; m < NDW; ++m)
 		{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+			px[m] = (uint32_t)s[0][4 * m] ^ (BI ? (uint32_t)s[NREF - 1][4 * m] : 0u);
+#else
 			int t[4];
 #pragma unroll
 			for (int b = 0; b < 4; ++b)
@@ -475,6 +515,7 @@ __device__ __forceinline__ void pred_stream_body(
 			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
 			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
 			px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);   // low halves of (hi, lo)
+#endif
 		}
 		uint8_t *out = dst + (size_t)out_off;
 		if (BRANCH_FREE)
@@ -719,6 +760,12 @@ template <int AHEAD> struct StripStream4
 		const uint32_t x0 = pick(at >= 12u, d3, pick(at >= 8u, d2, pick(at >= 4u, d1, d0)));
 		const uint32_t x1 = pick(at >= 8u, d3, pick(at >= 4u, d2, d1));
 		const uint32_t x2 = pick(at >= 4u, d3, d2);
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+		e[into][0] = d0 ^ d3 ^ at; e[into][1] = d1; e[into][2] = d2;
+#pragma unroll
+		for (int m = 0; m < 3; ++m) o[into][m] = e[into][m];
+		(void)sh; return;
+#endif
 		const uint32_t w[3] = { __builtin_amdgcn_alignbit(x1, x0, sh), __builtin_amdgcn_alignbit(x2, x1, sh), __builtin_amdgcn_alignbit(d3, x2, sh) };
 #pragma unroll
 		for (int m = 0; m < 3; ++m)
@@ -746,6 +793,9 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 	}
 	constexpr int NREF = BI ? 2 : 1;
 	constexpr int TAPS = 4, UNROLL = AHEAD > TAPS ? AHEAD : TAPS;
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+	occupancy_pad<(FAST && AHEAD == 8) ? (BI ? 2 : 4) : 8>(n_blocks);      // chroma 8x8's kernels: uni 106 registers = 4 waves per SIMD, bi 177 = 2
+#endif
 	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));      // (wave-uniform: the address arithmetic that follows stays in SGPRs)
 	// row segments (round 4): a small launch of tall PUs is few, long waves -- 64 frames of 8x32 chroma PUs are 1920 waves of 32 rows, not two
@@ -823,6 +873,12 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 			st.take(i % AHEAD, (i + TAPS - 1) % TAPS);                                              // window row y + 3
 			if (LOADS && (BRANCH_FREE || y + TAPS - 1 + AHEAD < rows)) st.issue(i % AHEAD, step_ref);     // window row y + 3 + AHEAD
 			uint32_t ve[3], vo[3];
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+#pragma unroll
+			for (int m = 0; m < 8; ++m) s[r][m] = (int)(st.e[i % TAPS][m / 4] ^ st.e[(i + TAPS - 1) % TAPS][m / 4] ^ (m == 0 ? st.e[i % TAPS][2] ^ st.e[(i + TAPS - 1) % TAPS][2] : 0u));
+			(void)ve; (void)vo;
+			continue;
+#endif
 #pragma unroll
 			for (int m = 0; m < 3; ++m)
 			{
@@ -863,6 +919,9 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 #pragma unroll
 		for (int m = 0; m < 2; ++m)
 		{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+			px[m] = (uint32_t)s[0][4 * m] ^ (BI ? (uint32_t)s[NREF - 1][4 * m] : 0u);
+#else
 			int t[4];
 #pragma unroll
 			for (int q = 0; q < 4; ++q)
@@ -871,6 +930,7 @@ __global__ __launch_bounds__(kThreads) void pred_strip4_kernel(
 			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(t[0], t[1], SHIFT);
 			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(t[2], t[3], SHIFT);
 			px[m] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
+#endif
 		}
 		uint8_t *out = dst + (size_t)out_off;
 		if (stores)
@@ -993,6 +1053,9 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	int W, int H, int S /* strips per PU = W / 8 */, int PPW /* PUs per wave */, uint32_t n_blocks, ptrdiff_t plane2_dst, ptrdiff_t plane2_ref0, ptrdiff_t plane2_ref1)
 {
 	static_assert(AHEAD == 8 || AHEAD == 4, "the ring turns a whole number of times per unrolled group of 8 rows");
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+	occupancy_pad<4>(n_blocks);      // 112 registers: 4 waves per SIMD
+#endif
 	if (blockIdx.y)
 	{
 		dst += plane2_dst;
@@ -1067,6 +1130,11 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	// 8 horizontal sums of one window row
 	auto hrow = [&](const uint32_t (&d)[4], int (&h)[8])
 	{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+#pragma unroll
+		for (int x = 0; x < 8; ++x) h[x] = (int)(d[x & 3] ^ (x < 4 ? 0u : hsh + (sh8 ? 1u : 0u)));
+		return;
+#endif
 		// shift back: by 8 bytes = take the upper half (what lands above it only meets zero taps), by one byte = v_alignbyte across the four words
 		const uint32_t e0 = (sh8 ? d[2] : d[0]) ^ 0x80808080u, e1 = (sh8 ? d[3] : d[1]) ^ 0x80808080u;
 		const uint32_t e2 = d[2] ^ 0x80808080u, e3 = d[3] ^ 0x80808080u;
@@ -1107,6 +1175,11 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 	// t: this reference's second-pass sums of one row; the partner lane holds the other reference's
 	auto store_row = [&](const int (&t)[8])
 	{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+		if (stores) reinterpret_cast<U1 *>(dst + (size_t)out_off)->v = (uint32_t)(t[0] ^ t[1] ^ t[2] ^ t[3] ^ t[4] ^ t[5] ^ t[6] ^ t[7]);
+		out_off += step_dst;
+		return;
+#endif
 		int mine[4];
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
@@ -1129,8 +1202,12 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 #pragma unroll
 		for (int c = 0; c < 8; ++c)
 		{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+			odd[c] = (int)P[s0][c]; even[c] = (int)(P[s0][c] ^ P[s3][c]);
+#else
 			odd[c] = dot2_first(P[s0][c], O0);
 			even[c] = dot2(P[s3][c], E3, dot2(P[s2][c], E2, dot2(P[s1][c], E1, dot2_first(P[s0][c], E0))));
+#endif
 		}
 		store_row(even);
 		int h0[8], h1[8];
@@ -1144,8 +1221,13 @@ __global__ __launch_bounds__(kThreads) void pred_hfirst_bi8_kernel(
 #pragma unroll
 		for (int c = 0; c < 8; ++c)
 		{
+#ifdef HEVCASM_PRED_PATTERN_ONLY
+			P[s0][c] = (uint32_t)(h1[c] ^ h0[c]);
+			odd[c] ^= (int)P[s0][c];
+#else
 			P[s0][c] = __builtin_amdgcn_perm((uint32_t)h1[c], (uint32_t)h0[c], 0x05040100);
 			odd[c] = dot2(P[s0][c], O4, dot2(P[s3][c], O3, dot2(P[s2][c], O2, dot2(P[s1][c], O1, odd[c]))));
+#endif
 		}
 		store_row(odd);
 	};

@@ -51,9 +51,15 @@ def test_pattern_probe_is_a_comment_on_the_measurement():
     without the probe it is empty and the line goes out without those keys.  Its keys name rows the flattened record has."""
     got = bench.pred_pattern_ms()
     assert isinstance(got, dict) and all(isinstance(v, float) and v > 0 for v in got.values())
-    assert set(bench.PATTERN_KEYS.values()) <= set(bench.FAMILY_KEYS.values())
-    for probe in bench.PATTERN_PROBES:
+    assert set(bench.PATTERN_KEYS.values()) | set(bench.PATTERN_ROWS.values()) <= set(bench.FAMILY_KEYS.values())
+    assert set(bench.PATTERN_ROWS.values()) == set(bench.PATTERN_HEADLINES)
+    for probe in bench.PATTERN_PROBES + ("pattern/libhevcasm_hip.so",):
         assert os.path.exists(os.path.join(ROOT, "hevcasm_amd", "lib", probe)), "built by hevcasm_amd/csrc/Makefile (__graft_entry__.build())"
+    # round 6: the prediction floor is the shipped kernels without their arithmetic -- the same exports as the library proper, a different pred_inter object
+    import subprocess
+    nm = lambda p: {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", p], capture_output=True, text=True, check=True).stdout.splitlines() if " T " in l}
+    lib = os.path.join(ROOT, "hevcasm_amd", "lib")
+    assert nm(os.path.join(lib, "pattern", "libhevcasm_hip.so")) == nm(os.path.join(lib, "libhevcasm_hip.so"))
 
 
 def test_gather_without_a_process_group_is_the_identity():
@@ -132,7 +138,7 @@ def _canned_full_record(nan=False):
     """A full record shaped as bench.main() builds it: 40 detail rows, the per-family rows, ~170 flattened roofline keys, both CPU columns."""
     rows = _canned_family_rows()
     flat = bench.flatten_families(rows)
-    for k in bench.PATTERN_KEYS.values():
+    for k in list(bench.PATTERN_KEYS.values()) + list(bench.PATTERN_ROWS.values()):
         flat[k + "_pattern_ms"] = 0.09
         flat[k + "_vs_pattern"] = 0.93
     detail = [dict(kernel="sad_multiref_4" if ways == 4 else "sad", size="%dx%d" % (w, h), ms_per_pass=0.7561, launches_per_pass=1, mblocks_per_s=1386.7,

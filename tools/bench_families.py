@@ -465,6 +465,9 @@ if __name__ == "__main__":
     what = sys.argv[1:] or ["quant", "transform", "pred", "satd", "intra", "ssdlin", "me", "subpel"]
     torch.cuda.set_device(0)
     for w in what:
+        if w == "pred16":                                 # the four headline rows: luma 16x16 + chroma 8x8 (Cb + Cr), uni and bi, 64 frames (bench.py runs this on the pattern-only library)
+            bench_pred(frames=64, only=((16, 16),))
+            continue
         if w == "pred4tap":                               # chroma only, every PU size
             bench_pred(taps_only=4)
             continue
