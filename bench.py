@@ -375,7 +375,7 @@ ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic
                  "me_valu_frac", "me_frame_ms", "frac_nominal", "hbm_frac", "per_family_error")
 CPU_KEYS = ("value", "unit", "cores", "kind", "sample", "value_1core", "simd_value", "simd_value_1core", "simd_cores", "gpu_multiple", "checked_ctus", "mismatches", "simd_error", "family_error")
 CONFIG_KEYS = ("workload", "blocks_per_step_per_gpu", "launches_per_step", "parallelism", "frame", "step_ms_median", "step_ms_min", "library", "library_sha256",
-               "me_split", "ctus_per_rank", "slowest_rank_ms", "rank0_kernel_ms", "frames_per_s", "gsad_evals_per_s")
+               "frames", "predicted_slowest_rank_ms_at_8_gpus", "me_split", "ctus_per_rank", "slowest_rank_ms", "rank0_kernel_ms", "frames_per_s", "gsad_evals_per_s")
 
 
 def _finite(v):
@@ -533,6 +533,7 @@ def main():
     ap.add_argument("--no-families", action="store_true", help="skip the per-family measurements (inter prediction, transforms, full search) after the timed region")
     ap.add_argument("--me-split", default="ctus", choices=("rows", "ctus"), help="me5: ranks own raster runs of CTUs balanced to one CTU (default; each still holds whole CTU rows + halo), or whole CTU rows")
     ap.add_argument("--workload", default="sad", choices=("sad", "me5"), help="sad = BASELINE.json configs[1] (the metric's configuration); me5 = configs[4], full search sharded by CTU rows")
+    ap.add_argument("--frames", type=int, default=1, help="me5: consecutive frames per step, each rank's slab of every one of them searched in ONE launch (1 = the config literally: strong scaling of a 1.1 ms frame)")
     ap.add_argument("--plumbing", default=None, metavar="RECORD.json", help="TEST ONLY (tests/test_bench_plumbing.py): no GPU, no measurement -- the launcher / rank / "
                     "barrier / emit path alone, emitting the given full record with n_gpus = the ranks that met")
     ap.add_argument("--full-out", default=None, help="where the full record goes (default gpurun_out/bench_last.json, untracked)")
@@ -926,27 +927,30 @@ def bench_me5(args, rank, world, device):
     else:
         first, last = shard.ctu_range(rows * cols, rank, world)
         row0, row1 = shard.rows_of_ctus(first, last, cols)
-    # a few distinct frame pairs, rotated over the steps; every rank builds the same frames from the seed and keeps only its slab
-    # (the rows its CTUs lie in + reference rows with the halo) -- its H2D copy is the slab, never the frame
+    # a few distinct groups of F frame pairs, rotated over the steps; every rank builds the same frames from the seed and keeps only its slabs
+    # (the rows its CTUs lie in + reference rows with the halo, F of them stacked) -- its H2D copy is the slabs, never the frames
+    F = max(1, args.frames)
     n_pairs = 3
     slabs, frames0 = [], None
     for i in range(n_pairs):
-        f = me_frame.synthetic_frame_pair(fw, fh, R, seed=500 + i)
+        group = [me_frame.synthetic_frame_pair(fw, fh, R, seed=500 + i + 10 * k) for k in range(F)]
         if i == 0 and rank == 0:
-            frames0 = f
+            frames0 = group[0]
         if last > first:
-            sl = me_frame.Slab(f, ctu, R, row0, row1)
-            slabs.append(dict(slab=sl, cur=torch.from_numpy(sl.cur).to(device), ref=torch.from_numpy(sl.ref).to(device),
-                              out=torch.empty((last - first, 3), dtype=torch.int32, device=device)))
-        del f
+            st = me_frame.CtuRunStack(group, ctu, R, first, last)
+            slabs.append(dict(stack=st, cur=torch.from_numpy(st.cur).to(device), ref=torch.from_numpy(st.ref).to(device),
+                              out=torch.empty((F, last - first, 3), dtype=torch.int32, device=device)))
+        del group
     torch.cuda.synchronize()
 
     def step(i):
         if not slabs:
             return
         d = slabs[i % n_pairs]
-        sl = d["slab"]
-        B.me_full_search_frame_ctus(d["cur"], sl.cur_byte0, sl.stride_cur, d["ref"], sl.ref_byte0, sl.stride_ref, fw, fh, ctu, R, first, last - first, out=d["out"])
+        st = d["stack"]
+        sl = st.slab
+        B.me_full_search_frames_ctus(d["cur"], sl.cur_byte0, sl.stride_cur, st.pitch_cur, d["ref"], sl.ref_byte0, sl.stride_ref, st.pitch_ref, F, fw, fh, ctu, R,
+                                     first, last - first, out=d["out"])
 
     def bracket():
         if world > 1:
@@ -970,8 +974,28 @@ def bench_me5(args, rank, world, device):
     # the answers of the first frame pair, from every rank (outside the timed region)
     step(0)
     torch.cuda.synchronize()
-    part = (first, last, slabs[0]["out"].cpu().numpy() if slabs else np.zeros((0, 3), dtype=np.int32))
-    table = gather_me_results(part, fw, fh, ctu, device=device if world > 1 and dist.get_backend() == "nccl" else "cpu", unit="ctus")
+    mine = slabs[0]["out"].cpu().numpy() if slabs else np.zeros((F, 0, 3), dtype=np.int32)
+    gather_dev = device if world > 1 and dist.get_backend() == "nccl" else "cpu"
+    table = gather_me_results((first, last, mine[0]), fw, fh, ctu, device=gather_dev, unit="ctus")      # frame 0 of the group: checked against the reference below
+    # what the slowest of 8 ranks would take for its share of these F frames, measured HERE when this is a one-GPU run: the largest 8-way run (255 CTUs), F slabs, one launch
+    predicted8 = None
+    if world == 1 and slabs:
+        a8, b8 = shard.ctu_range(rows * cols, 0, 8)
+        group = [me_frame.synthetic_frame_pair(fw, fh, R, seed=500 + 10 * k) for k in range(F)]
+        st8 = me_frame.CtuRunStack(group, ctu, R, a8, b8)
+        c8, r8 = torch.from_numpy(st8.cur).to(device), torch.from_numpy(st8.ref).to(device)
+        o8 = torch.empty((F, b8 - a8, 3), dtype=torch.int32, device=device)
+        run8 = lambda: B.me_full_search_frames_ctus(c8, st8.slab.cur_byte0, st8.slab.stride_cur, st8.pitch_cur, r8, st8.slab.ref_byte0, st8.slab.stride_ref, st8.pitch_ref, F,
+                                                    fw, fh, ctu, R, a8, b8 - a8, out=o8)
+        run8(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            run8()
+        e1.record(); torch.cuda.synchronize()
+        predicted8 = e0.elapsed_time(e1) / 5
+        assert torch.equal(o8[0].cpu(), torch.from_numpy(mine[0][a8:b8])), "the 255-CTU launch of F slabs disagrees with the whole-frame launch"
+        del group, st8, c8, r8, o8
 
     exit_code = 0
     if rank == 0:
@@ -987,8 +1011,8 @@ def bench_me5(args, rank, world, device):
         cpu = None
         if args.cpu_seconds > 0:
             cpu = me_cpu_baseline(frames0, table, ctu, R, min(args.cpu_seconds, 12.0), args.cpu_procs)
-        value = n_ctus * args.steps / elapsed / 1e6
-        achieved = my_diffs / (kernel_ms * 1e-3) / 1e12
+        value = n_ctus * F * args.steps / elapsed / 1e6
+        achieved = my_diffs * F / (kernel_ms * 1e-3) / 1e12
         checked = (cpu or {}).get("checked_ctus")
         mismatches = (cpu or {}).get("mismatches")
         line = {
@@ -998,17 +1022,18 @@ def bench_me5(args, rank, world, device):
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             # valid: the GPU's answers equal the reference's on every CTU checked; null when the check did not run (no refdrv, --cpu-seconds 0)
             "valid": None if checked is None else mismatches == 0,
-            "config": {"workload": "configs[4]: full search +-64, 3840x2160 frame/step = 2040 CTUs (33 rows 64x64 + one 64x48); block = CTU",
+            "config": {"workload": "configs[4]: full search +-64, %d x 3840x2160 frame/step = %d CTUs (33 rows 64x64 + one 64x48 each); block = CTU" % (F, F * n_ctus),
+                       "frames": F, "predicted_slowest_rank_ms_at_8_gpus": round(predicted8, 4) if predicted8 else None,
                        "parallelism": "%s split x%d, rows + 64-row halo per rank, no collective" % ("CTU rows" if args.me_split == "rows" else "CTU runs", world),
                        "me_split": args.me_split, "ctus_per_rank": last - first, "rank0_first_ctu": first, "rank0_rows": "%d..%d" % (row0, row1),
                        "slowest_rank_ms": round(elapsed / args.steps * 1e3, 4), "rank0_kernel_ms": round(kernel_ms, 4),
-                       "frames_per_s": round(args.steps / elapsed, 1), "gsad_evals_per_s": round(sad_evals * args.steps / elapsed / 1e9, 2), **library_record()},
+                       "frames_per_s": round(F * args.steps / elapsed, 1), "gsad_evals_per_s": round(sad_evals * F * args.steps / elapsed / 1e9, 2), **library_record()},
             "roofline": {"bound": "valu", "kernel": "me_full_search_kernel<frame>", "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "unit": "T byte differences/s", "frac": round(achieved / peak, 4), "traffic": None,
                          "frac_nominal": round(achieved / NOMINAL_QSAD_TBYTEDIFFS, 4), "peak_nominal": round(NOMINAL_QSAD_TBYTEDIFFS, 1),
                          "avg_launch_ms": round(kernel_ms, 4), "peak_source": peak_src[:118],
-                         "hbm_algorithmic_bytes_per_frame": alg_bytes, "hbm_gbs": round(alg_bytes * args.steps / elapsed / 1e9, 1),
-                         "hbm_frac": round(alg_bytes * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+                         "hbm_algorithmic_bytes_per_frame": alg_bytes, "hbm_gbs": round(alg_bytes * F * args.steps / elapsed / 1e9, 1),
+                         "hbm_frac": round(alg_bytes * F * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                          "note": "bound by the v_qsad_pk_u16_u8 issue rate, not HBM (1.7 k byte differences per byte fetched); rank 0's launches"},
             "cpu_baseline": cpu,
         }

@@ -205,6 +205,15 @@ def me_full_search_frame_ctus(cur, cur_byte0, stride_cur, ref, ref_byte0, stride
     return out
 
 
+def me_full_search_frames_ctus(cur, cur_byte0, stride_cur, pitch_cur, ref, ref_byte0, stride_ref, pitch_ref, n_frames, frame_w, frame_h, ctu, search_range, first_ctu, n_ctus, out=None):
+    """The same run of CTUs in n_frames slabs (pitch bytes apart in both tensors) in ONE launch -> int32 [n_frames, n_ctus, 3]."""
+    out = torch.empty((n_frames, n_ctus, 3), dtype=torch.int32, device=cur.device) if out is None else out
+    check(lib().hevcasm_hip_me_full_search_frames_ctus(cur.data_ptr() + cur_byte0, stride_cur, pitch_cur, ref.data_ptr() + ref_byte0, stride_ref, pitch_ref, n_frames,
+                                                       frame_w, frame_h, ctu, search_range, first_ctu, n_ctus, out.data_ptr(), _stream()),
+          "me_full_search_frames_ctus")
+    return out
+
+
 def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metric=0, out=None):
     """Fused quarter-pel refinement: out[i] = (qx, qy, cost) of the best of the 49 displacements."""
     n = src_off.numel()

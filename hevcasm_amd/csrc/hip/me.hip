@@ -22,7 +22,14 @@ namespace hevc {
 // is rows of a CTU grid -- block i is CTU (i / cols, i % cols) of a slab whose first pixel both planes point at, CTUs
 // cut off by the frame's right / bottom edge are narrower / shorter (a 2160-row frame ends in a row of 64x48 CTUs) --
 // one launch for a whole frame or for one rank's rows of it, no descriptor arrays at all.
-struct MeFrame { int cols, ctu, frame_w, slab_h, first; };    // first: the launch's first CTU, counted in raster order from column 0 of the slab's first CTU row
+struct MeFrame
+{
+	int cols, ctu, frame_w, slab_h, first;      // first: the launch's first CTU, counted in raster order from column 0 of the slab's first CTU row
+	// round 6: gridDim.y slabs of the same geometry (consecutive frames, one rank's rows of each) in ONE launch: slab f lies f * pitch bytes further on in both
+	// planes and owns results [f * per_frame, (f + 1) * per_frame)
+	ptrdiff_t pitch_src, pitch_ref;
+	uint32_t per_frame;
+};
 
 // the 8-byte-aligned 8 bytes inside block k's 12-byte result slot: its first 8 bytes or its last 8, whichever the ADDRESS makes aligned
 // (result itself need only be int-aligned)
@@ -52,6 +59,9 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	const uint8_t *sp, *rp0;
 	if (FRAME)
 	{
+		src += (ptrdiff_t)blockIdx.y * fr.pitch_src;
+		ref += (ptrdiff_t)blockIdx.y * fr.pitch_ref;
+		result += 3 * (size_t)blockIdx.y * fr.per_frame;
 		const int g = fr.first + (int)blk;
 		const int row = g / fr.cols, col = g - row * fr.cols;
 		W = W64 ? 64 : min(fr.ctu, fr.frame_w - col * fr.ctu);
@@ -326,23 +336,23 @@ static int me_parts(size_t n_blocks, int W, int H, int range)
 // launches the search (and, with several workgroups per block, the preset of the key slots before it and their decoding after it)
 template <bool FRAME>
 static int me_launch(const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref, const uint32_t *src_off, const uint32_t *ref_off,
-		int *result, int W, int H, int range, bool w64, size_t n_blocks, const MeFrame &fr, hipStream_t st)
+		int *result, int W, int H, int range, bool w64, size_t n_blocks, const MeFrame &fr, hipStream_t st, size_t n_frames = 1)
 {
 	int win_stride;
 	// the domain does not depend on the batch: a window must fit LDS whole, whether or not this launch cuts it into parts
 	const size_t lds_whole = me_lds_bytes(W, H, range, H + 2 * range, &win_stride);
 	if (lds_whole > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
-	const int parts = me_parts(n_blocks, W, H, range);
+	const int parts = me_parts(n_blocks * n_frames, W, H, range);      // what counts is how many workgroups the LAUNCH has
 	const int per = (2 * range + 1 + parts - 1) / parts;             // candidate rows per workgroup
 	const size_t shmem = me_lds_bytes(W, H, range, H + per - 1, &win_stride);
-	if (parts > 1) HEVC_HIP_TRY(hipMemsetAsync(result, 0xff, 12 * n_blocks, st));
-	const dim3 grid((uint32_t)(n_blocks * parts));
+	if (parts > 1) HEVC_HIP_TRY(hipMemsetAsync(result, 0xff, 12 * n_blocks * n_frames, st));
+	const dim3 grid((uint32_t)(n_blocks * parts), (uint32_t)n_frames);
 	if (w64) hipLaunchKernelGGL((me_full_search_kernel<FRAME, true>), grid, dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, fr, parts);
 	else hipLaunchKernelGGL((me_full_search_kernel<FRAME, false>), grid, dim3(kThreads), shmem, st, src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, win_stride, fr, parts);
 	if (int e = launch_status("me_full_search_kernel")) return e;
 	if (parts > 1)
 	{
-		hipLaunchKernelGGL(me_decode_kernel, dim3(ceil_div(n_blocks, (size_t)kThreads)), dim3(kThreads), 0, st, result, (uint32_t)n_blocks, range);
+		hipLaunchKernelGGL(me_decode_kernel, dim3(ceil_div(n_blocks * n_frames, (size_t)kThreads)), dim3(kThreads), 0, st, result, (uint32_t)(n_blocks * n_frames), range);
 		return launch_status("me_decode_kernel");
 	}
 	return 0;
@@ -363,8 +373,7 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	return me_launch<false>(src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, W == 64, n_blocks, MeFrame{}, as_stream(stream));
 }
 
-extern "C" int hevcasm_hip_me_full_search_frame_ctus(
-	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+static int me_frames_ctus(const uint8_t *cur, ptrdiff_t stride_cur, ptrdiff_t pitch_cur, const uint8_t *ref, ptrdiff_t stride_ref, ptrdiff_t pitch_ref, size_t n_frames,
 	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream)
 {
 	if (int e = check_device()) return e;
@@ -373,14 +382,30 @@ extern "C" int hevcasm_hip_me_full_search_frame_ctus(
 	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
 	const int rows = (frame_h + ctu - 1) / ctu, cols = (frame_w + ctu - 1) / ctu;
 	if (first_ctu < 0 || n_ctus < 0 || (long long)first_ctu + n_ctus > (long long)rows * cols) return set_error(HEVCASM_HIP_EINVAL, "CTUs outside the frame");
-	if (n_ctus == 0) return 0;
+	if (n_frames > 65535) return set_error(HEVCASM_HIP_EINVAL, "at most 65535 frames per launch");
+	if ((unsigned long long)n_frames * (unsigned long long)n_ctus > 0x1fffffffull) return set_error(HEVCASM_HIP_EINVAL, "too many CTUs in one launch");
+	if (n_ctus == 0 || n_frames == 0) return 0;
 	if (!cur || !ref || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	// the planes point at column 0 of the CTU row that holds first_ctu; the slab ends with the row that holds the last CTU
 	const int row0 = first_ctu / cols, row1 = (first_ctu + n_ctus - 1) / cols + 1;
 	const int y1 = row1 * ctu < frame_h ? row1 * ctu : frame_h;
-	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu, first_ctu - row0 * cols };
+	const MeFrame fr = { cols, ctu, frame_w, y1 - row0 * ctu, first_ctu - row0 * cols, pitch_cur, pitch_ref, (uint32_t)n_ctus };
 	return me_launch<true>(cur, stride_cur, ref, stride_ref, nullptr, nullptr, result, ctu, ctu, range, ctu == 64 && frame_w % 64 == 0,
-			(size_t)n_ctus, fr, as_stream(stream));
+			(size_t)n_ctus, fr, as_stream(stream), n_frames);
+}
+
+extern "C" int hevcasm_hip_me_full_search_frame_ctus(
+	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
+	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream)
+{
+	return me_frames_ctus(cur, stride_cur, 0, ref, stride_ref, 0, 1, frame_w, frame_h, ctu, range, first_ctu, n_ctus, result, stream);
+}
+
+extern "C" int hevcasm_hip_me_full_search_frames_ctus(
+	const uint8_t *cur, ptrdiff_t stride_cur, ptrdiff_t frame_pitch_cur, const uint8_t *ref, ptrdiff_t stride_ref, ptrdiff_t frame_pitch_ref, size_t n_frames,
+	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream)
+{
+	return me_frames_ctus(cur, stride_cur, frame_pitch_cur, ref, stride_ref, frame_pitch_ref, n_frames, frame_w, frame_h, ctu, range, first_ctu, n_ctus, result, stream);
 }
 
 extern "C" int hevcasm_hip_me_full_search_frame_rows(

@@ -124,6 +124,51 @@ def hip_ctus_fn(device=None):
     return fn
 
 
+class CtuRunStack:
+    """One rank's share of F consecutive frames (round 6): the same raster run of CTUs [first, last) of each, the F slabs stacked back to back in two arrays --
+    what hevcasm_hip_me_full_search_frames_ctus takes in ONE launch (slab f lies f * pitch bytes after slab 0)."""
+
+    def __init__(self, frames, ctu, search_range, first, last):
+        self.runs = [CtuRun(f, ctu, search_range, first, last) for f in frames]
+        sl = self.runs[0].slab
+        self.first, self.last, self.n_frames = first, last, len(frames)
+        self.pitch_cur, self.pitch_ref = sl.cur.size, sl.ref.size
+        assert all(r.slab.cur.size == self.pitch_cur and r.slab.ref.size == self.pitch_ref for r in self.runs), "the frames of a stack share one geometry"
+        self.cur = np.concatenate([r.slab.cur for r in self.runs])
+        self.ref = np.concatenate([r.slab.ref for r in self.runs])
+        self.slab = sl
+
+    @property
+    def n_ctus(self):
+        return self.last - self.first
+
+
+def hip_frames_fn(device=None):
+    """stack_fn backed by hevcasm_hip_me_full_search_frames_ctus: uploads the stack, ONE launch for the F frames -> int32 [F, n_ctus, 3]."""
+    import torch
+    from . import batch as B
+
+    def fn(stack):
+        dev = device or torch.device("cuda", torch.cuda.current_device())
+        sl = stack.slab
+        cur_d, ref_d = torch.from_numpy(stack.cur).to(dev), torch.from_numpy(stack.ref).to(dev)
+        out = B.me_full_search_frames_ctus(cur_d, sl.cur_byte0, sl.stride_cur, stack.pitch_cur, ref_d, sl.ref_byte0, sl.stride_ref, stack.pitch_ref, stack.n_frames,
+                                           sl.frame_w, sl.frame_h, sl.ctu, sl.range, stack.first, stack.n_ctus)
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    return fn
+
+
+def search_rank_ctus_frames(frames, ctu, search_range, rank, world, stack_fn):
+    """One rank's share of F frames, split by CTUs: -> (first, last, int32[F, n, 3]).  stack_fn(CtuRunStack) -> [F, n, 3]."""
+    rows, cols = -(-frames[0]["h"] // ctu), -(-frames[0]["w"] // ctu)
+    first, last = shard.ctu_range(rows * cols, rank, world)
+    if first == last:
+        return first, last, np.zeros((len(frames), 0, 3), dtype=np.int32)
+    return first, last, np.asarray(stack_fn(CtuRunStack(frames, ctu, search_range, first, last)), dtype=np.int32).reshape(len(frames), last - first, 3)
+
+
 def search_rank_ctus(frame, ctu, search_range, rank, world, run_fn):
     """One rank's share of a frame when the split is by CTUs: -> (first, last, int32[n, 3])"""
     rows, cols = -(-frame["h"] // ctu), -(-frame["w"] // ctu)

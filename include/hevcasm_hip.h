@@ -411,6 +411,14 @@ int hevcasm_hip_me_full_search_frame_ctus(
 	const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *ref, ptrdiff_t stride_ref,
 	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream);
 
+/* The same run of CTUs in n_frames slabs of identical geometry -- consecutive frames, one rank's rows of each -- in ONE launch (round 6): slab f's planes lie
+ * f * frame_pitch_cur / f * frame_pitch_ref bytes after slab 0's (any layout the caller keeps its slabs in: a stack, or whole frames with the pointers at the rank's
+ * first row), its answers are result[3 (f * n_ctus + k) ...].  A frame split over 8 GPUs leaves each launch 255 CTUs -- a quarter of the device's workgroup slots;
+ * F frames per launch give every launch F times the work at no change to what a rank holds.  Per CTU and frame exactly hevcasm_hip_me_full_search_frame_ctus. */
+int hevcasm_hip_me_full_search_frames_ctus(
+	const uint8_t *cur, ptrdiff_t stride_cur, ptrdiff_t frame_pitch_cur, const uint8_t *ref, ptrdiff_t stride_ref, ptrdiff_t frame_pitch_ref, size_t n_frames,
+	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream);
+
 /* ---- fused quarter-pel refinement ------------------------------------- */
 
 /* For each block: the 49 luma quarter-pel displacements (qx, qy) in [-3, 3]^2 around the

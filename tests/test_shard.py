@@ -177,3 +177,91 @@ def test_two_rank_gloo_me_frame_rows_and_halo():
     for p, (o, e) in zip(procs, outs):
         assert p.returncode == 0, e[-3000:]
     assert "ME_SHARD_OK 0 2" in outs[0][0]
+
+
+# ----------------------------------------------------------------------- round 6: F frames per launch (bench.py --workload me5 --frames F)
+
+def _oracle_stack_fn(stack):
+    """A rank's F slabs on the CPU: the oracle over the run of each frame, each on a private copy cut out of the STACKED arrays at the stack's pitches
+    (so a wrong pitch, or a frame reading its neighbour's rows, shows)."""
+    from hevcasm_amd import me_frame
+    from oracle import pyoracle
+    sl = stack.slab
+    out = np.zeros((stack.n_frames, stack.n_ctus, 3), dtype=np.int32)
+    for f in range(stack.n_frames):
+        cur = stack.cur[f * stack.pitch_cur:(f + 1) * stack.pitch_cur].copy()
+        ref = stack.ref[f * stack.pitch_ref:(f + 1) * stack.pitch_ref].copy()
+        full = np.zeros((sl.n_ctus, 3), dtype=np.int32)
+        for j in me_frame.ctu_jobs(sl.frame_h, sl.frame_w, sl.ctu, sl.stride_cur, sl.stride_ref, sl.pad, sl.row0, sl.row1, cur_row_base=sl.y0, ref_row_base=sl.ref_row_base):
+            full[j["index"]] = pyoracle.me_full_search(cur, sl.stride_cur, ref, sl.stride_ref, j["cur_off"], j["ref_off"], j["w"], j["h"], sl.range)
+        a = stack.first - sl.row0 * stack.runs[0].cols
+        out[f] = full[a: a + stack.n_ctus]
+    return out
+
+
+def test_me_f_frames_per_launch_split_equals_the_unsharded_search():
+    """Each rank's share of F frames as one stack (what one launch takes): every frame of every split reassembles into that frame's unsharded result."""
+    from hevcasm_amd import me_frame
+    frames = [me_frame.synthetic_frame_pair(200, 176, 32, seed=40 + i, ctu=64, max_motion=20) for i in range(3)]
+    want = [_whole_frame_oracle(f, 64, 32) for f in frames]
+    assert not np.array_equal(want[0], want[1])
+    for world in (1, 2, 3, 5, 13):
+        parts = [me_frame.search_rank_ctus_frames(frames, 64, 32, rank, world, _oracle_stack_fn) for rank in range(world)]
+        for k in range(3):
+            got = me_frame.assemble_ctus([(a, b, res[k]) for (a, b, res) in parts], 200, 176, 64)
+            assert np.array_equal(got, want[k]), (world, k)
+
+
+_ME_FRAMES_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from hevcasm_amd import me_frame
+import bench, test_shard
+
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+rank, world = dist.get_rank(), dist.get_world_size()
+frames = [me_frame.synthetic_frame_pair(192, 112, 16, seed=60 + i, ctu=64, max_motion=12) for i in range(4)]
+first, last, res = me_frame.search_rank_ctus_frames(frames, 64, 16, rank, world, test_shard._oracle_stack_fn)      # the oracle stands in for the GPU
+# bench.py's own collection, frame by frame
+tables = [bench.gather_me_results((first, last, res[k]), 192, 112, 64, unit="ctus") for k in range(4)]
+if rank == 0:
+    for k in range(4):
+        assert np.array_equal(tables[k], test_shard._whole_frame_oracle(frames[k], 64, 16)), k
+    print("ME_FRAMES_OK", first, last)
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_me_f_frames():
+    port = 33500 + os.getpid() % 2000
+    code = _ME_FRAMES_WORKER % dict(root=ROOT, port=port)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+    assert "ME_FRAMES_OK 0 3" in outs[0][0]
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_hip_f_frames_in_one_launch_equal_the_oracle_and_the_per_frame_launches():
+    """hevcasm_hip_me_full_search_frames_ctus: every split of 3 frames, each rank's F slabs in ONE launch, reassembles per frame into the unsharded oracle;
+    and a 4K-sized run of 255 CTUs x 4 frames equals the four single-frame launches (the bench's geometry, part-workgroups and their decode pass included)."""
+    import torch
+    from hevcasm_amd import batch as B, me_frame
+    frames = [me_frame.synthetic_frame_pair(200, 176, 32, seed=40 + i, ctu=64, max_motion=20) for i in range(3)]
+    want = [_whole_frame_oracle(f, 64, 32) for f in frames]
+    fn = me_frame.hip_frames_fn()
+    for world in (1, 2, 5):
+        parts = [me_frame.search_rank_ctus_frames(frames, 64, 32, rank, world, fn) for rank in range(world)]
+        for k in range(3):
+            assert np.array_equal(me_frame.assemble_ctus([(a, b, res[k]) for (a, b, res) in parts], 200, 176, 64), want[k]), (world, k)
+    big = [me_frame.synthetic_frame_pair(3840, 2160, 64, seed=70 + i) for i in range(4)]
+    st = me_frame.CtuRunStack(big, 64, 64, 255, 510)
+    many = fn(st)
+    one = me_frame.hip_ctus_fn()
+    for k in range(4):
+        assert np.array_equal(many[k], one(st.runs[k])), k
