@@ -123,23 +123,38 @@ __device__ __forceinline__ void transform_pass(const int16_t *in, int16_t *out, 
 	constexpr int P = N + 4;
 	constexpr int G = (kLanes / N) < N ? (kLanes / N) : N;      // row groups: 4x4: 4 (16 lanes busy), 8x8: 8, 16x16: 4, 32x32: 2
 	constexpr int PER = N / G;                                  // rows per lane: 1, 1, 4, 16
+	// A lane's sum is a chain of N / 2 dependent v_dot2_i32_i16, and this wave is alone on its SIMD most of the time (the kernel is a dependency chain, not a
+	// throughput loop): one chain at a time runs at the instruction's latency, not its issue rate.  So FOUR rows' sums advance together (independent chains).
+	constexpr int CH = PER < 4 ? PER : 4;
 	const int b = lane % N, g = lane / N;
 	if (g < G)
 	{
 		const int add = 1 << (shift - 1);
 #pragma unroll
-		for (int i = 0; i < PER; ++i)
+		for (int i0 = 0; i0 < PER; i0 += CH)
 		{
-			const int a = g * PER + i;
-			const uint32_t *row = reinterpret_cast<const uint32_t *>(in + a * P);
-			int acc = add;
+			int acc[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c) acc[c] = add;
 #pragma unroll
 			for (int k = 0; k < N / 2; ++k)
-				acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, row[k]), __builtin_bit_cast(i16x2, w[k]), acc, false);
-			acc >>= shift;
-			if (INVERSE) acc = clip3(-32768, 32767, acc);
-			if (TRANSPOSE_OUT) out[b * P + a] = (int16_t)acc;
-			else out[a * P + b] = (int16_t)acc;
+			{
+#pragma unroll
+				for (int c = 0; c < CH; ++c)
+				{
+					const uint32_t *row = reinterpret_cast<const uint32_t *>(in + (g * PER + i0 + c) * P);
+					acc[c] = __builtin_amdgcn_sdot2(__builtin_bit_cast(i16x2, row[k]), __builtin_bit_cast(i16x2, w[k]), acc[c], false);
+				}
+			}
+#pragma unroll
+			for (int c = 0; c < CH; ++c)
+			{
+				const int a = g * PER + i0 + c;
+				int v = acc[c] >> shift;
+				if (INVERSE) v = clip3(-32768, 32767, v);
+				if (TRANSPOSE_OUT) out[b * P + a] = (int16_t)v;
+				else out[a * P + b] = (int16_t)v;
+			}
 		}
 	}
 }
@@ -192,14 +207,13 @@ template <int N> __device__ __forceinline__ void build_neighbours(CtuLds &L, con
 		if (lane < U) { px = tx - 1; py = ty + 2 * N - 4 - 4 * lane; }
 		else if (lane == U) { px = tx - 1; py = ty - 1; }
 		else { px = tx + 4 * (lane - U - 1); py = ty - 1; }
+		// the samples are read whether or not they count (the reads stay inside the LDS allocation for every position a unit can have): they travel together
+		// with the availability lookup instead of waiting for it
+		if (lane < U)            // memory order of the record = search order: the lowest byte is the bottom-most row
+			val = (uint32_t)tile_at(L, px, py + 3) | ((uint32_t)tile_at(L, px, py + 2) << 8) | ((uint32_t)tile_at(L, px, py + 1) << 16) | ((uint32_t)tile_at(L, px, py) << 24);
+		else if (lane == U) val = tile_at(L, px, py);
+		else val = *reinterpret_cast<const uint32_t *>(&tile_at(L, px, py));
 		have = sample_available(L, v, px, py);
-		if (have)
-		{
-			if (lane < U)            // memory order of the record = search order: the lowest byte is the bottom-most row
-				val = (uint32_t)tile_at(L, px, py + 3) | ((uint32_t)tile_at(L, px, py + 2) << 8) | ((uint32_t)tile_at(L, px, py + 1) << 16) | ((uint32_t)tile_at(L, px, py) << 24);
-			else if (lane == U) val = tile_at(L, px, py);
-			else val = *reinterpret_cast<const uint32_t *>(&tile_at(L, px, py));
-		}
 	}
 	const unsigned long long mask = __ballot(have);
 	const unsigned long long below = mask & ((1ull << lane) - 1ull);
@@ -250,11 +264,15 @@ template <int N> __device__ __forceinline__ void smooth_neighbours(CtuLds &L, in
 	}
 }
 
+// OR over the wave, in every lane's hands as a scalar: four DPP steps inside each row of 16 lanes, then the four rows by v_readlane -- no trip through the
+// LDS crossbar (six __shfl_xor steps are six dependent ds_bpermute round trips, a tenth of a 4x4 TU's time)
 __device__ __forceinline__ int wave_or(int v)
 {
-#pragma unroll
-	for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, kLanes);
-	return v;
+	v |= __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
+	v |= __builtin_amdgcn_mov_dpp(v, 0x4e /* quad_perm [2, 3, 0, 1] */, 0xf, 0xf, true);
+	v |= __builtin_amdgcn_mov_dpp(v, 0x141 /* row_half_mirror */, 0xf, 0xf, true);
+	v |= __builtin_amdgcn_mov_dpp(v, 0x140 /* row_mirror */, 0xf, 0xf, true);
+	return __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
 }
 
 // One TU, start to finish.  (tx, ty): position inside the CTU.
@@ -265,8 +283,10 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 	constexpr int PX = IntraGeom<N>::PX, LPB = IntraGeom<N>::LPB, LOG2 = IntraGeom<N>::LOG2, P = N + 4;
 	const bool luma = A.cIdx == 0;
 
+#ifndef IF_KNOCK_NB
 	build_neighbours<N>(L, v, tx, ty, lane);
 	wave_sync();
+#endif
 	// filterFlag (8.4.4.2.3): luma, not DC, not 4x4, and far enough from the horizontal / vertical modes for the size
 	bool filter = false;
 	if (N > 4 && luma && mode != 1)
@@ -280,7 +300,11 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 		wave_sync();
 	}
 	Chunk<PX> pred;
+#ifndef IF_KNOCK_PRED
 	intra_predict_block<N, kLanes>(filter ? L.flt : L.raw, L.ref, L.ptile, lane, mode, luma && N < 32, wave_sync, pred);
+#else
+	for (int k = 0; k < PX / 4; ++k) pred.d[k] = (uint32_t)mode * 0x01010101u;
+#endif
 
 	// the lane's PX bytes sit at row r, columns c0 .. of the block (row-major position PX * lane)
 	const bool owner = lane < LPB;
@@ -306,14 +330,17 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 		load_weights<N>(L.tables, false, dst, lane % N, w);
 		wave_sync();
 		// residual_decode.c:855-892: rows of the residual with shift log2 - 1, then the transposed intermediate with shift log2 + 6
+#ifndef IF_KNOCK_FWD
 		transform_pass<N, false, true>(L.buf_a, L.buf_b, w, LOG2 - 1, lane);
 		wave_sync();
 		transform_pass<N, false, true>(L.buf_b, L.buf_a, w, LOG2 + 6, lane);
 		wave_sync();
+#endif
 	}
 
 	// quantise (encoder) or fetch (decoder) the lane's PX levels; dequantise; the dequantised coefficients go to buf_b TRANSPOSED (the inverse passes sum along rows)
 	int cbf = 0;
+#ifndef IF_KNOCK_QUANT
 	if (owner)
 	{
 		int level[PX];
@@ -328,7 +355,7 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 				int x = (b & 1) ? (int)pair >> 16 : (int)(int16_t)(pair & 0xffff);
 				const bool neg = x < 0;
 				x = neg ? -x : x;                                           // abs(-32768) = 32768 in int (quantize.c:176)
-				x = (x * q.q_scale + offset) >> q.q_shift;
+				x = (__mul24(x, q.q_scale) + offset) >> q.q_shift;               // both factors below 2^16 (quantize.c:162-168): the full-rate 24-bit multiply is exact
 				x = neg ? -x : x;
 				x = clip3(-32768, 32767, x);
 				cbf |= x;
@@ -359,20 +386,23 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 		const int dq_add = 1 << (q.dq_shift - 1);
 #pragma unroll
 		for (int b = 0; b < PX; ++b)
-			L.buf_b[(c0 + b) * P + r] = (int16_t)clip3(-32768, 32767, (level[b] * q.dq_scale + dq_add) >> q.dq_shift);
+			L.buf_b[(c0 + b) * P + r] = (int16_t)clip3(-32768, 32767, (__mul24(level[b], q.dq_scale) + dq_add) >> q.dq_shift);      // int16 x int16: exact in 24-bit factors
 	}
 	if (encode && cbf_out)
 	{
 		cbf = wave_or(cbf);
 		if (lane == 0) *cbf_out = cbf;
 	}
+#endif
 	load_weights<N>(L.tables, true, dst, lane % N, w);
 	wave_sync();
 	// residual_decode.c:371-413: columns of the coefficients with shift 7 (clipped, stored transposed), then the same with shift 12
+#ifndef IF_KNOCK_INV
 	transform_pass<N, true, true>(L.buf_b, L.buf_a, w, 7, lane);
 	wave_sync();
 	transform_pass<N, true, false>(L.buf_a, L.buf_b, w, 12, lane);
 	wave_sync();
+#endif
 
 	if (owner)
 	{
@@ -639,8 +669,8 @@ extern "C" int hevcasm_hip_intra_reconstruct_frames(
 	HEVC_HIP_TRY(hipMemsetAsync(ws, 0, w.order, st));      // ticket counter, status, abort word and every granule's tag: zero before every launch
 	hipLaunchKernelGGL(intra_frames_order_kernel, dim3(ceil_div(w.n_items, 256)), dim3(256), 0, st, a.order, w.cols, w.rows, a.n_frames);
 	if (int e = launch_status("intra_frames_order_kernel")) return e;
-	// single-wave workgroups, ~27 KiB of LDS each: up to five per CU; any grid size is correct (tickets), more than the work is pointless
-	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * 5);
+	// single-wave workgroups, 24.4 KiB of LDS each: six per CU; any grid size is correct (tickets), more than the work is pointless
+	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * 6);
 	hipLaunchKernelGGL(intra_frames_kernel, dim3(grid), dim3(kLanes), 0, st, a);
 	return launch_status("intra_frames_kernel");
 }

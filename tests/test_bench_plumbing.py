@@ -74,8 +74,12 @@ def _canned_family_rows():
     for fam in ("inter_pred", "inter_pred_256f"):
         for k in ("pred_uni_8tap 16x16", "pred_bi_8tap 16x16", "pred_uni_4tap 8x8", "pred_bi_4tap 8x8", "pred_uni_4tap Cb+Cr 8x8", "pred_bi_4tap Cb+Cr 8x8"):
             rows.append(dict(family=fam, kernel=k, ms=0.1, mblocks_per_s=5000.0, gbs=3900.0, frac=0.49, bytes_per_block=785))
-    for k in ("pred_uni_8tap 16x16", "pred_uni_4tap 8x8", "pred_uni frame graph 16x16 luma + 2 x 8x8 chroma", "pred_bi frame graph 16x16 luma + 2 x 8x8 chroma"):
+    for k in ("pred_uni_8tap 16x16", "pred_uni_4tap 8x8", "pred_uni frame graph 16x16 luma + 2 x 8x8 chroma", "pred_bi frame graph 16x16 luma + 2 x 8x8 chroma",
+              "pred_uni frame partition, one launch 24 sizes x 3 planes", "pred_bi frame partition, one launch 22 sizes x 3 planes",
+              "pred_uni frame partition, a launch per (size, plane) 24 sizes x 3 planes", "pred_bi frame partition, a launch per (size, plane) 22 sizes x 3 planes"):
         rows.append(dict(family="inter_pred_latency", kernel=k, ms=0.015, mblocks_per_s=800.0, gbs=600.0, frac=0.08, bytes_per_block=785, note="x" * 300))
+    for k, ms in (("intra_frames 1080p x 1", 9.4), ("intra_frames 1080p x 64", 10.7)):      # round 6: whole intra frames in wavefront order
+        rows.append(dict(family="intra_frames", kernel=k, ms=ms, mblocks_per_s=2.9, gbs=0.9, frac=0.0001, bytes_per_block=320, frames=1, note="n" * 200))
     for fam, sfx in (("", ""), ("_large_launch", "")):
         for n in (8, 16, 32):
             rows.append(dict(family="idct" + fam, kernel="inverse_transform_add dct%d" % n, ms=0.06, mblocks_per_s=1000.0, gbs=4500.0, frac=0.57, bytes_per_block=4 * n * n + 8))
@@ -96,7 +100,8 @@ def test_the_record_keeps_every_family_as_scalars():
     assert "nested" not in kept and "rows" not in kept
     want = ["sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "pred_uni_chroma8_1plane", "pred_uni_chroma8_256f",
             "pred_bi_chroma8_256f", "pred_uni_luma16_256f", "idct8", "idct16", "idct32", "fused_idct8", "fused_idct16", "fused_idct32", "fdct8", "fdct16", "fdct32",
-            "idct16_2p28", "idct32_2p28", "fused_idct32_2p28", "fdct32_2p28", "pred_uni_luma16_1frame", "pred_uni_frame_graph", "pred_bi_frame_graph"]
+            "idct16_2p28", "idct32_2p28", "fused_idct32_2p28", "fdct32_2p28", "pred_uni_luma16_1frame", "pred_uni_frame_graph", "pred_bi_frame_graph",
+            "pred_uni_frame_runs", "pred_bi_frame_runs", "pred_uni_frame_72_launches", "intra_frame", "intra_frames64"]
     for k in want:
         for sfx in ("_frac", "_gbs", "_ms", "_mblocks"):
             assert isinstance(kept[k + sfx], float), k + sfx

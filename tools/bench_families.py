@@ -403,6 +403,29 @@ def bench_intra_modes(pixels=1 << 28):
         torch.cuda.empty_cache()
 
 
+def bench_intra_frames(reps=3, frames=(1, 64)):
+    """SURVEY 8f row 3, second half: whole 1080p intra frames reconstructed on the device (hevcasm_hip_intra_reconstruct_frames) -- a random quad-tree of TUs
+    4x4 ... 32x32, every mode, QP 27, strong smoothing on: one frame alone (the dependency-limited latency: cols + 2 (rows - 1) = 62 wavefront steps) and 64 frames
+    in one call (throughput: frames are independent and interleave inside every step).  Blocks = TUs; bytes per TU = (source + reconstruction + 2-byte levels
+    per pixel) + 12 of descriptor and cbf."""
+    w, h, ctu = 1920, 1080, 64
+    maps = [wl.intra_tu_map(w, h, ctu, 100 + f, modes="mixed") for f in range(4)]
+    srcs = [B.u8(wl.frame_2d(w, h, w, 7 + f)) for f in range(4)]
+    for F in frames:
+        tus = [maps[f % 4][0] for f in range(F)]
+        job = B.IntraFrames(w, h, ctu, tus, [maps[f % 4][1] for f in range(F)], wl.intra_qp(27), c_idx=0, strong=1, stride=w)
+        src = torch.cat([srcs[f % 4] for f in range(F)])
+        job.run(src)
+        torch.cuda.synchronize()
+        job.status()
+        ms = timed(lambda i: job.run(src), reps)
+        n_tus = sum(len(t) for t in tus)
+        report("intra_frames", n_tus, (4 * w * h * F + 12 * n_tus) // n_tus, ms, size="1080p x %d" % F, frames=F, ms_per_frame=round(ms / F, 4), frames_per_s=round(F / ms * 1e3, 1),
+               note="mixed quad-tree 4x4..32x32, all 35 modes, QP 27; wavefront of 62 CTU steps per frame; %s" % ("one frame alone: dependency-limited" if F == 1 else "%d independent frames in one call" % F))
+        del job, src
+        torch.cuda.empty_cache()
+
+
 def bench_ssd_linear():
     """linear SSD, 2 x 256 MiB per launch cut into runs of `size` bytes (whole-frame PSNR = sum of rows)."""
     total = 1 << 28
@@ -504,4 +527,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, predlat=bench_pred_latency, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()

@@ -55,7 +55,7 @@ def main():
             n_tus = sum(len(t) for t in tus)
             # algorithmic bytes per frame: source + reconstruction (1 byte per pixel each) + levels (2 per pixel) + 8 per TU descriptor + 4 per cbf
             bytes_alg = F * (4 * w * h) + 12 * n_tus
-            print(json.dumps(dict(family="intra_frames", map=name, decode=args.decode, frame="%dx%d" % (w, h), ctu=ctu, frames=F, tus_per_frame=n_tus // F,
+            print(json.dumps(dict(kernel="intra_frames " + name, size="F=%d" % F, family="intra_frames", map=name, decode=args.decode, frame="%dx%d" % (w, h), ctu=ctu, frames=F, tus_per_frame=n_tus // F,
                                   ms=round(ms, 4), ms_min=round(min(times), 4), ms_per_frame=round(ms / F, 4), frames_per_s=round(F / ms * 1e3, 1),
                                   mpixels_per_s=round(F * w * h / ms / 1e3, 1), wavefront_steps=steps,
                                   us_per_step=round(ms * 1e3 / steps, 2) if F == 1 else None,

@@ -1,0 +1,9 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
+timeout -k 10 300 python tools/jobs/r06_intra_first.py > gpurun_out/r06_intra_parity3.log 2>&1 || { grep -v "^ok" gpurun_out/r06_intra_parity3.log | tail -20; exit 1; }
+tail -1 gpurun_out/r06_intra_parity3.log
+timeout -k 10 400 python tools/bench_intra_frames.py --frames 1,16,64 --reps 3 | python -c "
+import sys, json
+for l in sys.stdin:
+    r = json.loads(l); print('%-16s F=%-3d ms=%8.3f ms/frame=%7.3f fps=%8.1f us/step=%s' % (r['map'], r['frames'], r['ms'], r['ms_per_frame'], r['frames_per_s'], r['us_per_step']))
+"
