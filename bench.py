@@ -509,13 +509,11 @@ def quiet_stdout():
 def relaunch_as_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher: start `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD
     (never exec: nothing here has touched the GPU, and a child is always safe), relay rank 0's one line and the exit code."""
-    import socket
     import subprocess
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # --standalone: the launcher picks its own free rendezvous port (a port chosen here by bind / close / reuse could be taken in between when several benches
+    # share a box: ADVICE round 5)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")

@@ -55,16 +55,34 @@ class HipOps:
         self.t, self.B, self.device = torch, batch, device
         self._plans = {}
 
+    MAX_PLANS = 4      # resident frames kept (the cache used to grow by one pair of device planes per frame dict, for ever)
+
     def plan(self, frame, size):
+        """Device copies of the frame's planes and its block grid, made on first use and kept while the SAME frame dict (same arrays) comes back -- what
+        capture() / replay need.  The host arrays are copied ONCE: to run the chain on new content, write into the resident planes (update()) or pass a new
+        frame dict; at most MAX_PLANS frames stay resident, the oldest goes first."""
+        if frame["w"] % size or frame["h"] % size:
+            raise ValueError("the chain tiles the frame with %dx%d blocks: %dx%d is not a multiple (uncovered pixels would stay 0 in the reconstruction and count in the SSE)"
+                             % (size, size, frame["w"], frame["h"]))
         key = (id(frame["cur"]), id(frame["ref"]), size)
         if key not in self._plans:
             cur_off, ref_base = block_grid(frame["w"], frame["h"], size, frame["stride_cur"], frame["stride_ref"], frame["pad"])
             up = lambda a: self.t.from_numpy(np.ascontiguousarray(a)).to(self.device)
+            while len(self._plans) >= self.MAX_PLANS:
+                self._plans.pop(next(iter(self._plans)))
             self._plans[key] = (frame, up(frame["cur"]), up(frame["ref"]), self.B.off32(cur_off), self.B.off32(ref_base),
                                 self.B.off32(np.zeros(1, dtype=np.uint32)))
         p = self._plans[key]
         self._zero = p[5]
         return p[1], p[2], p[3], p[4]
+
+    def update(self, frame, size, cur=None, ref=None):
+        """New content for a resident frame: copied INTO the device planes plan() made (so a captured graph replays on it)."""
+        cur_d, ref_d, _, _ = self.plan(frame, size)
+        if cur is not None:
+            cur_d.copy_(self.t.from_numpy(np.ascontiguousarray(cur)))
+        if ref is not None:
+            ref_d.copy_(self.t.from_numpy(np.ascontiguousarray(ref)))
 
     def me_full_search(self, cur, sc, ref, sr, cur_off, ref_off, w, h, search_range):
         return self.B.me_full_search(cur, sc, ref, sr, cur_off, ref_off, w, h, search_range)
