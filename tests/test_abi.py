@@ -221,6 +221,24 @@ def test_c_example_per_block_table_equals_batch_call(tmp_path):
     assert " 0 differ" in r.stdout
 
 
+def test_intra_frame_example_compiles_and_refuses_without_a_gpu(tmp_path):
+    """examples/intra_frame.c (round 6): a C codec's intra reconstruction loop through the function-pointer tables, then the same frame as one call of
+    hevcasm_hip_intra_reconstruct_frames.  Plain C against include/*.h; without a device the second half refuses (77) after the first has run."""
+    import subprocess
+    import torch
+    exe = _build_example(tmp_path, "intra_frame")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    assert subprocess.run([exe], capture_output=True).returncode == 77
+
+
+@pytest.mark.gpu
+def test_intra_frame_example_tables_equal_the_device_pipeline(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_example(tmp_path, "intra_frame")], capture_output=True, text=True)
+    assert r.returncode == 0 and " 0 of (reconstruction, levels, cbf) differ" in r.stdout, r.stdout + r.stderr
+
+
 def test_multi_gpu_example_compiles_and_refuses_without_a_gpu(tmp_path):
     """examples/multi_gpu_sad.c (one process, a thread + stream per device, contiguous block ranges, no exchange) is plain C + pthreads."""
     import subprocess
