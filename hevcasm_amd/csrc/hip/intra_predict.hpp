@@ -7,8 +7,22 @@
 
 namespace hevc {
 
-__constant__ int8_t kIntraAngle[35] = { 0, 0, 32, 26, 21, 17, 13, 9, 5, 2, 0, -2, -5, -9, -13, -17, -21, -26, -32, -26, -21, -17, -13, -9, -5, -2, 0, 2, 5, 9, 13, 17, 21, 26, 32 };
-__constant__ int16_t kIntraInvAngle[15] = { -4096, -1638, -910, -630, -482, -390, -315, -256, -315, -390, -482, -630, -910, -1638, -4096 };
+// intraPredAngle and invAngle of H.265 8.4.4.2.6 (tables 8-4, 8-5) from packed literals, no memory: with d = the mode's distance from its pure direction
+// (10 - mode for the horizontal family 2..17, mode - 26 for the vertical one 18..34; -8 .. 8) the angle is sign(d) * { 0, 2, 5, 9, 13, 17, 21, 26, 32 }[|d|]
+// and the inverse angle of a negative one -{ 4096, 1638, 910, 630, 482, 390, 315, 256 }[|d| - 1].  (Round 6: these were two __constant__ arrays -- in the
+// frame pipeline, where the mode is wave-uniform, two dependent scalar-memory loads on every TU's critical path.)
+__device__ __forceinline__ int intra_angle(int mode)
+{
+	const int d = mode < 18 ? 10 - mode : mode - 26, a = min(d < 0 ? -d : d, 8);      // (modes 0 and 1 have no angle: whatever comes out is not used)
+	const int mag = a == 8 ? 32 : (int)((0x1a15110d09050200ull >> (8 * a)) & 0xffu);
+	return d < 0 ? -mag : mag;
+}
+__device__ __forceinline__ int intra_inv_angle(int mode)      // modes 11 .. 25 (negative angles)
+{
+	const int d = mode < 18 ? 10 - mode : mode - 26, a = (d < 0 ? -d : d) - 1;      // 0 .. 7
+	const unsigned long long packed = a < 4 ? 0x0276038e06661000ull : 0x0100013b018601e2ull;      // 4096 1638 910 630 | 482 390 315 256, 16 bits each
+	return -(int)((packed >> (16 * (a & 3))) & 0xffffu);
+}
 
 typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_mad_u16(uint32_t a, uint32_t b, uint32_t c)
@@ -50,7 +64,7 @@ __device__ __forceinline__ void intra_predict_block(const uint8_t *raw, uint8_t 
 	const bool computes = STRIDE == LPB || j < LPB;
 	auto top_at = [&](int x) { return (int)raw[2 * N + x]; };          // p[x][-1]
 	auto left_at = [&](int y) { return (int)raw[2 * N - 1 - y]; };     // p[-1][y]
-	const int angle = kIntraAngle[mode];
+	const int angle = intra_angle(mode);
 	const bool vertical = mode >= 18;
 	if (mode >= 2)
 	{
@@ -81,7 +95,7 @@ __device__ __forceinline__ void intra_predict_block(const uint8_t *raw, uint8_t 
 		if (angle < 0)
 		{
 			// i < 0: the other edge projected by the inverse angle (8.4.4.2.6); entries below (N * angle) >> 5 are never read
-			const int inv = (int)kIntraInvAngle[mode - 11];
+			const int inv = intra_inv_angle(mode);
 			for (int e = j; e < N; e += STRIDE)
 			{
 				const int i = e - N;
