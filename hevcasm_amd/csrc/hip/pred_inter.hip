@@ -146,7 +146,12 @@ template <int TAPS> struct Coefs
 	static __device__ __forceinline__ int tap(int k, int f)
 	{
 		if (TAPS == 8) return __builtin_amdgcn_sbfe((int)kTaps.luma[k], (uint32_t)(8 * (f & 3)), 8u);
-		const uint32_t packed = (f & 4) ? kTaps.chroma[k & 3][1] : kTaps.chroma[k & 3][0];
+		// the word of phases 0..3 or of phases 4..7, picked by ARITHMETIC on two literals.  Written as `(f & 4) ? chroma[k][1] : chroma[k][0]` the compiler turns the
+		// select of two constant-array elements back into a LOAD from the table in constant memory indexed by f & 4 -- eight global_load_dword per reference behind the
+		// fraction byte, the very second dependent round trip of the prologue this packing was meant to remove (found in round 6: the pattern-only build issues 8 fewer
+		// loads per wave and reference, profiles/r06_pred_floor.txt).
+		const uint32_t lo = kTaps.chroma[k & 3][0], hi = kTaps.chroma[k & 3][1];
+		const uint32_t packed = lo ^ ((lo ^ hi) & (0u - (((uint32_t)f >> 2) & 1u)));
 		return __builtin_amdgcn_sbfe((int)packed, (uint32_t)(8 * (f & 3)), 8u);
 	}
 	__device__ __forceinline__ void load(int frac)
