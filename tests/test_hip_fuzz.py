@@ -202,3 +202,56 @@ def test_frame_search_and_two_plane_prediction_random_geometry():
             B.pred_uni(wb, ca["stride_dst"], rb[0], ca["stride_ref"], doff, offs[0], fr[0], taps, w, h)
         torch.cuda.synchronize()
         assert torch.equal(da, wa) and torch.equal(db, wb), ("fuzz 2 planes", taps, w, h, bi, n)
+
+
+def test_intra_frames_random_geometry_batches_and_parameters():
+    """Round 6: whole intra frames through the persistent kernel -- random frame sizes (multiples of 4, partial CTUs), the three CTU sizes, luma / chroma, random QP
+    and quad-tree shape, every mode, strong smoothing on and off, 1 ... 9 frames per call (NMUL: more), encoder then decoder on the levels just produced.  The
+    hand-offs between workgroups are exercised by every multi-CTU frame; batches of unequal frames give them uneven load."""
+    import torch
+    from hevcasm_amd import batch as B
+    from oracle import pyoracle
+    rng = np.random.default_rng(20261010 + SEED)
+    for i in range(14):
+        ctu = int(rng.choice([16, 32, 64]))
+        w, h = 4 * int(rng.integers(2, 70)), 4 * int(rng.integers(2, 50))
+        cidx, strong, qp = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 52))
+        frames = int(rng.integers(1, 10)) * NMUL
+        split = tuple([1.0 if ctu == 64 else float(rng.random())] + [float(rng.random()) for _ in range(3)])
+        cs = [cases._intra_frame_case(w, h, ctu, 9000 + 100 * i + f, "mixed" if i % 5 else "dc", qp=qp, cidx=cidx, strong=strong, split=split,
+                                      kind=["video", "noise", "flat", "max"][int(rng.integers(0, 4))]) for f in range(frames)]
+        c0 = cs[0]
+        tus = [c["tus"].view(wl.INTRA_TU_DTYPE).reshape(-1) for c in cs]
+        job = B.IntraFrames(w, h, ctu, tus, [c["ctu_first"] for c in cs], c0["qp"], c_idx=cidx, strong=strong, stride=c0["stride"])
+        job.run(torch.cat([B.u8(c["src"]) for c in cs]))
+        torch.cuda.synchronize()
+        job.status()
+        plane, per_frame = c0["stride"] * h, job.levels.numel() // frames
+        rec, lev, cbf = job.recon.cpu().numpy(), job.levels.cpu().numpy(), job.cbf.cpu().numpy()
+        t0 = 0
+        for f, c in enumerate(cs):
+            want = pyoracle.intra_reconstruct_frame(c["src"], c["stride"], None, c["tus"], c["qp"], w, h, c["stride"], ctu, cidx, strong)
+            what = "fuzz intra %dx%d ctu=%d cidx=%d qp=%d frame %d/%d" % (w, h, ctu, cidx, qp, f, frames)
+            cases.assert_same(what + " recon", (rec[f * plane:(f + 1) * plane],), (want[0],))
+            cases.assert_same(what + " levels", (lev[f * per_frame:(f + 1) * per_frame],), (want[1],))
+            cases.assert_same(what + " cbf", (cbf[t0:t0 + len(c["tus"])],), (want[2],))
+            t0 += len(c["tus"])
+        enc = job.recon.clone()
+        job.recon.zero_()
+        job.run(None)                                     # the decoder's half on the same levels
+        torch.cuda.synchronize()
+        job.status()
+        assert torch.equal(job.recon, enc), "fuzz intra: decoder != encoder's reconstruction (%dx%d ctu=%d)" % (w, h, ctu)
+
+
+def test_pred_runs_random_partitions():
+    """Round 6: a frame's inter partition in one launch -- random frame sizes (multiples of 8), uni and bi, with and without chroma, against the oracle per run."""
+    import test_pred_runs
+    from oracle import pyoracle
+    rng = np.random.default_rng(20261011 + SEED)
+    for i in range(8):
+        w, h = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 30))
+        bi, chroma = bool(rng.integers(0, 2)), bool(rng.integers(0, 4))
+        c = wl.pred_frame_case(w, h, 9500 + i, bi=bi, chroma=chroma, kind=["noise", "video", "max"][int(rng.integers(0, 3))])
+        for plane, (g, x) in enumerate(zip(test_pred_runs._run_hip(c), test_pred_runs._oracle_planes(pyoracle, c))):
+            assert np.array_equal(g, x), "fuzz pred runs %dx%d bi=%s plane %d" % (w, h, bi, plane)
