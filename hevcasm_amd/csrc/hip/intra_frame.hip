@@ -126,8 +126,7 @@ __device__ __forceinline__ void transform_pass(const int16_t *in, int16_t *out, 
 	// A lane's sum is a chain of N / 2 dependent v_dot2_i32_i16, and this wave is alone on its SIMD most of the time (the kernel is a dependency chain, not a
 	// throughput loop): one chain at a time runs at the instruction's latency, not its issue rate.  So FOUR rows' sums advance together (independent chains).
 	constexpr int CH = PER < 4 ? PER : 4;
-	const int b = lane % N, g = lane / N;
-	if (g < G)
+	const int b = lane % N, g = min(lane / N, G - 1);      // (4x4: lanes 16 .. 63 repeat group 3 -- same values to the same places, no branch)
 	{
 		const int add = 1 << (shift - 1);
 #pragma unroll
@@ -167,7 +166,7 @@ struct CtuLds
 	uint8_t tile[kTileRows * kTileStride];     // reconstruction of this CTU + the row above (x = -1 .. 95) + the column to the left
 	uint8_t srcs[64 * 64];                     // source pixels of the CTU (encoder)
 	uint8_t done[16 * 16];                     // per 4x4 cell: reconstructed
-	hevcasm_hip_intra_tu tus[kMaxCtuTus];
+	uint32_t dig[kMaxCtuTus];                  // the CTU's TUs, digested once when the list is fetched: valid << 31 | z-scan index << 16 | mode << 10 | (log2 - 2) << 8 | (ty / 4) << 4 | tx / 4
 	uint8_t raw[144], flt[144];                // compact neighbour record, and its smoothed form: [2N - 1 - y] left, [2N + x] top, [4N] corner
 	uint8_t ref[128];                          // predictor scratch (intra_predict.hpp)
 	uint8_t ptile[32 * 32];
@@ -179,15 +178,17 @@ struct CtuView
 	int x0, y0, ctu, frame_w, frame_h;         // CTU origin in the plane
 };
 
-// H.265 6.4.1 / 8.4.4.2.2 for a sample at CTU-local (px, py) as the TU now being predicted sees it
+// H.265 6.4.1 / 8.4.4.2.2 for a sample at CTU-local (px, py) as the TU now being predicted sees it.  No branches: a lone wave pays an issue slot for every
+// exec-mask instruction around a lane conditional, and this runs once per TU.
 __device__ __forceinline__ bool sample_available(const CtuLds &L, const CtuView &v, int px, int py)
 {
 	const int gx = v.x0 + px, gy = v.y0 + py;
-	if (gx < 0 || gy < 0 || gx >= v.frame_w || gy >= v.frame_h) return false;
-	if (py < 0) return true;                      // the CTU row above: the three CTUs a TU can reach into precede in the wavefront
-	if (px < 0) return py < v.ctu;                // the CTU to the left; the one below it comes later
-	if (px >= v.ctu || py >= v.ctu) return false; // to the right / below: later
-	return L.done[(py >> 2) * 16 + (px >> 2)] != 0;
+	const bool in_picture = (unsigned)gx < (unsigned)v.frame_w & (unsigned)gy < (unsigned)v.frame_h;
+	const bool above = py < 0;                                        // the CTU row above: the three CTUs a TU can reach into precede in the wavefront
+	const bool left = !above & (px < 0) & (py < v.ctu);              // the CTU to the left; the one below it comes later
+	const bool inside = !above & (px >= 0) & (px < v.ctu) & (py < v.ctu);      // to the right / below: later
+	const int cell = inside ? (py >> 2) * 16 + (px >> 2) : 0;
+	return in_picture & (above | left | (inside & (L.done[cell] != 0)));
 }
 
 __device__ __forceinline__ uint8_t &tile_at(CtuLds &L, int px, int py) { return L.tile[(py + 1) * kTileStride + px + 16]; }
@@ -201,34 +202,29 @@ template <int N> __device__ __forceinline__ void build_neighbours(CtuLds &L, con
 	constexpr int U = N / 2;
 	bool have = false;
 	uint32_t val = 0;
-	if (lane <= 2 * U)
 	{
-		int px, py;
-		if (lane < U) { px = tx - 1; py = ty + 2 * N - 4 - 4 * lane; }
-		else if (lane == U) { px = tx - 1; py = ty - 1; }
-		else { px = tx + 4 * (lane - U - 1); py = ty - 1; }
-		// the samples are read whether or not they count (the reads stay inside the LDS allocation for every position a unit can have): they travel together
-		// with the availability lookup instead of waiting for it
-		if (lane < U)            // memory order of the record = search order: the lowest byte is the bottom-most row
-			val = (uint32_t)tile_at(L, px, py + 3) | ((uint32_t)tile_at(L, px, py + 2) << 8) | ((uint32_t)tile_at(L, px, py + 1) << 16) | ((uint32_t)tile_at(L, px, py) << 24);
-		else if (lane == U) val = tile_at(L, px, py);
-		else val = *reinterpret_cast<const uint32_t *>(&tile_at(L, px, py));
-		have = sample_available(L, v, px, py);
+		// one code path for the three kinds of unit: four bytes `step` apart from `first` -- a left unit walks UP its column from its bottom-most row (memory order
+		// of the record = search order: the lowest byte is the bottom-most row), a top unit walks right, the corner repeats its byte; lanes beyond the record
+		// repeat the last unit (their result is not used).  The samples are read whether or not they count: the reads travel with the availability lookup
+		// (every position a unit can have lies inside the LDS allocation).
+		const int u = min(lane, 2 * U);
+		const bool is_left = u < U, is_corner = u == U;
+		const int px = is_left | is_corner ? tx - 1 : tx + 4 * (u - U - 1);
+		const int py = is_left ? ty + 2 * N - 4 - 4 * u : ty - 1;
+		const int first = (py + 1 + (is_left ? 3 : 0)) * kTileStride + px + 16;
+		const int step = is_left ? -kTileStride : is_corner ? 0 : 1;
+		val = (uint32_t)L.tile[first] | ((uint32_t)L.tile[first + step] << 8) | ((uint32_t)L.tile[first + 2 * step] << 16) | ((uint32_t)L.tile[first + 3 * step] << 24);
+		have = sample_available(L, v, px, py) & (lane <= 2 * U);
 	}
 	const unsigned long long mask = __ballot(have);
 	const unsigned long long below = mask & ((1ull << lane) - 1ull);
 	const int from = mask == 0 ? 0 : below ? 63 - __clzll((long long)below) : __ffsll((long long)mask) - 1;
 	const uint32_t theirs = (uint32_t)__shfl((int)val, from, kLanes);
-	if (!have)
-	{
-		uint32_t s = 128;
-		if (mask != 0) s = from == U ? (theirs & 0xffu) : below ? (theirs >> 24) : (theirs & 0xffu);
-		val = s * 0x01010101u;
-	}
+	// (selects, not branches; the corner's byte [4N] is the low byte of dword N of the record, so every unit is ONE dword store)
+	const uint32_t sub = mask == 0 ? 128u : from == U ? (theirs & 0xffu) : below ? (theirs >> 24) : (theirs & 0xffu);
+	val = have ? val : sub * 0x01010101u;
 	uint32_t *raw32 = reinterpret_cast<uint32_t *>(L.raw);
-	if (lane < U) raw32[lane] = val;
-	else if (lane == U) L.raw[4 * N] = (uint8_t)val;
-	else if (lane <= 2 * U) raw32[lane - 1] = val;
+	if (lane <= 2 * U) raw32[lane < U ? lane : lane == U ? N : lane - 1] = val;
 }
 
 // H.265 8.4.4.2.3 on the record: [1 2 1] / 4 along the run left column (bottom-up) - corner - top row, end samples kept; 32x32 with strong smoothing and two
@@ -242,30 +238,21 @@ template <int N> __device__ __forceinline__ void smooth_neighbours(CtuLds &L, in
 		const int a = corner + L.raw[2 * N + 63] - 2 * L.raw[2 * N + 31], b = corner + L.raw[2 * N - 1 - 63] - 2 * L.raw[2 * N - 1 - 31];
 		bi = abs(a) < 8 && abs(b) < 8;
 	}
-	auto s_at = [&](int i) { return (int)(i < 2 * N ? L.raw[i] : i == 2 * N ? L.raw[4 * N] : L.raw[i - 1]); };      // the run: 4N + 1 samples
-	for (int i = lane; i <= 4 * N; i += kLanes)
+	// sample i of the run (4N + 1 of them) lies at byte at(i) of the record: the corner, logically between the two edges, is stored behind them
+	auto at = [](int i) { return i < 2 * N ? i : i == 2 * N ? 4 * N : i - 1; };
+	const int end_left = L.raw[0], end_top = L.raw[4 * N - 1];
+	for (int i0 = 0; i0 <= 4 * N; i0 += kLanes)      // selects only: 1, 2 or 3 trips (8x8, 16x16, 32x32)
 	{
-		int r;
-		if (i == 0 || i == 4 * N) r = s_at(i);
-		else if (bi)
-		{
-			if (i == 2 * N) r = corner;
-			else
-			{
-				const int k = i < 2 * N ? 2 * N - 1 - i : i - 2 * N - 1;      // distance from the corner along the edge: 0 .. 62 here
-				const int end = i < 2 * N ? L.raw[0] : L.raw[4 * N - 1];
-				r = ((63 - k) * corner + (k + 1) * end + 32) >> 6;
-			}
-		}
-		else r = (s_at(i - 1) + 2 * s_at(i) + s_at(i + 1) + 2) >> 2;
-		if (i < 2 * N) L.flt[i] = (uint8_t)r;
-		else if (i == 2 * N) L.flt[4 * N] = (uint8_t)r;
-		else L.flt[i - 1] = (uint8_t)r;
+		const int i = min(i0 + lane, 4 * N), below = max(i - 1, 0), above = min(i + 1, 4 * N);
+		const int cur = L.raw[at(i)];
+		const int smooth = ((int)L.raw[at(below)] + 2 * cur + (int)L.raw[at(above)] + 2) >> 2;
+		const int k = i < 2 * N ? 2 * N - 1 - i : i - 2 * N - 1;      // distance from the corner along the edge (bi-linear form: 0 .. 62 inside an edge)
+		const int linear = ((63 - k) * corner + (k + 1) * (i < 2 * N ? end_left : end_top) + 32) >> 6;
+		const bool keep = i == 0 | i == 4 * N | (bi & (i == 2 * N));      // the two end samples always; the corner in the bi-linear form
+		L.flt[at(i)] = (uint8_t)(keep ? cur : bi ? linear : smooth);
 	}
 }
 
-// OR over the wave, in every lane's hands as a scalar: four DPP steps inside each row of 16 lanes, then the four rows by v_readlane -- no trip through the
-// LDS crossbar (six __shfl_xor steps are six dependent ds_bpermute round trips, a tenth of a 4x4 TU's time)
 __device__ __forceinline__ int wave_or(int v)
 {
 	v |= __builtin_amdgcn_mov_dpp(v, 0xb1 /* quad_perm [1, 0, 3, 2] */, 0xf, 0xf, true);
@@ -361,15 +348,26 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 				cbf |= x;
 				level[b] = x;
 			}
-			Chunk<PX> lo, hi;      // 2 PX bytes of levels: two stores of PX bytes
-#pragma unroll
-			for (int k = 0; k < PX / 4; ++k)
+			// 2 PX bytes of levels, contiguous: one store for 4x4 / 8x8 lanes (8 / 16 bytes), two of 16 bytes above
+			if constexpr (PX <= 8)
 			{
-				lo.d[k] = pack16(level[2 * k], level[2 * k + 1]);
-				hi.d[k] = pack16(level[PX / 2 + 2 * k], level[PX / 2 + 2 * k + 1]);
+				Chunk<2 * PX> both;
+#pragma unroll
+				for (int k = 0; k < PX / 2; ++k) both.d[k] = pack16(level[2 * k], level[2 * k + 1]);
+				both.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
 			}
-			lo.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
-			hi.store(reinterpret_cast<uint8_t *>(lev + r * N + c0 + PX / 2));
+			else
+			{
+				Chunk<PX> lo, hi;
+#pragma unroll
+				for (int k = 0; k < PX / 4; ++k)
+				{
+					lo.d[k] = pack16(level[2 * k], level[2 * k + 1]);
+					hi.d[k] = pack16(level[PX / 2 + 2 * k], level[PX / 2 + 2 * k + 1]);
+				}
+				lo.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
+				hi.store(reinterpret_cast<uint8_t *>(lev + r * N + c0 + PX / 2));
+			}
 		}
 		else
 		{
@@ -486,7 +484,24 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 		const uint32_t n_tus = min(last - first, (uint32_t)kMaxCtuTus);
 
 		// the CTU's TU list and source pixels: requested before the wait for the neighbours, they land meanwhile
-		for (uint32_t i = lane; i < n_tus; i += kLanes) L.tus[i] = A.tus[first + i];
+		// (each lane checks and digests its TUs here, all at once, so that the TU loop -- a chain on ONE wave -- starts a TU with one LDS read and a few bit-field extracts)
+		{
+			bool bad = false;
+			for (uint32_t i = lane; i < n_tus; i += kLanes)
+			{
+				const hevcasm_hip_intra_tu d = A.tus[first + i];
+				const int log2n = d.log2TrafoSize, mode = d.intraPredMode, tx = (int)d.x - v.x0, ty = (int)d.y - v.y0, n = 1 << (log2n & 7);
+				const bool good = log2n >= 2 && log2n <= 5 && n <= ctu && mode <= 34 && tx >= 0 && ty >= 0 && tx + n <= ctu && ty + n <= ctu && tx % n == 0 && ty % n == 0 &&
+					v.x0 + tx + n <= A.frame_w && v.y0 + ty + n <= A.frame_h;
+				const uint32_t ux = (uint32_t)tx >> 2, uy = (uint32_t)ty >> 2;
+				uint32_t z = 0;      // z-scan index of the TU's first 4x4 cell inside the CTU: where its levels lie
+#pragma unroll
+				for (int b = 0; b < 4; ++b) z |= ((ux >> b) & 1u) << (2 * b) | ((uy >> b) & 1u) << (2 * b + 1);
+				L.dig[i] = good ? (1u << 31) | (z << 16) | ((uint32_t)mode << 10) | ((uint32_t)(log2n - 2) << 8) | (uy << 4) | ux : 0u;
+				bad |= !good;
+			}
+			if (__any(bad) && lane == 0) __hip_atomic_fetch_or((gu32 *)(A.head + 1), kStatusBadTu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a malformed TU is skipped and flagged
+		}
 		if (encode)
 		{
 			const uint8_t *src = A.src + f * A.pitch_src;
@@ -549,22 +564,10 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 		int16_t *ctu_levels = A.levels + ((size_t)f * n_ctus + c) * (size_t)(ctu * ctu);
 		for (uint32_t i = 0; i < n_tus; ++i)
 		{
-			const hevcasm_hip_intra_tu d = L.tus[i];
-			const int log2n = __builtin_amdgcn_readfirstlane((int)d.log2TrafoSize), mode = __builtin_amdgcn_readfirstlane((int)d.intraPredMode);
-			const int tx = __builtin_amdgcn_readfirstlane((int)d.x) - v.x0, ty = __builtin_amdgcn_readfirstlane((int)d.y) - v.y0;
-			const int n = 1 << (log2n & 7);
-			const bool good = log2n >= 2 && log2n <= 5 && n <= ctu && mode <= 34 && tx >= 0 && ty >= 0 && tx + n <= ctu && ty + n <= ctu && tx % n == 0 && ty % n == 0 &&
-				v.x0 + tx + n <= A.frame_w && v.y0 + ty + n <= A.frame_h;
-			if (!good)
-			{
-				if (lane == 0) __hip_atomic_fetch_or((gu32 *)(A.head + 1), kStatusBadTu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				continue;
-			}
-			// z-scan index of the TU's first 4x4 cell inside the CTU
-			const uint32_t ux = (uint32_t)tx >> 2, uy = (uint32_t)ty >> 2;
-			uint32_t z = 0;
-#pragma unroll
-			for (int b = 0; b < 4; ++b) z |= ((ux >> b) & 1u) << (2 * b) | ((uy >> b) & 1u) << (2 * b + 1);
+			const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.dig[i]);
+			if (!(d >> 31)) continue;
+			const int tx = (int)(d & 15u) << 2, ty = (int)((d >> 4) & 15u) << 2, log2n = (int)((d >> 8) & 3u) + 2, mode = (int)((d >> 10) & 63u);
+			const uint32_t z = (d >> 16) & 255u;
 			int16_t *lev = ctu_levels + 16u * z;
 			int *cbf_out = A.cbf ? A.cbf + first + i : nullptr;
 			switch (log2n)
