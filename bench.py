@@ -833,14 +833,17 @@ def pred_pattern_ms():
         lib_dir = os.path.dirname(capi.LIB_PATH)
         pattern_lib = os.path.join(lib_dir, "pattern", "libhevcasm_hip.so")
         if os.path.exists(pattern_lib) and not os.environ.get("HEVCASM_HIP_LIB"):
-            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_families.py"), "pred16"], capture_output=True, text=True, timeout=300,
-                                 env=dict(os.environ, HEVCASM_HIP_LIB=pattern_lib))
-            for l in out.stdout.splitlines():
-                if l.startswith("{"):
-                    r = json.loads(l)
-                    key = PATTERN_ROWS.get((r.get("kernel"), r.get("size")))
-                    if key and 0.0 < r["ms"] < 100.0:
-                        got[key] = float(r["ms"])
+            # two runs of the child, the faster figure per row: a floor is the LEAST time the pattern takes, and a single run's median of four launches is now
+            # and then caught by something else on the box (seen once: 0.158 ms for a row that is 0.088 ms in every other run -- a "floor" above the kernel)
+            for _ in range(2):
+                out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_families.py"), "pred16"], capture_output=True, text=True, timeout=300,
+                                     env=dict(os.environ, HEVCASM_HIP_LIB=pattern_lib))
+                for l in out.stdout.splitlines():
+                    if l.startswith("{"):
+                        r = json.loads(l)
+                        key = PATTERN_ROWS.get((r.get("kernel"), r.get("size")))
+                        if key and 0.0 < r["ms"] < 100.0:
+                            got[key] = min(got.get(key, 1e9), float(r["ms"]))
         for probe in PATTERN_PROBES:
             out = subprocess.run([os.path.join(lib_dir, probe), "live"], capture_output=True, text=True, timeout=120)
             if out.returncode != 0:
