@@ -240,6 +240,9 @@ FAMILY_KEYS = {   # (family, kernel + size as bench_families reports them) -> ke
     ("inter_pred_latency", "pred_bi frame partition, one launch 22 sizes x 3 planes"): "pred_bi_frame_runs",
     ("inter_pred_latency", "pred_uni frame partition, a launch per (size, plane) 24 sizes x 3 planes"): "pred_uni_frame_72_launches",
     ("inter_pred_latency", "pred_bi frame partition, a launch per (size, plane) 22 sizes x 3 planes"): "pred_bi_frame_66_launches",
+    ("block_cost_latency", "sad frame partition, one launch 24 sizes"): "sad_frame_runs", ("block_cost_latency", "sad_multiref_4 frame partition, one launch 24 sizes"): "sad4_frame_runs",
+    ("block_cost_latency", "sad frame partition, a launch per size 24 sizes"): "sad_frame_24_launches",
+    ("block_cost_latency", "sad_multiref_4 frame partition, a launch per size 24 sizes"): "sad4_frame_24_launches",
     ("intra_frames", "intra_frames 1080p x 1"): "intra_frame", ("intra_frames", "intra_frames 1080p x 64"): "intra_frames64",
 }
 for _n in (8, 16, 32):
@@ -375,7 +378,7 @@ def cpu_family_legs(budget_s, max_procs=16, sample_pus=8100):
 
 HEADLINE_FAMILIES = ("sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "idct16", "idct32", "fused_idct32", "fdct32")
 # families whose headline is a TIME, not a fraction of the HBM peak: a frame's partition in one launch; one intra frame alone (dependency-limited) and 64 per call
-HEADLINE_MS = ("pred_uni_frame_runs", "pred_bi_frame_runs", "intra_frame", "intra_frames64")
+HEADLINE_MS = ("sad_frame_runs", "sad4_frame_runs", "pred_uni_frame_runs", "pred_bi_frame_runs", "intra_frame", "intra_frames64")
 PATTERN_HEADLINES = ("pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8")
 LINE_LIMIT = 4096
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch", "avg_launch_ms", "bytes_per_block",
@@ -881,6 +884,8 @@ def measure_families():
     collect("#3, 256 frames of 1080p per launch", lambda r: "inter_pred_256f")
     fam.bench_pred_latency()                                  # the same PUs, ONE frame per launch; and luma + Cb + Cr of a frame as one HIP graph
     collect("#3, one 1080p frame", lambda r: "inter_pred_latency")
+    fam.bench_cost_latency()                                  # the block costs of a frame's partition (24 PU sizes) in one launch, and as a launch per size
+    collect("#2's kernels, one 1080p frame's partition", lambda r: "block_cost_latency")
     fam.bench_intra_frames()                                  # whole intra frames in wavefront order, one alone and 64 per call
     collect("8f-3, 1080p intra frames", lambda r: "intra_frames")
     fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32

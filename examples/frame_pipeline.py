@@ -31,3 +31,16 @@ moved = int((np.abs(r["mv"][:, :2]).sum(axis=1) > 0).sum())
 print("%dx%d frame, %d blocks of %dx%d, search +-%d: %d blocks moved, %d with a fractional vector, %d coded (cbf), PSNR %.2f dB"
       % (w, h, r["mv"].shape[0], size, size, rng, moved, int((r["qmv"][:, :2] & 3).any(axis=1).sum()), int((r["cbf"] != 0).sum()), pipeline.psnr(int(r["frame_sse"][0]), w, h)))
 print("the chain per frame: %.3f ms launched from Python stage by stage, %.3f ms as one replayed HIP graph (%.0f frames/s)" % (eager_ms, graph_ms, 1e3 / graph_ms))
+
+# the same chain on a REAL partition: PUs of every HEVC size from a random quad-tree; prediction, the PUs' SAD and the PUs' SSD are ONE launch each
+from hevcasm_amd import workload
+pus = workload.inter_partition(w, h, 2)
+graph, results = ops.capture(frame, pus=pus, tu=size, search_range=rng)
+e0.record()
+for _ in range(20):
+    graph.replay()
+e1.record()
+r = pipeline.HipOps.to_numpy(results)
+sizes = sorted({(p[2], p[3]) for p in pus})
+print("mixed partition: %d PUs of %d sizes, %dx%d transform units: PSNR %.2f dB; prediction cost == refinement cost on %d of %d PUs; %.3f ms per frame as one HIP graph"
+      % (len(pus), len(sizes), size, size, pipeline.psnr(int(r["frame_sse"][0]), w, h), int((r["pu_sad"] == r["qmv"][:, 2]).sum()), len(pus), e0.elapsed_time(e1) / 20))

@@ -56,6 +56,21 @@ def sad_multiref(src, stride_src, ref, stride_ref, src_off, ref_off4, w, h, out=
     return out
 
 
+def cost_runs(kind, src, stride_src, ref, stride_ref, src_off, ref_off, runs, out=None):
+    """hevcasm_hip_sad_runs / _sad_multiref_runs / _ssd_runs (kind "sad" | "sad4" | "ssd"): ONE launch for the block costs of a frame's whole partition.
+    runs: numpy array of workload.COST_RUN_DTYPE (host); ref_off holds 4 offsets per block for "sad4", and the result is [n, 4]."""
+    n = src_off.numel()
+    ways = 4 if kind == "sad4" else 1
+    assert ref_off.numel() == ways * n
+    runs = np.ascontiguousarray(runs)
+    assert runs.dtype.itemsize == 12
+    if out is None:
+        out = torch.zeros((n, 4) if ways == 4 else (n,), dtype=torch.int32, device=src.device)
+    fn = {"sad": lib().hevcasm_hip_sad_runs, "sad4": lib().hevcasm_hip_sad_multiref_runs, "ssd": lib().hevcasm_hip_ssd_runs}[kind]
+    check(fn(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(), ref_off.data_ptr(), out.data_ptr(), runs.ctypes.data, len(runs), _stream()), kind + "_runs")
+    return out
+
+
 def ssd(a, stride_a, b, stride_b, a_off, b_off, w, h, out=None):
     n = a_off.numel()
     out = torch.empty(n, dtype=torch.int32, device=a.device) if out is None else out

@@ -32,6 +32,9 @@ HIP_API = {
     "hevcasm_hip_sad_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _sz, _vp]),
     "hevcasm_hip_sad_multiref_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _sz, _vp]),
     "hevcasm_hip_ssd_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _sz, _vp]),
+    "hevcasm_hip_sad_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hevcasm_hip_sad_multiref_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hevcasm_hip_ssd_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_hadamard_satd_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_pred_uni_8to8_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_bi_8to8_batch": (_i, [_vp, _pd, _vp, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),

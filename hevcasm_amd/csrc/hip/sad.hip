@@ -22,7 +22,9 @@
 
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace hevc {
 
@@ -498,16 +500,16 @@ __device__ __forceinline__ void block_cost_body(
 	}
 }
 
+// One workgroup's waves of a batch of `n_blocks` equally sized blocks; `wg` = the workgroup's index within that batch's grid.
 template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
-__global__ __launch_bounds__(kThreads) void block_cost_kernel(
+__device__ __forceinline__ void block_cost_workgroup(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
 	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
-	int *__restrict__ out, int H, uint32_t n_blocks)
+	int *__restrict__ out, int H, uint32_t n_blocks, uint32_t wg)
 {
 	typedef Tiling<W, C, R> T;
 	constexpr int BPW = T::BPW;
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
 	const uint32_t wave = __builtin_amdgcn_readfirstlane(wg * (kThreads / kWave) + (threadIdx.x >> 6));
 	const uint32_t lane = threadIdx.x & 63;
 	const uint32_t sub = Deal<W, C, R, WAYS>::sub_block(lane);
@@ -523,6 +525,74 @@ __global__ __launch_bounds__(kThreads) void block_cost_kernel(
 	const int scalar_first = -1;
 #endif
 	block_cost_body<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, lane, blk, live, scalar_first);
+}
+
+template <int W, int C, int R, int U, int WAYS, int OP, bool LOOP, bool TIGHT>
+__global__ __launch_bounds__(kThreads) void block_cost_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src,
+	const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off,
+	int *__restrict__ out, int H, uint32_t n_blocks)
+{
+	block_cost_workgroup<W, C, R, U, WAYS, OP, LOOP, TIGHT>(src, stride_src, ref, stride_ref, src_off, ref_off, out, H, n_blocks, xcd_contiguous(blockIdx.x, gridDim.x));
+}
+
+// ---- one launch for a frame's partition: runs of equally sized blocks, any of HEVC's sizes (round 6) ---------------------------------------------
+//
+// The motion search of a frame scores PUs of many sizes (HEVC: 24, pred_inter.c:438-444); a launch per size is 11 - 21 us each for data that moves in a few
+// microseconds.  As for the prediction kernels (pred_inter.hip, pred_runs_kernel) the host lists the frame as RUNS -- `count` consecutive descriptors of one
+// size -- and one launch serves them all: a workgroup finds its run by comparing its index with the runs' first workgroups (the table travels in the kernel
+// arguments) and runs the general (looping) form of the block kernel for that width: 4 rows in flight per instruction, 1 / 2 / 4 rows per lane and trip by
+// what divides the height.  The size-specialised single-trip and LDS-window variants of the one-size launches are a throughput matter; a frame is latency.
+constexpr int kMaxCostRuns = 96;
+struct CostRunDev { uint32_t wg_count, first, count; uint8_t variant, H, pad[2]; };
+struct CostRunsArgs
+{
+	const uint8_t *src, *ref;
+	ptrdiff_t stride_src, stride_ref;
+	const uint32_t *src_off, *ref_off;
+	int *out;
+	uint32_t wg_start[kMaxCostRuns];      // first workgroup of run i; unused entries hold 0xffffffff
+	CostRunDev runs[kMaxCostRuns];
+};
+
+// widths of HEVC's partitions, in the order of the variant index
+__host__ __device__ constexpr int cost_run_width(int i) { return i == 0 ? 4 : i == 1 ? 8 : i == 2 ? 12 : i == 3 ? 16 : i == 4 ? 24 : i == 5 ? 32 : i == 6 ? 48 : 64; }
+constexpr int kCostRunWidths = 8;
+
+template <int WI> constexpr int cost_run_bpw() { return Tiling<cost_run_width(WI), Plan<cost_run_width(WI)>::C, 4>::BPW; }
+constexpr int kCostRunBlocksPerWave[kCostRunWidths] = { cost_run_bpw<0>(), cost_run_bpw<1>(), cost_run_bpw<2>(), cost_run_bpw<3>(), cost_run_bpw<4>(), cost_run_bpw<5>(), cost_run_bpw<6>(), cost_run_bpw<7>() };
+
+// rows per lane and trip: 4 with one reference; 2 with four (4 would be 160 row registers in the two sets the row loop keeps: 251 VGPRs, measured)
+template <int WAYS> constexpr int kCostRunMaxRowsPerTrip = WAYS == 1 ? 4 : 2;
+
+template <int WAYS, int OP>
+__global__ __launch_bounds__(kThreads) void block_cost_runs_kernel(const CostRunsArgs a)
+{
+	uint32_t at_or_before = 0, start = 0;
+#pragma unroll
+	for (int i = 0; i < kMaxCostRuns; ++i)
+	{
+		const bool in = a.wg_start[i] <= blockIdx.x;
+		at_or_before += in ? 1u : 0u;
+		start = in ? a.wg_start[i] : start;      // starts ascend: the last one taken is the run's
+	}
+	const CostRunDev r = a.runs[at_or_before - 1];
+	const uint32_t wg = xcd_contiguous(blockIdx.x - start, r.wg_count);
+	// variant = 3 * (index of the width) + log2(rows per lane and trip)
+#define HEVC_RUN(WI, U) case 3 * WI + (U == 4 ? 2 : U == 2 ? 1 : 0): \
+		if constexpr (U <= kCostRunMaxRowsPerTrip<WAYS>) \
+			block_cost_workgroup<cost_run_width(WI), Plan<cost_run_width(WI)>::C, 4, U, WAYS, OP, true, false>(a.src, a.stride_src, a.ref, a.stride_ref, \
+				a.src_off + r.first, a.ref_off + (size_t)r.first * WAYS, a.out + (size_t)r.first * WAYS, r.H, r.count, wg); \
+		break;
+#define HEVC_RUN_W(WI) HEVC_RUN(WI, 1) HEVC_RUN(WI, 2) HEVC_RUN(WI, 4)
+	switch (r.variant)
+	{
+		HEVC_RUN_W(0) HEVC_RUN_W(1) HEVC_RUN_W(2) HEVC_RUN_W(3) HEVC_RUN_W(4) HEVC_RUN_W(5) HEVC_RUN_W(6) HEVC_RUN_W(7)
+	default: break;
+	}
+#undef HEVC_RUN_W
+#undef HEVC_RUN
 }
 
 // ---- 4-way SAD of wide blocks whose candidates lie close together: the union window goes through LDS ----------------
@@ -907,7 +977,76 @@ static int launch(const uint8_t *src, ptrdiff_t ss, const uint8_t *ref, ptrdiff_
 	return set_error(HEVCASM_HIP_EINVAL, "unsupported width");
 }
 
+// host side of the runs entry points: the run table, each run validated like a one-size call
+template <int WAYS, int OP>
+static int launch_runs(const uint8_t *src, ptrdiff_t ss, const uint8_t *ref, ptrdiff_t sr,
+		const uint32_t *so, const uint32_t *ro, int *out, const hevcasm_hip_cost_run *runs, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs || !src || !ref || !so || !ro || !out) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<CostRunDev> table;
+	table.reserve((size_t)n_runs);
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const int W = (int)(runs[i].rect >> 8), H = (int)(runs[i].rect & 0xff);
+		int wi = -1;
+		for (int j = 0; j < kCostRunWidths; ++j) if (cost_run_width(j) == W) wi = j;
+		if (wi < 0 || (runs[i].rect >> 16)) return set_error(HEVCASM_HIP_EINVAL, "run width must be one of HEVC's: 4, 8, 12, 16, 24, 32, 48, 64 (other widths: the one-size batch calls)");
+		if (H < 4 || H > 64 || (H & 3)) return set_error(HEVCASM_HIP_EINVAL, "block size must be a multiple of 4 in 4..64");
+		if ((uint64_t)runs[i].first + runs[i].count > 0xffffffffull) return set_error(HEVCASM_HIP_EINVAL, "run exceeds 2^32-1 descriptors");
+		if (runs[i].count == 0) continue;
+		CostRunDev d = {};
+		d.first = runs[i].first; d.count = runs[i].count; d.H = (uint8_t)H;
+		d.variant = (uint8_t)(3 * wi + (H % 16 == 0 && kCostRunMaxRowsPerTrip<WAYS> >= 4 ? 2 : H % 8 == 0 ? 1 : 0));
+		const uint32_t blocks_per_wg = (uint32_t)kCostRunBlocksPerWave[wi] * (kThreads / kWave);
+		d.wg_count = ceil_div((size_t)d.count, (size_t)blocks_per_wg);
+		table.push_back(d);
+	}
+	// the runs are dealt to the grid TALLEST FIRST: the launch ends when its last wave does, and a 64-row block that starts in the last generation of
+	// workgroups would be the whole tail
+	std::stable_sort(table.begin(), table.end(), [](const CostRunDev &x, const CostRunDev &y) { return x.H > y.H; });
+	for (size_t base = 0; base < table.size(); base += kMaxCostRuns)      // more runs than one table holds: the next launch
+	{
+		CostRunsArgs a = {};
+		a.src = src; a.ref = ref; a.stride_src = ss; a.stride_ref = sr; a.src_off = so; a.ref_off = ro; a.out = out;
+		uint32_t wgs = 0, used = 0;
+		for (int i = 0; i < kMaxCostRuns; ++i) a.wg_start[i] = 0xffffffffu;
+		for (size_t i = base; i < table.size() && i < base + kMaxCostRuns; ++i)
+		{
+			a.runs[used] = table[i];
+			a.wg_start[used++] = wgs;
+			wgs += table[i].wg_count;
+		}
+		hipLaunchKernelGGL((block_cost_runs_kernel<WAYS, OP>), dim3(wgs), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("block_cost_runs_kernel")) return e;
+	}
+	return 0;
+}
+
 }  // namespace hevc
+
+extern "C" int hevcasm_hip_sad_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad, const hevcasm_hip_cost_run *runs, int n_runs, void *stream)
+{
+	return hevc::launch_runs<1, hevc::OP_SAD>(src, stride_src, ref, stride_ref, src_off, ref_off, sad, runs, n_runs, stream);
+}
+
+extern "C" int hevcasm_hip_sad_multiref_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad, const hevcasm_hip_cost_run *runs, int n_runs, void *stream)
+{
+	return hevc::launch_runs<4, hevc::OP_SAD>(src, stride_src, ref, stride_ref, src_off, ref_off, sad, runs, n_runs, stream);
+}
+
+extern "C" int hevcasm_hip_ssd_runs(
+	const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB,
+	const uint32_t *offA, const uint32_t *offB, int *ssd, const hevcasm_hip_cost_run *runs, int n_runs, void *stream)
+{
+	return hevc::launch_runs<1, hevc::OP_SSD>(srcA, stride_srcA, srcB, stride_srcB, offA, offB, ssd, runs, n_runs, stream);
+}
 
 extern "C" int hevcasm_hip_sad_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,

@@ -42,6 +42,47 @@ def stages(frame, ops, size=16, search_range=8, qscale=26214, qshift=21, qoffset
     return dict(mv=mv, qmv=qmv, pred=pred, residual=residual, coeffs=coeffs, levels=levels, cbf=cbf, recon=recon, block_ssd=block_ssd, frame_sse=frame_sse)
 
 
+def partition_grid(pus, stride_cur, stride_ref, pad):
+    """A frame's prediction units [(x, y, w, h)] (hevcasm_amd.workload.inter_partition) sorted by size -> descriptor arrays in that order and the runs:
+    (cur_off, ref_base, sizes = [(w, h, first, count)], order = the sort permutation)."""
+    pus = np.asarray(pus, dtype=np.int64).reshape(-1, 4)
+    order = np.lexsort((np.arange(len(pus)), pus[:, 3], pus[:, 2]))
+    p = pus[order]
+    cur_off = (p[:, 1] * stride_cur + p[:, 0]).astype(np.uint32)
+    ref_base = ((p[:, 1] + pad) * stride_ref + p[:, 0] + pad).astype(np.uint32)
+    sizes, start = [], 0
+    for i in range(1, len(p) + 1):
+        if i == len(p) or (p[i, 2:] != p[start, 2:]).any():
+            sizes.append((int(p[start, 2]), int(p[start, 3]), start, i - start))
+            start = i
+    return cur_off, ref_base, sizes, order
+
+
+def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1):
+    """The same chain on a REAL partition (round 6): the frame cut into prediction units of many sizes (`pus`, any of the 24 of
+    pred_inter.c:438-444), transform units on a uniform tu x tu grid (HEVC's transform tree is independent of the PU boundaries inside a CU).
+    The search and the refinement take one size per call (one launch per size present); everything that follows is ONE launch per stage for the whole frame:
+    hevcasm_hip_pred_uni_8to8_runs, hevcasm_hip_sad_runs (the PUs' prediction cost -- which must be the refinement's winning cost), the transform stages on
+    the TU grid, hevcasm_hip_ssd_runs per PU.  -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
+    w, h, pad = frame["w"], frame["h"], frame["pad"]
+    sc, sr = frame["stride_cur"], frame["stride_ref"]
+    log2n = tu.bit_length() - 1
+    cur, ref, cur_off, ref_base, sizes, order, tu_off = ops.plan_partition(frame, pus, tu)
+    mv = ops.concat([ops.me_full_search(cur, sc, ref, sr, cur_off[f:f + n], ref_base[f:f + n], pw, ph, search_range) for (pw, ph, f, n) in sizes])
+    ref_int = ops.offsets_after_search(ref_base, mv, sr)
+    qmv = ops.concat([ops.subpel_refine(cur, sc, ref, sr, cur_off[f:f + n], ref_int[f:f + n], pw, ph) for (pw, ph, f, n) in sizes])
+    ref_sub, frac = ops.subpel_descriptors(ref_int, qmv, sr)
+    pred = ops.pred_uni_runs(w * h, sc, ref, sr, cur_off, ref_sub, frac, sizes)                 # every PU size, one launch
+    pu_sad = ops.cost_runs("sad", cur, sc, pred, sc, cur_off, cur_off, sizes)                   # one launch; == qmv[:, 2]
+    residual = ops.residual(cur, pred)
+    coeffs = ops.transform(residual, sc, tu_off, 0, log2n)
+    levels, cbf = ops.quantize(coeffs, qscale, qshift, qoffset, tu * tu)
+    recon = ops.dequant_inverse_transform_add(w * h, sc, pred, sc, tu_off, tu_off, levels, dqscale, dqshift, 0, log2n)
+    pu_ssd = ops.cost_runs("ssd", cur, sc, recon, sc, cur_off, cur_off, sizes)                  # one launch
+    frame_sse = ops.frame_sse(cur, sc, recon, sc, w, h)
+    return dict(mv=mv, qmv=qmv, pred=pred, pu_sad=pu_sad, residual=residual, coeffs=coeffs, levels=levels, cbf=cbf, recon=recon, pu_ssd=pu_ssd, frame_sse=frame_sse, order=order)
+
+
 def psnr(frame_sse, w, h):
     return float("inf") if frame_sse == 0 else 10.0 * np.log10(255.0 * 255.0 * w * h / float(frame_sse))
 
@@ -54,6 +95,7 @@ class HipOps:
         from . import batch
         self.t, self.B, self.device = torch, batch, device
         self._plans = {}
+        self._partitions = {}
 
     MAX_PLANS = 4      # resident frames kept (the cache used to grow by one pair of device planes per frame dict, for ever)
 
@@ -75,6 +117,33 @@ class HipOps:
         p = self._plans[key]
         self._zero = p[5]
         return p[1], p[2], p[3], p[4]
+
+    def plan_partition(self, frame, pus, tu):
+        """plan() for stages_partition: the resident planes of plan() (TU grid = the uniform blocks) + the PUs' descriptor arrays and runs, cached with them."""
+        cur, ref, tu_off, _ = self.plan(frame, tu)
+        key = (id(frame["cur"]), id(frame["ref"]), tu, "pus", id(pus))
+        if key not in self._partitions:
+            cur_off, ref_base, sizes, order = partition_grid(pus, frame["stride_cur"], frame["stride_ref"], frame["pad"])
+            from . import workload as wl
+            while len(self._partitions) >= self.MAX_PLANS:
+                self._partitions.pop(next(iter(self._partitions)))
+            self._partitions[key] = (pus, self.B.off32(cur_off), self.B.off32(ref_base), sizes, order,
+                                     np.array([(f, n, 8, pw, ph, 0) for (pw, ph, f, n) in sizes], dtype=wl.PRED_RUN_DTYPE),
+                                     np.array([(f, n, (pw << 8) | ph) for (pw, ph, f, n) in sizes], dtype=wl.COST_RUN_DTYPE))
+        p = self._partitions[key]
+        self._pred_runs, self._cost_runs = p[5], p[6]
+        return cur, ref, p[1], p[2], p[3], p[4], tu_off
+
+    def concat(self, parts):
+        return self.t.cat(parts)
+
+    def pred_uni_runs(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, sizes):
+        dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)
+        self.B.pred_runs([(dst, sd, ref, None, sr)], self._pred_runs, dst_off, ref_off, frac)
+        return dst
+
+    def cost_runs(self, kind, a, sa, b, sb, a_off, b_off, sizes):
+        return self.B.cost_runs(kind, a, sa, b, sb, a_off, b_off, self._cost_runs)
 
     def update(self, frame, size, cur=None, ref=None):
         """New content for a resident frame: copied INTO the device planes plan() made (so a captured graph replays on it)."""
@@ -121,19 +190,20 @@ class HipOps:
     def frame_sse(self, a, sa, b, sb, w, h):
         return self.B.frame_sse(a, sa, b, sb, self._zero, self._zero, w, h)
 
-    def capture(self, frame, **kw):
-        """The whole chain of `frame` as ONE HIP graph (torch.cuda.CUDAGraph: stream capture of the launches stages() issues).
+    def capture(self, frame, pus=None, **kw):
+        """The whole chain of `frame` as ONE HIP graph (torch.cuda.CUDAGraph: stream capture of the launches stages() -- with `pus`: stages_partition() -- issues).
         -> (graph, results): graph.replay() re-runs the chain on the frame's resident planes, results are the tensors it writes."""
         t = self.t
+        run = (lambda: stages(frame, self, **kw)) if pus is None else (lambda: stages_partition(frame, self, pus, **kw))
         side = t.cuda.Stream()
         side.wait_stream(t.cuda.current_stream())
         with t.cuda.stream(side):                  # warm-up on a side stream: uploads, allocator, first launches
-            stages(frame, self, **kw)
+            run()
         t.cuda.current_stream().wait_stream(side)
         t.cuda.synchronize()
         graph = t.cuda.CUDAGraph()
         with t.cuda.graph(graph):
-            results = stages(frame, self, **kw)
+            results = run()
         return graph, results
 
     @staticmethod

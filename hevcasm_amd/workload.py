@@ -388,3 +388,33 @@ def pred_frame_case(w, h, seed, bi=False, border=80, kind="noise", chroma=True):
         out["ref%d_off" % r] = np.concatenate(arrays["ref%d_off" % r]).astype(np.uint32)
         out["frac%d" % r] = np.concatenate(arrays["frac%d" % r]).astype(np.uint8)
     return out
+
+
+# the same partition for the motion search's block costs: one launch (hevcasm_hip_sad_runs / _sad_multiref_runs / _ssd_runs)
+
+COST_RUN_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("rect", "<u4")])      # = hevcasm_hip_cost_run, 12 bytes
+
+
+def cost_frame_case(w, h, seed, border=80, kind="noise", search=7):
+    """One frame's PUs (inter_partition: all 24 sizes of pred_inter.c:438-444) as RUNS for the block-cost entry points: the source plane w x h, a reference plane
+    with a `border`, per PU one candidate (ref_off) and four (ref_off4) within +-search pixels.  PUs sorted by size, coding order inside a size.
+    Keys: src, stride_src, ref, stride_ref, src_off, ref_off, ref_off4, runs (COST_RUN_DTYPE), sizes [(w, h, first, count)]."""
+    assert w % 8 == 0 and h % 8 == 0
+    rng = np.random.default_rng(seed + 3)
+    pus = np.array(inter_partition(w, h, seed), dtype=np.int64)
+    order = np.lexsort((np.arange(len(pus)), pus[:, 3], pus[:, 2]))
+    pus = pus[order]
+    stride_src, stride_ref = w, w + 2 * border
+    d = rng.integers(-search, search + 1, size=(len(pus), 4, 2))
+    src_off = pus[:, 1] * stride_src + pus[:, 0]
+    ref_off4 = (pus[:, 1, None] + border + d[:, :, 1]) * stride_ref + pus[:, 0, None] + border + d[:, :, 0]
+    runs, sizes, start = [], [], 0
+    for i in range(1, len(pus) + 1):
+        if i == len(pus) or (pus[i, 2:] != pus[start, 2:]).any():
+            pw, ph = int(pus[start, 2]), int(pus[start, 3])
+            runs.append((start, i - start, (pw << 8) | ph))
+            sizes.append((pw, ph, start, i - start))
+            start = i
+    return dict(w=w, h=h, src=fill_u8(stride_src * h, seed + 20, kind), stride_src=stride_src, ref=fill_u8(stride_ref * (h + 2 * border), seed + 21, kind), stride_ref=stride_ref,
+                src_off=src_off.astype(np.uint32), ref_off=np.ascontiguousarray(ref_off4[:, 0]).astype(np.uint32), ref_off4=np.ascontiguousarray(ref_off4).astype(np.uint32).reshape(-1),
+                runs=np.array(runs, dtype=COST_RUN_DTYPE), sizes=sizes, n_pus=len(pus))

@@ -118,6 +118,28 @@ int hevcasm_hip_ssd_batch(
 	const uint32_t *offA, const uint32_t *offB, int *ssd,
 	int w, int h, size_t n_blocks, void *stream);
 
+/* ONE launch for a frame's whole partition (round 6): the block costs of PUs of many sizes.  As the prediction `_runs` entry points below: run i = `count`
+ * consecutive entries, from `first`, of the descriptor arrays, all of one size `rect` = HEVCASM_RECT(w, h); w one of HEVC's partition widths 4, 8, 12, 16, 24,
+ * 32, 48, 64 (anything else: HEVCASM_HIP_EINVAL -- the one-size calls take every multiple of 4), h a multiple of 4 in 4..64.  `runs` is a HOST array, read
+ * during the call (it travels in the kernel arguments, 96 runs per launch; more runs = more launches, made by the call).  Per block exactly the result of
+ * hevcasm_hip_sad_batch / _sad_multiref_batch / _ssd_batch for the run's size: sad[i] (multiref: sad[4 i .. 4 i + 3], ref_off[4 i .. 4 i + 3]) for descriptor
+ * i.  Memory touched: no more than the one-size calls touch. */
+typedef struct
+{
+	uint32_t first, count;      /* descriptor entries [first, first + count) */
+	uint32_t rect;              /* HEVCASM_RECT(w, h) */
+} hevcasm_hip_cost_run;
+
+int hevcasm_hip_sad_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad, const hevcasm_hip_cost_run *runs, int n_runs, void *stream);
+int hevcasm_hip_sad_multiref_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *sad, const hevcasm_hip_cost_run *runs, int n_runs, void *stream);
+int hevcasm_hip_ssd_runs(
+	const uint8_t *srcA, ptrdiff_t stride_srcA, const uint8_t *srcB, ptrdiff_t stride_srcB,
+	const uint32_t *offA, const uint32_t *offB, int *ssd, const hevcasm_hip_cost_run *runs, int n_runs, void *stream);
+
 /* Batched hevcasm_hadamard_satd (reference hadamard.h:53; C body hadamard.c:76-111):
  * log2TrafoSize 1, 2 or 3 (2x2, 4x4, 8x8 blocks). */
 int hevcasm_hip_hadamard_satd_batch(

@@ -78,6 +78,9 @@ def _canned_family_rows():
               "pred_uni frame partition, one launch 24 sizes x 3 planes", "pred_bi frame partition, one launch 22 sizes x 3 planes",
               "pred_uni frame partition, a launch per (size, plane) 24 sizes x 3 planes", "pred_bi frame partition, a launch per (size, plane) 22 sizes x 3 planes"):
         rows.append(dict(family="inter_pred_latency", kernel=k, ms=0.015, mblocks_per_s=800.0, gbs=600.0, frac=0.08, bytes_per_block=785, note="x" * 300))
+    for k in ("sad frame partition, one launch 24 sizes", "sad_multiref_4 frame partition, one launch 24 sizes", "sad frame partition, a launch per size 24 sizes",
+              "sad_multiref_4 frame partition, a launch per size 24 sizes", "ssd frame partition, one launch 24 sizes"):      # round 6: a frame's block costs in one launch
+        rows.append(dict(family="block_cost_latency", kernel=k, ms=0.02, mblocks_per_s=870.0, gbs=210.0, frac=0.03, bytes_per_block=243, note="y" * 200))
     for k, ms in (("intra_frames 1080p x 1", 9.4), ("intra_frames 1080p x 64", 10.7)):      # round 6: whole intra frames in wavefront order
         rows.append(dict(family="intra_frames", kernel=k, ms=ms, mblocks_per_s=2.9, gbs=0.9, frac=0.0001, bytes_per_block=320, frames=1, note="n" * 200))
     for fam, sfx in (("", ""), ("_large_launch", "")):
@@ -101,7 +104,8 @@ def test_the_record_keeps_every_family_as_scalars():
     want = ["sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "pred_uni_chroma8_1plane", "pred_uni_chroma8_256f",
             "pred_bi_chroma8_256f", "pred_uni_luma16_256f", "idct8", "idct16", "idct32", "fused_idct8", "fused_idct16", "fused_idct32", "fdct8", "fdct16", "fdct32",
             "idct16_2p28", "idct32_2p28", "fused_idct32_2p28", "fdct32_2p28", "pred_uni_luma16_1frame", "pred_uni_frame_graph", "pred_bi_frame_graph",
-            "pred_uni_frame_runs", "pred_bi_frame_runs", "pred_uni_frame_72_launches", "intra_frame", "intra_frames64"]
+            "pred_uni_frame_runs", "pred_bi_frame_runs", "pred_uni_frame_72_launches", "intra_frame", "intra_frames64", "sad_frame_runs", "sad4_frame_runs",
+            "sad_frame_24_launches"]
     for k in want:
         for sfx in ("_frac", "_gbs", "_ms", "_mblocks"):
             assert isinstance(kept[k + sfx], float), k + sfx

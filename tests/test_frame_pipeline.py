@@ -51,6 +51,26 @@ class OracleOps:
         return pyoracle.frame_sse_batch(a, sa, b, sb, z, z, w, h)
 
 
+    # the mixed-partition chain (pipeline.stages_partition): every run of a size through the oracle's one-size batches
+    def plan_partition(self, frame, pus, tu):
+        cur_off, ref_base, sizes, order = pipeline.partition_grid(pus, frame["stride_cur"], frame["stride_ref"], frame["pad"])
+        tu_off, _ = pipeline.block_grid(frame["w"], frame["h"], tu, frame["stride_cur"], frame["stride_ref"], frame["pad"])
+        return frame["cur"], frame["ref"], cur_off, ref_base, sizes, order, tu_off
+
+    def concat(self, parts):
+        return np.concatenate(parts)
+
+    def pred_uni_runs(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, sizes):
+        dst = np.zeros(dst_bytes, dtype=np.uint8)
+        for (w, h, f, n) in sizes:
+            dst |= pyoracle.pred_uni_batch(8, dst_bytes, sd, ref, sr, dst_off[f:f + n], ref_off[f:f + n], frac[f:f + n], w, h)      # PUs tile the plane
+        return dst
+
+    def cost_runs(self, kind, a, sa, b, sb, a_off, b_off, sizes):
+        fn = pyoracle.sad_batch if kind == "sad" else pyoracle.ssd_batch
+        return np.concatenate([fn(a, sa, b, sb, a_off[f:f + n], b_off[f:f + n], w, h) for (w, h, f, n) in sizes])
+
+
 def _with_half_pel_motion(frame):
     """The generator moves blocks by whole pixels; here the lower half of the current frame becomes the mean of itself and its right-hand neighbour,
     i.e. content half a pixel away from anything in the reference, so that the refinement has fractional winners."""
@@ -110,3 +130,54 @@ def test_pipeline_as_one_hip_graph():
     ref_dev.copy_(torch.from_numpy(frame2["ref"]))
     graph.replay()
     _same_stages(pipeline.HipOps.to_numpy(results), pipeline.stages(frame2, OracleOps(), size=16, search_range=8))
+
+
+PARTITION_KEYS = ("mv", "qmv", "pred", "pu_sad", "residual", "coeffs", "levels", "cbf", "recon", "pu_ssd", "frame_sse")
+
+
+def _same_partition_stages(got, want):
+    for key in PARTITION_KEYS:
+        g, wv = np.asarray(got[key]), np.asarray(want[key])
+        if key == "cbf":
+            g, wv = g != 0, wv != 0
+        assert g.shape == wv.shape and np.array_equal(g, wv), "stage %s differs (%d of %d)" % (key, int((g != wv).sum()), g.size)
+
+
+def test_partition_chain_on_the_oracle_hangs_together(oracle_lib):
+    """CPU: the chain on a quad-tree partition -- the PUs' prediction cost IS the refinement's winning cost (two independent routes to one number: the fused
+    49-candidate kernel's minimum, and prediction written to memory + SAD), and the PUs' SSDs add up to the frame's."""
+    from hevcasm_amd import workload as wl
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(192, 128, 16, seed=5, ctu=16, max_motion=6))
+    pus = wl.inter_partition(192, 128, 3)
+    r = pipeline.stages_partition(frame, OracleOps(), pus, tu=16, search_range=8)
+    assert len(r["mv"]) == len(pus) and len({(p[2], p[3]) for p in pus}) >= 12
+    assert np.array_equal(r["pu_sad"], r["qmv"][:, 2])
+    assert int(r["pu_ssd"].astype(np.int64).sum()) == int(r["frame_sse"][0])
+    assert (r["qmv"][:, :2] & 3).any() and pipeline.psnr(int(r["frame_sse"][0]), 192, 128) > 30.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,tu,rng", [(960, 576, 16, 8), (512, 256, 32, 6), (384, 256, 8, 6)])
+def test_partition_chain_hip_equals_oracle_stage_by_stage(w, h, tu, rng):
+    """VERDICT round 5, item 2, last clause: the pipeline's chain on a MIXED partition -- prediction, the PUs' SAD and the PUs' SSD each as ONE launch over every
+    PU size present -- equals the oracle stage by stage."""
+    from hevcasm_amd import workload as wl
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + tu, ctu=16, max_motion=rng - 2))
+    pus = wl.inter_partition(w, h, w + 1)
+    want = pipeline.stages_partition(frame, OracleOps(), pus, tu=tu, search_range=rng)
+    got = pipeline.HipOps.to_numpy(pipeline.stages_partition(frame, pipeline.HipOps(), pus, tu=tu, search_range=rng))
+    _same_partition_stages(got, want)
+    assert np.array_equal(got["pu_sad"], got["qmv"][:, 2])
+
+
+@pytest.mark.gpu
+def test_partition_chain_as_one_hip_graph():
+    from hevcasm_amd import workload as wl
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(640, 384, 16, seed=31, ctu=16, max_motion=6))
+    pus = wl.inter_partition(640, 384, 8)
+    want = pipeline.stages_partition(frame, OracleOps(), pus, tu=16, search_range=8)
+    ops = pipeline.HipOps()
+    graph, results = ops.capture(frame, pus=pus, tu=16, search_range=8)
+    for _ in range(2):
+        graph.replay()
+    _same_partition_stages(pipeline.HipOps.to_numpy(results), want)

@@ -255,3 +255,15 @@ def test_pred_runs_random_partitions():
         c = wl.pred_frame_case(w, h, 9500 + i, bi=bi, chroma=chroma, kind=["noise", "video", "max"][int(rng.integers(0, 3))])
         for plane, (g, x) in enumerate(zip(test_pred_runs._run_hip(c), test_pred_runs._oracle_planes(pyoracle, c))):
             assert np.array_equal(g, x), "fuzz pred runs %dx%d bi=%s plane %d" % (w, h, bi, plane)
+
+
+def test_cost_runs_random_partitions():
+    """Round 6: the block costs of a frame's partition in one launch -- random frame sizes (multiples of 8), the three cost kinds, against the oracle per run."""
+    import test_cost_runs
+    from oracle import pyoracle
+    rng = np.random.default_rng(20261012 + SEED)
+    for i in range(8):
+        w, h = 8 * int(rng.integers(1, 40)), 8 * int(rng.integers(1, 30))
+        c = wl.cost_frame_case(w, h, 9700 + i, kind=["noise", "video", "max"][int(rng.integers(0, 3))], search=int(rng.integers(0, 40)))
+        for kind in test_cost_runs.KINDS:
+            assert np.array_equal(test_cost_runs._hip(c, kind), test_cost_runs._oracle(pyoracle, c, kind)), "fuzz cost runs %dx%d %s" % (w, h, kind)

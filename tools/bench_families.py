@@ -228,6 +228,44 @@ def bench_pred_latency(reps=30):
         torch.cuda.empty_cache()
 
 
+def bench_cost_latency(reps=30):
+    """Round 6: the block costs of ONE 1080p frame's partition -- a quad-tree over every PU size of pred_inter.c:438-444, one candidate (sad, ssd) or four
+    (sad_multiref, +-7 pixels) per PU -- as ONE launch (hevcasm_hip_*_runs) next to what it replaces: a launch per size.  Three frames rotate."""
+    frames3 = []
+    for k in range(3):
+        c = wl.cost_frame_case(1920, 1080, 950 + k)
+        frames3.append((c, dict(src=B.u8(c["src"]), ref=B.u8(c["ref"]), src_off=B.off32(c["src_off"]), ref_off=B.off32(c["ref_off"]), ref_off4=B.off32(c["ref_off4"]),
+                                out=torch.zeros(c["n_pus"], dtype=torch.int32, device="cuda"), out4=torch.zeros((c["n_pus"], 4), dtype=torch.int32, device="cuda"))))
+    c0 = frames3[0][0]
+    for kind in ("sad", "sad4", "ssd"):
+        ways = 4 if kind == "sad4" else 1
+
+        def one_launch(i):
+            c, d = frames3[i % 3]
+            B.cost_runs(kind, d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off4"] if ways == 4 else d["ref_off"], c["runs"], out=d["out4"] if ways == 4 else d["out"])
+
+        def per_size_launches(i):
+            c, d = frames3[i % 3]
+            for (w, h, first, count) in c["sizes"]:
+                s = slice(first, first + count)
+                if kind == "sad":
+                    B.sad(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"][s], d["ref_off"][s], w, h, out=d["out"][s])
+                elif kind == "ssd":
+                    B.ssd(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"][s], d["ref_off"][s], w, h, out=d["out"][s])
+                else:
+                    B.sad_multiref(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"][s], d["ref_off4"][4 * first:4 * (first + count)], w, h, out=d["out4"][s])
+
+        bytes_frame = sum(n * ((1 + ways) * w * h + 4 * (1 + 2 * ways)) for (w, h, _, n) in c0["sizes"])
+        for name, fn, launches in (("frame partition, one launch", one_launch, 1), ("frame partition, a launch per size", per_size_launches, len(c0["sizes"]))):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            report("%s %s" % ({"sad": "sad", "sad4": "sad_multiref_4", "ssd": "ssd"}[kind], name), c0["n_pus"], bytes_frame // c0["n_pus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1,
+                   launches=launches, note="one 1080p frame cut by a random quad-tree into PUs of every size; HIP events around the frame")
+    del frames3
+    torch.cuda.empty_cache()
+
+
 def bench_transform(coeffs_per_launch=1 << 26, only=None, label=""):
     for tr, lg in wl.TRANSFORMS:
         if only and (tr, lg) not in only:
@@ -527,4 +565,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, predlat=bench_pred_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, costlat=bench_cost_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
