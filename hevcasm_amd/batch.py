@@ -239,6 +239,28 @@ def subpel_refine(src, stride_src, ref, stride_ref, src_off, ref_off, w, h, metr
     return out
 
 
+def me_full_search_runs(src, stride_src, ref, stride_ref, src_off, ref_off, runs, search_range, out=None):
+    """hevcasm_hip_me_full_search_runs: the full search of a frame's whole partition (runs: numpy COST_RUN_DTYPE, host) in ONE launch -> int32 [n, 3]."""
+    n = src_off.numel()
+    out = _result_rows(out, n, src)
+    runs = np.ascontiguousarray(runs)
+    assert runs.dtype.itemsize == 12
+    check(lib().hevcasm_hip_me_full_search_runs(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(), ref_off.data_ptr(), out.data_ptr(),
+                                                runs.ctypes.data, len(runs), search_range, _stream()), "me_full_search_runs")
+    return out
+
+
+def subpel_refine_runs(src, stride_src, ref, stride_ref, src_off, ref_off, runs, metric=0, out=None):
+    """hevcasm_hip_subpel_refine_runs: the quarter-pel refinement of a frame's whole partition in ONE launch -> int32 [n, 3]."""
+    n = src_off.numel()
+    out = _result_rows(out, n, src)
+    runs = np.ascontiguousarray(runs)
+    assert runs.dtype.itemsize == 12
+    check(lib().hevcasm_hip_subpel_refine_runs(src.data_ptr(), stride_src, ref.data_ptr(), stride_ref, src_off.data_ptr(), ref_off.data_ptr(), out.data_ptr(),
+                                               runs.ctypes.data, len(runs), metric, _stream()), "subpel_refine_runs")
+    return out
+
+
 def pred_intra(dst, neighbours, neighbour_stride, mode, packed, n):
     """Batched hevcasm_pred_intra, one mode for the batch: block i reads neighbours + i * neighbour_stride, writes dst[i * N * N ...].
     packed | INTRA_COMPACT: compact records (see pred_intra_modes)."""

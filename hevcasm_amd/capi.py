@@ -35,6 +35,8 @@ HIP_API = {
     "hevcasm_hip_sad_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_sad_multiref_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_ssd_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hevcasm_hip_me_full_search_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "hevcasm_hip_subpel_refine_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "hevcasm_hip_hadamard_satd_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _sz, _vp]),
     "hevcasm_hip_pred_uni_8to8_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),
     "hevcasm_hip_pred_bi_8to8_batch": (_i, [_vp, _pd, _vp, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _sz, _vp]),

@@ -14,7 +14,9 @@
 // VALU/LDS-bound (about 1.7 k byte differences per byte fetched), not HBM-bound.
 
 #include "common.hpp"
+#include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace hevc {
 
@@ -46,16 +48,15 @@ __device__ __forceinline__ unsigned long long *me_key_slot(int *result, uint32_t
 // workgroup each (its window is the H + rows - 1 window rows the range needs); the ranges' minima meet in an atomicMin on the 64-bit key
 // (cost << 16 | index: ties still go to the raster-first candidate) held in the block's own 12-byte result slot, and me_decode_kernel
 // rewrites the keys as (dx, dy, cost) afterwards.
+// `wg`: the workgroup's index among the launch's (blocks x parts) of this geometry
 template <bool FRAME, bool W64>
-__global__ __launch_bounds__(kThreads) void me_full_search_kernel(
+__device__ __forceinline__ void me_search_workgroup(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, MeFrame fr, int parts)
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, const MeFrame &fr, int parts, uint32_t wg, uint8_t *lds)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-
-	const uint32_t blk = blockIdx.x / (uint32_t)parts;
-	const int part = (int)(blockIdx.x - blk * (uint32_t)parts);
+	const uint32_t blk = wg / (uint32_t)parts;
+	const int part = (int)(wg - blk * (uint32_t)parts);
 	const uint8_t *sp, *rp0;
 	if (FRAME)
 	{
@@ -273,6 +274,51 @@ __global__ __launch_bounds__(kThreads) void me_full_search_kernel(
 	}
 }
 
+template <bool FRAME, bool W64>
+__global__ __launch_bounds__(kThreads) void me_full_search_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
+	int W, int H, int R, int win_stride /* bytes, multiple of 16 */, MeFrame fr, int parts)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	me_search_workgroup<FRAME, W64>(src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, R, win_stride, fr, parts, blockIdx.x, lds);
+}
+
+// ---- one launch for a frame's partition: runs of equally sized blocks (round 6) -------------------------------------------------------------------
+//
+// The kernel above takes its geometry at run time, so a frame's PUs of many sizes (pred_inter.c:438-444) need only a table: run i = `count` consecutive
+// descriptors of one size; a workgroup finds its run by comparing its index with the runs' first workgroups (one workgroup per block, the table in the
+// kernel arguments, as pred_inter.hip's pred_runs_kernel) and searches its block.  The dynamic LDS is sized for the largest run.
+constexpr int kMaxMeRuns = 96;
+struct MeRunDev { uint32_t first, count; uint16_t W, H; };
+struct MeRunsArgs
+{
+	const uint8_t *src, *ref;
+	ptrdiff_t stride_src, stride_ref;
+	const uint32_t *src_off, *ref_off;
+	int *result;
+	int R;
+	uint32_t wg_start[kMaxMeRuns];      // first workgroup of run i; unused entries hold 0xffffffff
+	MeRunDev runs[kMaxMeRuns];
+};
+
+__global__ __launch_bounds__(kThreads) void me_full_search_runs_kernel(const MeRunsArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint32_t at_or_before = 0, start = 0;
+#pragma unroll
+	for (int i = 0; i < kMaxMeRuns; ++i)
+	{
+		const bool in = a.wg_start[i] <= blockIdx.x;
+		at_or_before += in ? 1u : 0u;
+		start = in ? a.wg_start[i] : start;      // starts ascend: the last one taken is the run's
+	}
+	const MeRunDev r = a.runs[at_or_before - 1];
+	const int W = r.W, win_stride = (W + 2 * a.R + 15) & ~15;
+	me_search_workgroup<false, false>(a.src, a.stride_src, a.ref, a.stride_ref, a.src_off + r.first, a.ref_off + r.first, a.result + 3 * (size_t)r.first,
+		W, r.H, a.R, win_stride, MeFrame{}, 1, blockIdx.x - start, lds);
+}
+
 // several workgroups per block: the 8-byte-aligned 8 bytes inside block k's 12-byte result slot (me_key_slot) hold the running minimum key,
 // preset to all ones; this turns them into the result
 __global__ __launch_bounds__(kThreads) void me_decode_kernel(int *result, uint32_t n_blocks, int R)
@@ -371,6 +417,51 @@ extern "C" int hevcasm_hip_me_full_search_batch(
 	if (n_blocks > 0x1fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 	return me_launch<false>(src, stride_src, ref, stride_ref, src_off, ref_off, result, W, H, range, W == 64, n_blocks, MeFrame{}, as_stream(stream));
+}
+
+extern "C" int hevcasm_hip_me_full_search_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	const hevcasm_hip_cost_run *runs, int n_runs, int range, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (range < 0 || range > 127) return set_error(HEVCASM_HIP_EINVAL, "range must be 0..127");
+	if (n_runs == 0) return 0;
+	if (!runs || !src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<MeRunDev> table;
+	table.reserve((size_t)n_runs);
+	size_t shmem = 0;
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const int W = (int)(runs[i].rect >> 8), H = (int)(runs[i].rect & 0xff);
+		if (W < 4 || W > 64 || H < 4 || H > 64 || (W & 3) || (H & 3) || (runs[i].rect >> 16)) return set_error(HEVCASM_HIP_EINVAL, "block size must be a multiple of 4 in 4..64");
+		if ((uint64_t)runs[i].first + runs[i].count > 0x1fffffffull) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
+		int win_stride;
+		const size_t lds = me_lds_bytes(W, H, range, H + 2 * range, &win_stride);
+		if (lds > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "search window does not fit in 64 KiB of LDS");
+		if (runs[i].count == 0) continue;
+		shmem = lds > shmem ? lds : shmem;
+		table.push_back(MeRunDev{ runs[i].first, runs[i].count, (uint16_t)W, (uint16_t)H });
+	}
+	// the largest blocks first: the launch ends when its last workgroup does
+	std::stable_sort(table.begin(), table.end(), [](const MeRunDev &x, const MeRunDev &y) { return (int)x.W * x.H > (int)y.W * y.H; });
+	for (size_t base = 0; base < table.size(); base += kMaxMeRuns)      // more runs than one table holds: the next launch
+	{
+		MeRunsArgs a = {};
+		a.src = src; a.ref = ref; a.stride_src = stride_src; a.stride_ref = stride_ref; a.src_off = src_off; a.ref_off = ref_off; a.result = result; a.R = range;
+		uint32_t wgs = 0, used = 0;
+		for (int i = 0; i < kMaxMeRuns; ++i) a.wg_start[i] = 0xffffffffu;
+		for (size_t i = base; i < table.size() && i < base + kMaxMeRuns; ++i)
+		{
+			a.runs[used] = table[i];
+			a.wg_start[used++] = wgs;
+			wgs += table[i].count;
+		}
+		hipLaunchKernelGGL(me_full_search_runs_kernel, dim3(wgs), dim3(kThreads), shmem, as_stream(stream), a);
+		if (int e = launch_status("me_full_search_runs_kernel")) return e;
+	}
+	return 0;
 }
 
 static int me_frames_ctus(const uint8_t *cur, ptrdiff_t stride_cur, ptrdiff_t pitch_cur, const uint8_t *ref, ptrdiff_t stride_ref, ptrdiff_t pitch_ref, size_t n_frames,

@@ -24,6 +24,8 @@
 // pixel), not HBM-bound: algorithmic bytes per block are (W + 8)(H + 8) + W H + 8 + 12.
 
 #include "common.hpp"
+#include <algorithm>
+#include <vector>
 
 namespace hevc {
 
@@ -170,21 +172,37 @@ struct SubpelGeometry
 	int off_src, off_plane, off_cost;   // byte offsets inside a block's LDS
 };
 
+// a W x H block's geometry (host: the one-size launcher; device: the runs kernel, from its run's size)
+__host__ __device__ inline SubpelGeometry subpel_geometry(int W, int H)
+{
+	SubpelGeometry g;
+	g.W = W; g.H = H;
+	const int items = W * H / 4;
+	g.lpb = items < kThreads ? items : kThreads;
+	g.bpw = kThreads / g.lpb;
+	g.seg = (g.lpb % 16 == 0) ? 16 : (g.lpb % 8 == 0) ? 8 : 4;
+	const int win_bytes = (H + 8) * (W + 8), src_bytes = W * H, plane_bytes = 2 * H * (W + 8) * 2;
+	g.off_src = (win_bytes + 7) & ~7;
+	g.off_plane = (g.off_src + src_bytes + 7) & ~7;
+	g.off_cost = g.off_plane + plane_bytes;
+	g.blk_bytes = (g.off_cost + 49 * 4 + 15) & ~15;
+	return g;
+}
+
 // METRIC 0 = SAD, 1 = Hadamard SATD over TILE x TILE tiles (TILE = 8 when both dimensions allow, else 4)
+// `wg`: the workgroup's index among the ceil(n_blocks / g.bpw) of this geometry
 template <int METRIC, int TILE>
-__global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
+__device__ __forceinline__ void subpel_refine_workgroup(
 	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
 	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
-	SubpelGeometry g, uint32_t n_blocks)
+	const SubpelGeometry &g, uint32_t n_blocks, uint32_t wg, uint8_t *lds)
 {
-	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-
 	const int W = g.W, H = g.H;
 	const int w4 = W / 4;              // output dwords per row
 	const int wd = (W + 8) / 4;        // window dwords per row
 	const int pitch = W + 8;           // plane row, int16 elements
 	const int b_local = threadIdx.x / g.lpb, l = threadIdx.x - b_local * g.lpb;
-	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * g.bpw + b_local;
+	const uint32_t blk = wg * g.bpw + b_local;
 	const bool active = b_local < g.bpw && blk < n_blocks;
 
 	uint8_t *mine = lds + (active ? b_local : 0) * g.blk_bytes;
@@ -325,9 +343,100 @@ __global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
 	}
 }
 
+template <int METRIC, int TILE>
+__global__ __launch_bounds__(kThreads) void subpel_refine_kernel(
+	const uint8_t *__restrict__ src, ptrdiff_t stride_src, const uint8_t *__restrict__ ref, ptrdiff_t stride_ref,
+	const uint32_t *__restrict__ src_off, const uint32_t *__restrict__ ref_off, int *__restrict__ result,
+	SubpelGeometry g, uint32_t n_blocks)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	subpel_refine_workgroup<METRIC, TILE>(src, stride_src, ref, stride_ref, src_off, ref_off, result, g, n_blocks, xcd_contiguous(blockIdx.x, gridDim.x), lds);
+}
+
+// ---- one launch for a frame's partition: runs of equally sized blocks (round 6; see me.hip's me_full_search_runs_kernel) ---------------------------
+constexpr int kMaxSubpelRuns = 96;
+struct SubpelRunDev { uint32_t wg_count, first, count; uint16_t W, H; };
+struct SubpelRunsArgs
+{
+	const uint8_t *src, *ref;
+	ptrdiff_t stride_src, stride_ref;
+	const uint32_t *src_off, *ref_off;
+	int *result;
+	uint32_t wg_start[kMaxSubpelRuns];      // first workgroup of run i; unused entries hold 0xffffffff
+	SubpelRunDev runs[kMaxSubpelRuns];
+};
+
+template <int METRIC>
+__global__ __launch_bounds__(kThreads) void subpel_refine_runs_kernel(const SubpelRunsArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+	uint32_t at_or_before = 0, start = 0;
+#pragma unroll
+	for (int i = 0; i < kMaxSubpelRuns; ++i)
+	{
+		const bool in = a.wg_start[i] <= blockIdx.x;
+		at_or_before += in ? 1u : 0u;
+		start = in ? a.wg_start[i] : start;      // starts ascend: the last one taken is the run's
+	}
+	const SubpelRunDev r = a.runs[at_or_before - 1];
+	const SubpelGeometry g = subpel_geometry(r.W, r.H);
+	const uint32_t wg = xcd_contiguous(blockIdx.x - start, r.wg_count);
+#define HEVC_RUN(TILE) subpel_refine_workgroup<METRIC, TILE>(a.src, a.stride_src, a.ref, a.stride_ref, a.src_off + r.first, a.ref_off + r.first, a.result + 3 * (size_t)r.first, g, r.count, wg, lds)
+	if (METRIC == 0) HEVC_RUN(4);
+	else if (r.W % 8 == 0 && r.H % 8 == 0) HEVC_RUN(8);
+	else HEVC_RUN(4);
+#undef HEVC_RUN
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_subpel_refine_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	const hevcasm_hip_cost_run *runs, int n_runs, int metric, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (metric != 0 && metric != 1) return set_error(HEVCASM_HIP_EINVAL, "metric must be 0 (SAD) or 1 (Hadamard SATD)");
+	if (n_runs == 0) return 0;
+	if (!runs || !src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<SubpelRunDev> table;
+	table.reserve((size_t)n_runs);
+	size_t shmem = 0;
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const int W = (int)(runs[i].rect >> 8), H = (int)(runs[i].rect & 0xff);
+		if (W < 4 || W > 64 || H < 4 || H > 64 || (W & 3) || (H & 3) || (runs[i].rect >> 16)) return set_error(HEVCASM_HIP_EINVAL, "block size must be a multiple of 4 in 4..64");
+		if ((uint64_t)runs[i].first + runs[i].count > 0x7fffffffull / 3) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
+		const SubpelGeometry g = subpel_geometry(W, H);
+		const size_t lds = (size_t)g.blk_bytes * g.bpw;
+		if (lds > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "block does not fit in 64 KiB of LDS");
+		if (runs[i].count == 0) continue;
+		shmem = lds > shmem ? lds : shmem;
+		table.push_back(SubpelRunDev{ ceil_div((size_t)runs[i].count, (size_t)g.bpw), runs[i].first, runs[i].count, (uint16_t)W, (uint16_t)H });
+	}
+	// the largest blocks first: the launch ends when its last workgroup does
+	std::stable_sort(table.begin(), table.end(), [](const SubpelRunDev &x, const SubpelRunDev &y) { return (int)x.W * x.H > (int)y.W * y.H; });
+	for (size_t base = 0; base < table.size(); base += kMaxSubpelRuns)      // more runs than one table holds: the next launch
+	{
+		SubpelRunsArgs a = {};
+		a.src = src; a.ref = ref; a.stride_src = stride_src; a.stride_ref = stride_ref; a.src_off = src_off; a.ref_off = ref_off; a.result = result;
+		uint32_t wgs = 0, used = 0;
+		for (int i = 0; i < kMaxSubpelRuns; ++i) a.wg_start[i] = 0xffffffffu;
+		for (size_t i = base; i < table.size() && i < base + kMaxSubpelRuns; ++i)
+		{
+			a.runs[used] = table[i];
+			a.wg_start[used++] = wgs;
+			wgs += table[i].wg_count;
+		}
+		if (metric == 0) hipLaunchKernelGGL(subpel_refine_runs_kernel<0>, dim3(wgs), dim3(kThreads), shmem, as_stream(stream), a);
+		else hipLaunchKernelGGL(subpel_refine_runs_kernel<1>, dim3(wgs), dim3(kThreads), shmem, as_stream(stream), a);
+		if (int e = launch_status("subpel_refine_runs_kernel")) return e;
+	}
+	return 0;
+}
 
 extern "C" int hevcasm_hip_subpel_refine_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
@@ -342,17 +451,7 @@ extern "C" int hevcasm_hip_subpel_refine_batch(
 	if (n_blocks > 0x7fffffffull / 3) return set_error(HEVCASM_HIP_EINVAL, "n_blocks too large");
 	if (!src || !ref || !src_off || !ref_off || !result) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
 
-	SubpelGeometry g;
-	g.W = W; g.H = H;
-	const int items = W * H / 4;
-	g.lpb = items < kThreads ? items : kThreads;
-	g.bpw = kThreads / g.lpb;
-	g.seg = (g.lpb % 16 == 0) ? 16 : (g.lpb % 8 == 0) ? 8 : 4;
-	const int win_bytes = (H + 8) * (W + 8), src_bytes = W * H, plane_bytes = 2 * H * (W + 8) * 2;
-	g.off_src = (win_bytes + 7) & ~7;
-	g.off_plane = (g.off_src + src_bytes + 7) & ~7;
-	g.off_cost = g.off_plane + plane_bytes;
-	g.blk_bytes = (g.off_cost + 49 * 4 + 15) & ~15;
+	const SubpelGeometry g = subpel_geometry(W, H);
 	const size_t shmem = (size_t)g.blk_bytes * g.bpw;
 	if (shmem > 64 * 1024) return set_error(HEVCASM_HIP_EINVAL, "block does not fit in 64 KiB of LDS");
 	const uint32_t grid = ceil_div(n_blocks, g.bpw);

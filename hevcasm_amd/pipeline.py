@@ -61,16 +61,16 @@ def partition_grid(pus, stride_cur, stride_ref, pad):
 def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1):
     """The same chain on a REAL partition (round 6): the frame cut into prediction units of many sizes (`pus`, any of the 24 of
     pred_inter.c:438-444), transform units on a uniform tu x tu grid (HEVC's transform tree is independent of the PU boundaries inside a CU).
-    The search and the refinement take one size per call (one launch per size present); everything that follows is ONE launch per stage for the whole frame:
-    hevcasm_hip_pred_uni_8to8_runs, hevcasm_hip_sad_runs (the PUs' prediction cost -- which must be the refinement's winning cost), the transform stages on
-    the TU grid, hevcasm_hip_ssd_runs per PU.  -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
+    Every stage is ONE launch for the whole frame: hevcasm_hip_me_full_search_runs, hevcasm_hip_subpel_refine_runs, hevcasm_hip_pred_uni_8to8_runs,
+    hevcasm_hip_sad_runs (the PUs' prediction cost -- which must be the refinement's winning cost), the transform stages on the TU grid,
+    hevcasm_hip_ssd_runs per PU.  -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
     w, h, pad = frame["w"], frame["h"], frame["pad"]
     sc, sr = frame["stride_cur"], frame["stride_ref"]
     log2n = tu.bit_length() - 1
     cur, ref, cur_off, ref_base, sizes, order, tu_off = ops.plan_partition(frame, pus, tu)
-    mv = ops.concat([ops.me_full_search(cur, sc, ref, sr, cur_off[f:f + n], ref_base[f:f + n], pw, ph, search_range) for (pw, ph, f, n) in sizes])
+    mv = ops.me_full_search_runs(cur, sc, ref, sr, cur_off, ref_base, sizes, search_range)      # every PU size, one launch
     ref_int = ops.offsets_after_search(ref_base, mv, sr)
-    qmv = ops.concat([ops.subpel_refine(cur, sc, ref, sr, cur_off[f:f + n], ref_int[f:f + n], pw, ph) for (pw, ph, f, n) in sizes])
+    qmv = ops.subpel_refine_runs(cur, sc, ref, sr, cur_off, ref_int, sizes)                      # one launch
     ref_sub, frac = ops.subpel_descriptors(ref_int, qmv, sr)
     pred = ops.pred_uni_runs(w * h, sc, ref, sr, cur_off, ref_sub, frac, sizes)                 # every PU size, one launch
     pu_sad = ops.cost_runs("sad", cur, sc, pred, sc, cur_off, cur_off, sizes)                   # one launch; == qmv[:, 2]
@@ -134,8 +134,11 @@ class HipOps:
         self._pred_runs, self._cost_runs = p[5], p[6]
         return cur, ref, p[1], p[2], p[3], p[4], tu_off
 
-    def concat(self, parts):
-        return self.t.cat(parts)
+    def me_full_search_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes, search_range):
+        return self.B.me_full_search_runs(cur, sc, ref, sr, cur_off, ref_off, self._cost_runs, search_range)
+
+    def subpel_refine_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes):
+        return self.B.subpel_refine_runs(cur, sc, ref, sr, cur_off, ref_off, self._cost_runs)
 
     def pred_uni_runs(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, sizes):
         dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)

@@ -441,6 +441,15 @@ int hevcasm_hip_me_full_search_frames_ctus(
 	const uint8_t *cur, ptrdiff_t stride_cur, ptrdiff_t frame_pitch_cur, const uint8_t *ref, ptrdiff_t stride_ref, ptrdiff_t frame_pitch_ref, size_t n_frames,
 	int frame_w, int frame_h, int ctu, int range, int first_ctu, int n_ctus, int *result, void *stream);
 
+/* The search of a frame's whole partition in ONE launch (round 6): run i = `count` consecutive descriptors from `first`, all of size `rect`
+ * (hevcasm_hip_cost_run, above; any multiple of 4 in 4..64 per dimension), one `range` for the call.  `runs` is a HOST array read during the call (96 runs per
+ * launch; more = more launches, made by the call).  Per block exactly hevcasm_hip_me_full_search_batch's answer; one workgroup per block (no candidate-row
+ * split), so `result` is written once and never used as scratch. */
+int hevcasm_hip_me_full_search_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	const hevcasm_hip_cost_run *runs, int n_runs, int range, void *stream);
+
 /* ---- fused quarter-pel refinement ------------------------------------- */
 
 /* For each block: the 49 luma quarter-pel displacements (qx, qy) in [-3, 3]^2 around the
@@ -456,6 +465,13 @@ int hevcasm_hip_subpel_refine_batch(
 	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
 	const uint32_t *src_off, const uint32_t *ref_off, int *result,
 	uint32_t rect, int metric, size_t n_blocks, void *stream);
+
+/* The refinement of a frame's whole partition in ONE launch (round 6): runs as for hevcasm_hip_me_full_search_runs; per block exactly
+ * hevcasm_hip_subpel_refine_batch's answer for the run's size and `metric`. */
+int hevcasm_hip_subpel_refine_runs(
+	const uint8_t *src, ptrdiff_t stride_src, const uint8_t *ref, ptrdiff_t stride_ref,
+	const uint32_t *src_off, const uint32_t *ref_off, int *result,
+	const hevcasm_hip_cost_run *runs, int n_runs, int metric, void *stream);
 
 #ifdef __cplusplus
 }

@@ -92,3 +92,44 @@ def test_hip_cost_runs_small_frames_many_runs_and_bad_arguments(oracle_lib):
     assert L.hevcasm_hip_sad_runs(t.data_ptr(), 256, t.data_ptr(), 256, o.data_ptr(), o.data_ptr(), o.data_ptr(), None, 1, None) == capi.EINVAL
     assert L.hevcasm_hip_sad_runs(t.data_ptr(), 256, t.data_ptr(), 256, o.data_ptr(), o.data_ptr(), o.data_ptr(), None, 0, None) == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.gpu
+def test_hip_search_and_refinement_of_a_partition_in_one_launch_each(oracle_lib):
+    """hevcasm_hip_me_full_search_runs / hevcasm_hip_subpel_refine_runs (both metrics): a frame's PUs of every size, one launch, per PU the one-size entry
+    point's answer == the oracle's; > 96 runs; bad arguments."""
+    import torch
+    from hevcasm_amd import batch as B
+    c = wl.cost_frame_case(320, 192, 51, border=32, kind="video")
+    src, ref, so, ro = B.u8(c["src"]), B.u8(c["ref"]), B.off32(c["src_off"]), B.off32(c["ref_off"])
+    for rng in (6, 13):
+        got = B.me_full_search_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, c["runs"], rng).cpu().numpy()
+        want = np.concatenate([oracle_lib.me_full_search(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"][f:f + n], c["ref_off"][f:f + n], w, h, rng) for (w, h, f, n) in c["sizes"]])
+        assert np.array_equal(got, want), "search +-%d: %d PUs differ" % (rng, int((got != want).any(axis=1).sum()))
+    for metric in (0, 1):
+        got = B.subpel_refine_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, c["runs"], metric).cpu().numpy()
+        want = np.concatenate([oracle_lib.subpel_refine(c["src"], c["stride_src"], c["ref"], c["stride_ref"], c["src_off"][f:f + n], c["ref_off"][f:f + n], w, h, metric) for (w, h, f, n) in c["sizes"]])
+        assert np.array_equal(got, want), "refinement metric %d: %d PUs differ" % (metric, int((got != want).any(axis=1).sum()))
+    # more runs than one table holds
+    pieces = []
+    for (w, h, first, count) in c["sizes"]:
+        for s in range(0, count, 3):
+            pieces.append((first + s, min(3, count - s), (w << 8) | h))
+    pieces = np.array(pieces, dtype=wl.COST_RUN_DTYPE)
+    assert len(pieces) > 96
+    a = B.me_full_search_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, pieces, 6).cpu().numpy()
+    b = B.me_full_search_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, c["runs"], 6).cpu().numpy()
+    assert np.array_equal(a, b)
+    a = B.subpel_refine_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, pieces).cpu().numpy()
+    b = B.subpel_refine_runs(src, c["stride_src"], ref, c["stride_ref"], so, ro, c["runs"]).cpu().numpy()
+    assert np.array_equal(a, b)
+    L = capi.lib()
+    t = torch.zeros(1 << 18, dtype=torch.uint8, device="cuda")
+    o = torch.zeros(64, dtype=torch.int32, device="cuda")
+    one = np.array([(0, 1, (16 << 8) | 16)], dtype=wl.COST_RUN_DTYPE)
+    bad = np.array([(0, 1, (16 << 8) | 18)], dtype=wl.COST_RUN_DTYPE)
+    me = lambda r, rng: L.hevcasm_hip_me_full_search_runs(t.data_ptr(), 512, t.data_ptr(), 512, o.data_ptr(), o.data_ptr(), o.data_ptr(), r.ctypes.data, len(r), rng, None)
+    sp = lambda r, m: L.hevcasm_hip_subpel_refine_runs(t.data_ptr(), 512, t.data_ptr(), 512, o.data_ptr(), o.data_ptr(), o.data_ptr(), r.ctypes.data, len(r), m, None)
+    assert me(bad, 4) == capi.EINVAL and me(one, 128) == capi.EINVAL and me(one, -1) == capi.EINVAL
+    assert sp(bad, 0) == capi.EINVAL and sp(one, 2) == capi.EINVAL
+    torch.cuda.synchronize()

@@ -57,8 +57,11 @@ class OracleOps:
         tu_off, _ = pipeline.block_grid(frame["w"], frame["h"], tu, frame["stride_cur"], frame["stride_ref"], frame["pad"])
         return frame["cur"], frame["ref"], cur_off, ref_base, sizes, order, tu_off
 
-    def concat(self, parts):
-        return np.concatenate(parts)
+    def me_full_search_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes, search_range):
+        return np.concatenate([pyoracle.me_full_search(cur, sc, ref, sr, cur_off[f:f + n], ref_off[f:f + n], w, h, search_range) for (w, h, f, n) in sizes])
+
+    def subpel_refine_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes):
+        return np.concatenate([pyoracle.subpel_refine(cur, sc, ref, sr, cur_off[f:f + n], ref_off[f:f + n], w, h) for (w, h, f, n) in sizes])
 
     def pred_uni_runs(self, dst_bytes, sd, ref, sr, dst_off, ref_off, frac, sizes):
         dst = np.zeros(dst_bytes, dtype=np.uint8)

@@ -262,6 +262,33 @@ def bench_cost_latency(reps=30):
             torch.cuda.synchronize()
             report("%s %s" % ({"sad": "sad", "sad4": "sad_multiref_4", "ssd": "ssd"}[kind], name), c0["n_pus"], bytes_frame // c0["n_pus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1,
                    launches=launches, note="one 1080p frame cut by a random quad-tree into PUs of every size; HIP events around the frame")
+    # the search (+-8) and the quarter-pel refinement of the same partition: one launch against a launch per size
+    res = torch.zeros((c0["n_pus"], 3), dtype=torch.int32, device="cuda")
+    for kind in ("me_full_search +-8", "subpel_refine"):
+        def one_launch(i):
+            c, d = frames3[i % 3]
+            if kind.startswith("me"):
+                B.me_full_search_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], 8, out=res)
+            else:
+                B.subpel_refine_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], out=res)
+
+        def per_size_launches(i):
+            c, d = frames3[i % 3]
+            for (w, h, first, count) in c["sizes"]:
+                s = slice(first, first + count)
+                if kind.startswith("me"):
+                    B.me_full_search(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"][s], d["ref_off"][s], w, h, 8, out=res[s])
+                else:
+                    B.subpel_refine(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"][s], d["ref_off"][s], w, h, out=res[s])
+
+        margin = 16 if kind.startswith("me") else 8
+        bytes_frame = sum(n * (w * h + (w + margin) * (h + margin) + 8 + 12) for (w, h, _, n) in c0["sizes"])
+        for name, fn, launches in (("frame partition, one launch", one_launch, 1), ("frame partition, a launch per size", per_size_launches, len(c0["sizes"]))):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            report("%s %s" % (kind, name), c0["n_pus"], bytes_frame // c0["n_pus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=launches,
+                   note="one 1080p frame cut by a random quad-tree into PUs of every size; HIP events around the frame; VALU-bound kernels, the GB/s column is not their roofline")
     del frames3
     torch.cuda.empty_cache()
 
