@@ -263,14 +263,14 @@ def bench_cost_latency(reps=30):
             report("%s %s" % ({"sad": "sad", "sad4": "sad_multiref_4", "ssd": "ssd"}[kind], name), c0["n_pus"], bytes_frame // c0["n_pus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1,
                    launches=launches, note="one 1080p frame cut by a random quad-tree into PUs of every size; HIP events around the frame")
     # the search (+-8) and the quarter-pel refinement of the same partition: one launch against a launch per size
-    res = torch.zeros((c0["n_pus"], 3), dtype=torch.int32, device="cuda")
+    res = torch.zeros((max(c["n_pus"] for c, _ in frames3), 3), dtype=torch.int32, device="cuda")
     for kind in ("me_full_search +-8", "subpel_refine"):
         def one_launch(i):
             c, d = frames3[i % 3]
             if kind.startswith("me"):
-                B.me_full_search_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], 8, out=res)
+                B.me_full_search_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], 8, out=res[:c["n_pus"]])
             else:
-                B.subpel_refine_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], out=res)
+                B.subpel_refine_runs(d["src"], c["stride_src"], d["ref"], c["stride_ref"], d["src_off"], d["ref_off"], c["runs"], out=res[:c["n_pus"]])
 
         def per_size_launches(i):
             c, d = frames3[i % 3]
