@@ -160,13 +160,16 @@ __device__ __forceinline__ void transform_pass(const int16_t *in, int16_t *out, 
 
 // ---- one CTU's state in LDS ------------------------------------------------------------------------------------------------------------------------
 
-struct CtuLds
+// ENCODE: the kernel is built twice.  The encoder's TU loop then holds no global LOAD at all: on this hardware loads and stores share one counter (vmcnt), and
+// the wait in front of a load's first use also waits for every store issued before it -- the previous TU's reconstruction and levels, about 800 cycles a TU
+// (SQ_WAIT_ANY, profiles/r06_intra_ctu_counters.txt).  The decoder fetches the CTU's levels into LDS with the rest of the CTU's inputs, for the same reason.
+template <bool ENCODE> struct CtuLds
 {
 	Tables tables;
 	uint8_t tile[kTileRows * kTileStride];     // reconstruction of this CTU + the row above (x = -1 .. 95) + the column to the left
-	uint8_t srcs[64 * 64];                     // source pixels of the CTU (encoder)
+	uint8_t srcs[ENCODE ? 64 * 64 : 16];       // source pixels of the CTU (encoder)
+	int16_t levs[ENCODE ? 8 : 64 * 64];        // the CTU's levels as they lie in memory: 16 per 4x4 cell in z-scan order (decoder)
 	uint8_t done[16 * 16];                     // per 4x4 cell: reconstructed
-	uint32_t dig[kMaxCtuTus];                  // the CTU's TUs, digested once when the list is fetched: valid << 31 | z-scan index << 16 | mode << 10 | (log2 - 2) << 8 | (ty / 4) << 4 | tx / 4
 	uint8_t raw[144], flt[144];                // compact neighbour record, and its smoothed form: [2N - 1 - y] left, [2N + x] top, [4N] corner
 	uint8_t ref[128];                          // predictor scratch (intra_predict.hpp)
 	uint8_t ptile[32 * 32];
@@ -180,7 +183,7 @@ struct CtuView
 
 // H.265 6.4.1 / 8.4.4.2.2 for a sample at CTU-local (px, py) as the TU now being predicted sees it.  No branches: a lone wave pays an issue slot for every
 // exec-mask instruction around a lane conditional, and this runs once per TU.
-__device__ __forceinline__ bool sample_available(const CtuLds &L, const CtuView &v, int px, int py)
+template <typename LDS> __device__ __forceinline__ bool sample_available(const LDS &L, const CtuView &v, int px, int py)
 {
 	const int gx = v.x0 + px, gy = v.y0 + py;
 	const bool in_picture = (unsigned)gx < (unsigned)v.frame_w & (unsigned)gy < (unsigned)v.frame_h;
@@ -191,13 +194,13 @@ __device__ __forceinline__ bool sample_available(const CtuLds &L, const CtuView 
 	return in_picture & (above | left | (inside & (L.done[cell] != 0)));
 }
 
-__device__ __forceinline__ uint8_t &tile_at(CtuLds &L, int px, int py) { return L.tile[(py + 1) * kTileStride + px + 16]; }
+template <typename LDS> __device__ __forceinline__ uint8_t &tile_at(LDS &L, int px, int py) { return L.tile[(py + 1) * kTileStride + px + 16]; }
 
 // The 4N + 1 neighbouring samples of the N x N TU at CTU-local (tx, ty) into L.raw, unavailable ones substituted.  A lane takes one UNIT in the text's search
 // order -- lanes 0 .. N/2 - 1: four samples of the left column, bottom-up; lane N/2: the corner; lanes N/2 + 1 .. N: four samples of the top row --
 // because availability is a property of 4x4 cells.  Substitution: an unavailable unit repeats the LAST sample of the nearest available unit before it in
 // search order; the units before the first available one repeat its FIRST sample; nothing available: 128.
-template <int N> __device__ __forceinline__ void build_neighbours(CtuLds &L, const CtuView &v, int tx, int ty, int lane)
+template <int N, typename LDS> __device__ __forceinline__ void build_neighbours(LDS &L, const CtuView &v, int tx, int ty, int lane)
 {
 	constexpr int U = N / 2;
 	bool have = false;
@@ -229,7 +232,7 @@ template <int N> __device__ __forceinline__ void build_neighbours(CtuLds &L, con
 
 // H.265 8.4.4.2.3 on the record: [1 2 1] / 4 along the run left column (bottom-up) - corner - top row, end samples kept; 32x32 with strong smoothing and two
 // flat edges: the bi-linear form
-template <int N> __device__ __forceinline__ void smooth_neighbours(CtuLds &L, int strong, int lane)
+template <int N, typename LDS> __device__ __forceinline__ void smooth_neighbours(LDS &L, int strong, int lane)
 {
 	const int corner = L.raw[4 * N];
 	bool bi = false;
@@ -263,10 +266,12 @@ __device__ __forceinline__ int wave_or(int v)
 }
 
 // One TU, start to finish.  (tx, ty): position inside the CTU.
-template <int N>
-__device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, const IntraFramesArgs &A, uint8_t *recon, uint8_t *pred_out, bool encode,
+// lev: the TU's N x N levels -- in global memory (encoder: written) or in the CTU's LDS copy (decoder: read)
+template <int N, bool ENCODE>
+__device__ __forceinline__ void reconstruct_tu(CtuLds<ENCODE> &L, const CtuView &v, const IntraFramesArgs &A, uint8_t *recon, uint8_t *pred_out,
 	int tx, int ty, int mode, int16_t *lev, int *cbf_out, int lane)
 {
+	constexpr bool encode = ENCODE;
 	constexpr int PX = IntraGeom<N>::PX, LPB = IntraGeom<N>::LPB, LOG2 = IntraGeom<N>::LOG2, P = N + 4;
 	const bool luma = A.cIdx == 0;
 
@@ -325,21 +330,25 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 #endif
 	}
 
-	// quantise (encoder) or fetch (decoder) the lane's PX levels; dequantise; the dequantised coefficients go to buf_b TRANSPOSED (the inverse passes sum along rows)
+	// quantise (encoder) or fetch (decoder) the lane's levels; dequantise; the dequantised coefficients go to buf_b TRANSPOSED (the inverse passes sum along rows).
+	// These steps are per coefficient, so ALL 64 lanes share them: QPX = N * N / 64 consecutive coefficients of a row each (8x8: 1, 16x16: 4, 32x32: 16) -- dealt
+	// like the pixels (PX a lane, N * N / PX lanes) an 8x8 TU kept 8 lanes busy with 8 coefficients each, one after the other, and a 16x16 TU 16 with 16:
+	// a quarter of the TU's time (profiles/r06_intra_knockout_split.txt).  (4x4 TUs come here only under -DIF_TU4_GENERAL: 16 lanes, one coefficient each.)
+	constexpr int QPX = N == 4 ? 1 : N * N / kLanes;
+	const bool q_owner = QPX * lane < N * N;
+	const int qr = q_owner ? QPX * lane / N : 0, qc0 = q_owner ? QPX * lane % N : 0;
 	int cbf = 0;
 #ifndef IF_KNOCK_QUANT
-	if (owner)
+	if (q_owner)
 	{
-		int level[PX];
+		int level[QPX];
 		if (encode)
 		{
-			const uint32_t *a32 = reinterpret_cast<const uint32_t *>(L.buf_a + r * P + c0);
 			const int offset = q.q_offset << (q.q_shift - 16);
 #pragma unroll
-			for (int b = 0; b < PX; ++b)
+			for (int b = 0; b < QPX; ++b)
 			{
-				const uint32_t pair = a32[b / 2];
-				int x = (b & 1) ? (int)pair >> 16 : (int)(int16_t)(pair & 0xffff);
+				int x = L.buf_a[qr * P + qc0 + b];
 				const bool neg = x < 0;
 				x = neg ? -x : x;                                           // abs(-32768) = 32768 in int (quantize.c:176)
 				x = (__mul24(x, q.q_scale) + offset) >> q.q_shift;               // both factors below 2^16 (quantize.c:162-168): the full-rate 24-bit multiply is exact
@@ -348,43 +357,29 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 				cbf |= x;
 				level[b] = x;
 			}
-			// 2 PX bytes of levels, contiguous: one store for 4x4 / 8x8 lanes (8 / 16 bytes), two of 16 bytes above
-			if constexpr (PX <= 8)
-			{
-				Chunk<2 * PX> both;
-#pragma unroll
-				for (int k = 0; k < PX / 2; ++k) both.d[k] = pack16(level[2 * k], level[2 * k + 1]);
-				both.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
-			}
+			// 2 QPX bytes of levels, contiguous over the lanes
+			if constexpr (QPX == 1) lev[qr * N + qc0] = (int16_t)level[0];
 			else
 			{
-				Chunk<PX> lo, hi;
 #pragma unroll
-				for (int k = 0; k < PX / 4; ++k)
+				for (int h = 0; h < QPX; h += 8)
 				{
-					lo.d[k] = pack16(level[2 * k], level[2 * k + 1]);
-					hi.d[k] = pack16(level[PX / 2 + 2 * k], level[PX / 2 + 2 * k + 1]);
+					Chunk<(QPX < 8 ? 2 * QPX : 16)> piece;
+#pragma unroll
+					for (int k = 0; k < (QPX < 8 ? QPX : 8) / 2; ++k) piece.d[k] = pack16(level[h + 2 * k], level[h + 2 * k + 1]);
+					piece.store(reinterpret_cast<uint8_t *>(lev + qr * N + qc0 + h));
 				}
-				lo.store(reinterpret_cast<uint8_t *>(lev + r * N + c0));
-				hi.store(reinterpret_cast<uint8_t *>(lev + r * N + c0 + PX / 2));
 			}
 		}
 		else
 		{
-			Chunk<PX> lo, hi;
-			lo.load(reinterpret_cast<const uint8_t *>(lev + r * N + c0));
-			hi.load(reinterpret_cast<const uint8_t *>(lev + r * N + c0 + PX / 2));
 #pragma unroll
-			for (int k = 0; k < PX / 4; ++k)
-			{
-				level[2 * k] = (int)(int16_t)(lo.d[k] & 0xffff); level[2 * k + 1] = (int)lo.d[k] >> 16;
-				level[PX / 2 + 2 * k] = (int)(int16_t)(hi.d[k] & 0xffff); level[PX / 2 + 2 * k + 1] = (int)hi.d[k] >> 16;
-			}
+			for (int b = 0; b < QPX; ++b) level[b] = lev[qr * N + qc0 + b];      // (the CTU's LDS copy)
 		}
 		const int dq_add = 1 << (q.dq_shift - 1);
 #pragma unroll
-		for (int b = 0; b < PX; ++b)
-			L.buf_b[(c0 + b) * P + r] = (int16_t)clip3(-32768, 32767, (__mul24(level[b], q.dq_scale) + dq_add) >> q.dq_shift);      // int16 x int16: exact in 24-bit factors
+		for (int b = 0; b < QPX; ++b)
+			L.buf_b[(qc0 + b) * P + qr] = (int16_t)clip3(-32768, 32767, (__mul24(level[b], q.dq_scale) + dq_add) >> q.dq_shift);      // int16 x int16: exact in 24-bit factors
 	}
 	if (encode && cbf_out)
 	{
@@ -431,6 +426,213 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds &L, const CtuView &v, cons
 	wave_sync();
 }
 
+// ---- 4x4 TUs entirely in registers (round 6, second form) ---------------------------------------------------------------------------------------------
+//
+// A 4x4 TU through the general path above is a dozen dependent LDS round trips (record, reference array, tile transposes, four transform passes) and about
+// 700 instructions -- for 16 pixels, on a wave that is alone on its SIMD: 1.5 us, and a mixed frame's CTU is mostly 4x4 TUs.  Here lane 4 y + x owns pixel
+// (x, y) (lanes 16 .. 63 mirror lanes 0 .. 15: same values, only lanes 0 .. 15 store):
+//   * lane j <= 16 reads neighbour sample j in the text's search order (0 .. 7 left column bottom-up, 8 corner, 9 .. 16 top row) and its availability: ONE LDS
+//     round trip, shared with the source pixel; a ballot gives the availability mask;
+//   * every pixel needs two neighbour samples (a, b) whatever the mode: their record indices are arithmetic on (mode, x, y), substitution (8.4.4.2.2) is
+//     arithmetic on the mask (the nearest available sample below in search order, else the lowest available one), and the samples arrive by ds_bpermute from
+//     the lanes that hold them: the SECOND and last round trip.  No neighbour record, no reference array, no transposition (a horizontal mode is the vertical
+//     one with x and y exchanged in the index arithmetic);
+//   * the four 1-D transform passes are DPP: a horizontal pass reads the quad's four lanes (quad_perm broadcasts), a vertical pass the lanes 4, 8, 12 further
+//     round the row of 16 (row_ror), against per-lane weights held in registers for the whole kernel.
+// Same integer arithmetic as the general path, step for step (truncating forward stores, int16 clips of the inverse passes, the int16 narrowing before the
+// final clip); tests/test_intra_frames.py and the golden iframe_* cases run through it.
+struct Tu4Lane
+{
+	int x, y;                  // the lane's pixel
+	int ndx, ndy;              // neighbour sample min(lane, 16) relative to the TU's origin
+	int wfh[4], wfv[4];        // forward: horizontal pass W[x][k]; vertical pass W[y][(y - k) & 3] (the lane k rows up the rotation)
+	int wiv[4], wih[4];        // inverse: vertical pass M[(y - k) & 3][y]; horizontal pass M[k][x]
+	ptrdiff_t at;              // the pixel's offset from the TU's first in the reconstructed plane
+};
+
+__device__ __forceinline__ Tu4Lane make_tu4_lane(int lane, bool dst, ptrdiff_t stride_recon)
+{
+	Tu4Lane K;
+	K.x = lane & 3; K.y = (lane >> 2) & 3;
+	K.at = K.y * stride_recon + K.x;
+	const int j = min(lane, 16);
+	K.ndx = j <= 8 ? -1 : j - 9;
+	K.ndy = j < 8 ? 7 - j : -1;
+	// (narrowed to a signed char, which every coefficient of the two 4x4 matrices fits: the compiler then KNOWS the factor is small and multiplies with the
+	// full-rate 24-bit instruction; an int of unknown range made it a quarter-rate v_mul_lo_u32 per tap)
+	auto M = [&](int b, int i) { return (int)(signed char)(dst ? (int)kDst4[b][i] : (int)kDctDevice.m[8 * b][i]); };
+#pragma unroll
+	for (int k = 0; k < 4; ++k)
+	{
+		K.wfh[k] = M(K.x, k);
+		K.wfv[k] = M(K.y, (K.y - k) & 3);
+		K.wiv[k] = M((K.y - k) & 3, K.y);
+		K.wih[k] = M(k, K.x);
+	}
+	return K;
+}
+
+// Diagnostic build only (-DIF_STAMPS, tools/jobs/r06_intra_stamps.sh): s_memtime deltas of the 4x4 path's phases, summed over all waves into a buffer nothing else reads
+#ifdef IF_STAMPS
+__device__ unsigned long long g_if_stamps[8];
+__device__ unsigned long long *g_if_acc_dummy;
+#define IF_STAMP(k) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if_acc[k] += now_ - last_; last_ = now_; } while (0)
+#define IF_STAMP_ARG , unsigned long long (&if_acc)[4]
+#define IF_STAMP_PASS , if_acc
+#define IF_STAMP_BEGIN() unsigned long long last_ = __builtin_amdgcn_s_memtime()
+#else
+#define IF_STAMP(k) do { } while (0)
+#define IF_STAMP_BEGIN() do { } while (0)
+#define IF_STAMP_ARG
+#define IF_STAMP_PASS
+#endif
+
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+// sum_k w[k] * (the value of lane k of this lane's quad)
+__device__ __forceinline__ int quad_dot(int v, const int (&w)[4])
+{
+	return __mul24(w[0], dpp<0x00>(v)) + __mul24(w[1], dpp<0x55>(v)) + __mul24(w[2], dpp<0xaa>(v)) + __mul24(w[3], dpp<0xff>(v));
+}
+// sum_k w[k] * (the value of the lane 4 k below this one, round the row of 16)
+__device__ __forceinline__ int column_dot(int v, const int (&w)[4])
+{
+	return __mul24(w[0], v) + __mul24(w[1], dpp<0x124>(v)) + __mul24(w[2], dpp<0x128>(v)) + __mul24(w[3], dpp<0x12c>(v));      // row_ror:4, 8, 12
+}
+
+// angles: intra_angle(mode) in the low half, intra_inv_angle(mode) (0 unless the angle is negative) in the high half -- digested with the TU list
+template <bool ENCODE>
+__device__ __forceinline__ void reconstruct_tu4(CtuLds<ENCODE> &L, const CtuView &v, const IntraFramesArgs &A, const Tu4Lane &K, uint8_t *recon, uint8_t *pred_out,
+	int tx, int ty, int mode, uint32_t angles, int16_t *lev, int *cbf_out, int lane IF_STAMP_ARG)
+{
+	constexpr bool encode = ENCODE;
+	IF_STAMP_BEGIN();
+	const bool luma = A.cIdx == 0;
+	const hevcasm_hip_intra_qp q = A.qp[0];
+	int level = 0;
+	if (!encode) level = lev[lane & 15];      // (decoder: from the CTU's LDS copy)
+
+	// neighbour sample min(lane, 16), its availability, the lane's source pixel: one round trip
+	// (sample_available() spelled out so that its LDS read is issued WITH the other two; the scheduling barrier keeps the compiler from sinking them behind the wait)
+	const int px = tx + K.ndx, py = ty + K.ndy;
+	const bool in_picture = (unsigned)(v.x0 + px) < (unsigned)v.frame_w & (unsigned)(v.y0 + py) < (unsigned)v.frame_h;
+	const bool above = py < 0, beside = !above & (px < 0) & (py < v.ctu), inside = !above & (px >= 0) & (px < v.ctu) & (py < v.ctu);
+	const int nb = tile_at(L, px, py);
+	const int src_px = L.srcs[(ty + K.y) * 64 + tx + K.x];
+	const int cell_done = L.done[inside ? (py >> 2) * 16 + (px >> 2) : 0];
+	__builtin_amdgcn_sched_barrier(0);
+	const bool have = in_picture & (above | beside | (inside & (cell_done != 0))) & (lane <= 16);
+	const uint32_t m = (uint32_t)__ballot(have);      // 17 bits
+	IF_STAMP(0);
+	const int lowest = m ? __builtin_ctz(m) : 0;
+	// record index -> the lane whose sample stands in for it (8.4.4.2.2 per sample: availability is per 4-sample unit, so "the last sample of the nearest
+	// available unit below" is the nearest available sample below, and "the first sample of the first available unit" the lowest available sample)
+	auto stand_in = [&](int i) { const uint32_t t = m & ((2u << i) - 1u); return t ? 31 - (int)__clz(t) : lowest; };
+	// (& 0xff: a sample IS a byte, and the compiler must know it to multiply at full rate)
+	auto fetch = [&](int i) { const int s = __builtin_amdgcn_ds_bpermute(stand_in(i) << 2, nb) & 0xff; return m ? s : 128; };
+	auto fetch_uniform = [&](int i) { const int s = __builtin_amdgcn_readlane(nb, __builtin_amdgcn_readfirstlane(stand_in(i))) & 0xff; return m ? s : 128; };
+
+	int pred;
+	if (mode >= 2)
+	{
+		// 8.4.4.2.6 in family space: row fv, column fu; reference entry r >= 0 is the corner (0) and the main edge (r - 1), r < 0 the other edge projected
+		const int angle = (int)(int16_t)(angles & 0xffffu), inv = (int)angles >> 16;
+		const bool vertical = mode >= 18;
+		// (the main edge runs up the record -- top row, 9 .. -- or down it -- left column, 7 ..)
+		const int fv = vertical ? K.y : K.x, fu = vertical ? K.x : K.y;
+		const int tt = (fv + 1) * angle, idx = tt >> 5, f = tt & 31;
+		const int r = fu + idx + 1;
+		auto record = [&](int r)      // (selects only)
+		{
+			const int k = min((__mul24(r, inv) + 128) >> 8, 8), along = r >= 0 ? r : -k;
+			return min(max(8 + (vertical ? along : -along), 0), 16);
+		};
+		const int a = fetch(record(r));
+		const int b = fetch(angle == 0 ? 8 - (vertical ? fv + 1 : -(fv + 1)) : record(r + 1));      // (modes 10 / 26: b has weight 0 and carries the other edge's sample for the boundary filter)
+		pred = ((32 - f) * a + f * b + 16) >> 5;
+		if (luma && angle == 0)
+		{
+			const int corner = fetch_uniform(8);
+			pred = fu == 0 ? clip3(0, 255, a + ((b - corner) >> 1)) : pred;
+		}
+	}
+	else if (mode == 0)
+	{
+		const int left = fetch(7 - K.y), top = fetch(9 + K.x), tn = fetch_uniform(13), ln = fetch_uniform(3);      // 8.4.4.2.4
+		pred = ((3 - K.x) * left + (K.x + 1) * tn + (3 - K.y) * top + (K.y + 1) * ln + 4) >> 3;
+	}
+	else
+	{
+		const int top = fetch(9 + K.x), left = fetch(7 - K.y);      // pred_intra.c:68-103
+		int st = top + dpp<0xb1>(top);       // top depends on x only: the quad's sum is the row's
+		st += dpp<0x4e>(st);
+		int sl = left + dpp<0x124>(left);    // left depends on y only: round the row of 16 in steps of 4
+		sl += dpp<0x128>(sl);
+		const int dc = (st + sl + 4) >> 3;
+		pred = dc;
+		if (luma)
+		{
+			const int edge = K.y == 0 ? top : left;
+			const int filtered = (K.x == 0 & K.y == 0) ? (left + 2 * dc + top + 2) >> 2 : (edge + 3 * dc + 2) >> 2;
+			pred = (K.x == 0 | K.y == 0) ? filtered : dc;
+		}
+	}
+
+	int cbf = 0;
+#ifdef IF_STAMPS
+	pred = __builtin_amdgcn_readfirstlane(pred) == 0x7fffffff ? 0 : pred;      // (forces the prediction to be complete at the stamp)
+#endif
+	IF_STAMP(1);
+	if (encode)
+	{
+		// residual_decode.c:855-892 (4x4: :592-610 for the DST): rows with shift 1, columns with shift 8, both stored as int16 (truncating)
+		// The reference stores both intermediates as int16 (truncating).  For 4x4 blocks of 8-bit video nothing is ever cut off: |residual| <= 255 and the largest
+		// absolute row sum of either matrix is 256 (DCT) / 242 (DST), so |first pass| <= (256 * 255 + 1) >> 1 = 32640 and |second pass| <= (256 * 32640 + 128) >> 8
+		// = 32640: the casts are identities and are left out (written out, the compiler folded shift + cast into the weights -- w << 15 -- which no longer
+		// fit the full-rate 24-bit multiply).
+		const int t1 = (quad_dot(src_px - pred, K.wfh) + 1) >> 1;
+		const int c = (column_dot(t1, K.wfv) + 128) >> 8;
+		// quantize.c:160-186
+		const bool neg = c < 0;
+		int x = neg ? -c : c;
+		x = (__mul24(x, q.q_scale) + (q.q_offset << (q.q_shift - 16))) >> q.q_shift;
+		x = neg ? -x : x;
+		level = clip3(-32768, 32767, x);
+		cbf = level;
+	}
+	// quantize.c:53-62, then residual_decode.c:371-413: columns with shift 7, rows with shift 12, both clipped to int16
+	const int d = clip3(-32768, 32767, (__mul24(level, q.dq_scale) + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+	const int x1 = clip3(-32768, 32767, (column_dot(d, K.wiv) + 64) >> 7);
+	const int res = clip3(-32768, 32767, (quad_dot(x1, K.wih) + 2048) >> 12);
+	const int rec = clip3(0, 255, (int)(int16_t)(pred + res));      // hevcasm_clip narrows to int16 first (residual_decode.c:350-356, :365)
+	if (encode && cbf_out)
+	{
+		cbf |= dpp<0xb1>(cbf);
+		cbf |= dpp<0x4e>(cbf);
+		cbf |= dpp<0x141>(cbf);
+		cbf |= dpp<0x140>(cbf);
+		cbf = __builtin_amdgcn_readlane(cbf, 0);      // (the OR of the sixteen levels, as the general path reports it)
+	}
+#ifdef IF_STAMPS
+	if (__builtin_amdgcn_readfirstlane(rec) == 0x7fffffff) return;
+#endif
+	IF_STAMP(2);
+	if (lane < 16)
+	{
+		tile_at(L, tx + K.x, ty + K.y) = (uint8_t)rec;
+		const ptrdiff_t at = (ptrdiff_t)(v.y0 + ty) * A.stride_recon + (v.x0 + tx) + K.at;      // (a scalar product + the lane's constant)
+		recon[at] = (uint8_t)rec;
+		if (pred_out) pred_out[at] = (uint8_t)pred;
+		if (encode) lev[lane] = (int16_t)level;
+		if (lane == 0)
+		{
+			L.done[(ty >> 2) * 16 + (tx >> 2)] = 1;
+			if (encode && cbf_out) *cbf_out = cbf;
+		}
+	}
+	wave_sync();
+	IF_STAMP(3);
+}
+
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
@@ -458,15 +660,17 @@ __global__ __launch_bounds__(256) void intra_frames_order_kernel(uint32_t *order
 	order[before * n_frames + f * in_step + (uint32_t)(cy - jmin)] = (f << 20) | ((uint32_t)cy << 10) | (uint32_t)cx;
 }
 
+template <bool ENCODE>
 __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesArgs A)
 {
-	__shared__ __attribute__((aligned(16))) CtuLds L;
+	__shared__ __attribute__((aligned(16))) CtuLds<ENCODE> L;
 	const int lane = (int)threadIdx.x;
 	const int ctu = A.ctu, per_edge = ctu / 4;
 	const uint32_t n_ctus = (uint32_t)A.cols * A.rows;
-	const bool encode = A.src != nullptr;
+	constexpr bool encode = ENCODE;
 	build_tables(L.tables, lane);
 	wave_sync();
+	const Tu4Lane K4 = make_tu4_lane(lane, A.cIdx == 0, A.stride_recon);      // trType 1 (DST-VII) for 4x4 luma blocks of intra CUs
 
 	for (;;)
 	{
@@ -485,10 +689,16 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 
 		// the CTU's TU list and source pixels: requested before the wait for the neighbours, they land meanwhile
 		// (each lane checks and digests its TUs here, all at once, so that the TU loop -- a chain on ONE wave -- starts a TU with one LDS read and a few bit-field extracts)
+		uint32_t digs[kMaxCtuTus / kLanes];      // TU i of the CTU: lane i % 64 of register i / 64 (the loop below fetches it with one v_readlane: no LDS round trip per TU)
+		uint32_t angs[kMaxCtuTus / kLanes];      // its mode's angle and inverse angle (reconstruct_tu4): 40 scalar instructions per TU when derived in the TU loop
 		{
 			bool bad = false;
-			for (uint32_t i = lane; i < n_tus; i += kLanes)
+#pragma unroll
+			for (int k = 0; k < kMaxCtuTus / kLanes; ++k)
 			{
+				const uint32_t i = (uint32_t)(k * kLanes + lane);
+				digs[k] = 0; angs[k] = 0;
+				if (i >= n_tus) continue;
 				const hevcasm_hip_intra_tu d = A.tus[first + i];
 				const int log2n = d.log2TrafoSize, mode = d.intraPredMode, tx = (int)d.x - v.x0, ty = (int)d.y - v.y0, n = 1 << (log2n & 7);
 				const bool good = log2n >= 2 && log2n <= 5 && n <= ctu && mode <= 34 && tx >= 0 && ty >= 0 && tx + n <= ctu && ty + n <= ctu && tx % n == 0 && ty % n == 0 &&
@@ -497,12 +707,15 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 				uint32_t z = 0;      // z-scan index of the TU's first 4x4 cell inside the CTU: where its levels lie
 #pragma unroll
 				for (int b = 0; b < 4; ++b) z |= ((ux >> b) & 1u) << (2 * b) | ((uy >> b) & 1u) << (2 * b + 1);
-				L.dig[i] = good ? (1u << 31) | (z << 16) | ((uint32_t)mode << 10) | ((uint32_t)(log2n - 2) << 8) | (uy << 4) | ux : 0u;
+				// valid << 31 | z-scan index << 16 | mode << 10 | (log2 - 2) << 8 | (ty / 4) << 4 | tx / 4
+				digs[k] = good ? (1u << 31) | (z << 16) | ((uint32_t)mode << 10) | ((uint32_t)(log2n - 2) << 8) | (uy << 4) | ux : 0u;
+				const int angle = mode >= 2 && mode <= 34 ? intra_angle(mode) : 0;
+				angs[k] = ((uint32_t)angle & 0xffffu) | ((uint32_t)(angle < 0 ? intra_inv_angle(mode) : 0) << 16);
 				bad |= !good;
 			}
 			if (__any(bad) && lane == 0) __hip_atomic_fetch_or((gu32 *)(A.head + 1), kStatusBadTu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a malformed TU is skipped and flagged
 		}
-		if (encode)
+		if constexpr (encode)
 		{
 			const uint8_t *src = A.src + f * A.pitch_src;
 			for (int e = lane; e < ctu * ctu / 4; e += kLanes)      // dword pieces (the picture edge is a multiple of 4, rows need not be 16-byte multiples)
@@ -511,6 +724,12 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 				if (v.x0 + x < A.frame_w && v.y0 + y < A.frame_h)
 					*reinterpret_cast<uint32_t *>(L.srcs + y * 64 + x) = reinterpret_cast<const U1 *>(src + (ptrdiff_t)(v.y0 + y) * A.stride_src + v.x0 + x)->v;
 			}
+		}
+		int16_t *ctu_levels = A.levels + ((size_t)f * n_ctus + c) * (size_t)(ctu * ctu);
+		if constexpr (!encode)
+		{
+			for (int e = lane; e < ctu * ctu / 8; e += kLanes)      // 16-byte pieces; the CTU's block of the level array is ctu * ctu entries whatever the picture edge cuts off
+				*reinterpret_cast<u32x4 *>(L.levs + 8 * e) = reinterpret_cast<const U4 *>(ctu_levels + 8 * e)->v;
 		}
 		for (int e = lane; e < 256 / 4; e += kLanes) reinterpret_cast<uint32_t *>(L.done)[e] = 0;
 
@@ -561,24 +780,46 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 		}
 		wave_sync();
 
-		int16_t *ctu_levels = A.levels + ((size_t)f * n_ctus + c) * (size_t)(ctu * ctu);
+		uint32_t holder = 0, holder_angles = 0;
+#ifdef IF_STAMPS
+		const unsigned long long loop_t0 = __builtin_amdgcn_s_memtime();
+		unsigned long long if_acc[4] = { 0, 0, 0, 0 };
+#endif
 		for (uint32_t i = 0; i < n_tus; ++i)
 		{
-			const uint32_t d = (uint32_t)__builtin_amdgcn_readfirstlane((int)L.dig[i]);
+			if (i % kLanes == 0)      // (every 64th TU: the registers that hold the next 64)
+			{
+				const uint32_t which = i / kLanes;
+				holder = which == 0 ? digs[0] : which == 1 ? digs[1] : which == 2 ? digs[2] : digs[3];
+				holder_angles = which == 0 ? angs[0] : which == 1 ? angs[1] : which == 2 ? angs[2] : angs[3];
+			}
+			const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)holder, (int)(i % kLanes));
+			const uint32_t angles = (uint32_t)__builtin_amdgcn_readlane((int)holder_angles, (int)(i % kLanes));
 			if (!(d >> 31)) continue;
 			const int tx = (int)(d & 15u) << 2, ty = (int)((d >> 4) & 15u) << 2, log2n = (int)((d >> 8) & 3u) + 2, mode = (int)((d >> 10) & 63u);
 			const uint32_t z = (d >> 16) & 255u;
-			int16_t *lev = ctu_levels + 16u * z;
+			int16_t *lev = (encode ? ctu_levels : L.levs) + 16u * z;
 			int *cbf_out = A.cbf ? A.cbf + first + i : nullptr;
 			switch (log2n)
 			{
-			case 2: reconstruct_tu<4>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
-			case 3: reconstruct_tu<8>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
-			case 4: reconstruct_tu<16>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
-			default: reconstruct_tu<32>(L, v, A, recon, pred_out, encode, tx, ty, mode, lev, cbf_out, lane); break;
+#ifndef IF_TU4_GENERAL
+			case 2: reconstruct_tu4<ENCODE>(L, v, A, K4, recon, pred_out, tx, ty, mode, angles, lev, cbf_out, lane IF_STAMP_PASS); break;
+#else
+			case 2: reconstruct_tu<4, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;      // (A/B switch: the general path for 4x4 too)
+#endif
+			case 3: reconstruct_tu<8, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
+			case 4: reconstruct_tu<16, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
+			default: reconstruct_tu<32, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
 			}
 		}
 
+#ifdef IF_STAMPS
+		if (lane == 0)
+		{
+			atomicAdd(&g_if_stamps[4], __builtin_amdgcn_s_memtime() - loop_t0); atomicAdd(&g_if_stamps[5], (unsigned long long)n_tus);
+			for (int k = 0; k < 4; ++k) atomicAdd(&g_if_stamps[k], if_acc[k]);
+		}
+#endif
 		// publish: bottom row, then right column; four samples + the tag in one 8-byte store each (written once, by this lane only)
 		{
 			unsigned long long *mine = A.granules + ((size_t)f * n_ctus + c) * 2 * per_edge;
@@ -672,9 +913,10 @@ extern "C" int hevcasm_hip_intra_reconstruct_frames(
 	HEVC_HIP_TRY(hipMemsetAsync(ws, 0, w.order, st));      // ticket counter, status, abort word and every granule's tag: zero before every launch
 	hipLaunchKernelGGL(intra_frames_order_kernel, dim3(ceil_div(w.n_items, 256)), dim3(256), 0, st, a.order, w.cols, w.rows, a.n_frames);
 	if (int e = launch_status("intra_frames_order_kernel")) return e;
-	// single-wave workgroups, 24.4 KiB of LDS each: six per CU; any grid size is correct (tickets), more than the work is pointless
-	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * 6);
-	hipLaunchKernelGGL(intra_frames_kernel, dim3(grid), dim3(kLanes), 0, st, a);
+	// single-wave workgroups, 23.4 KiB of LDS each (decoder: 27.4): six (five) per CU; any grid size is correct (tickets), more than the work is pointless
+	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * (src ? 6 : 5));
+	if (src) hipLaunchKernelGGL(intra_frames_kernel<true>, dim3(grid), dim3(kLanes), 0, st, a);
+	else hipLaunchKernelGGL(intra_frames_kernel<false>, dim3(grid), dim3(kLanes), 0, st, a);
 	return launch_status("intra_frames_kernel");
 }
 
@@ -689,3 +931,12 @@ extern "C" int hevcasm_hip_intra_frames_status(const void *workspace, void *stre
 	if (head[1] & kStatusBadTu) return set_error(HEVCASM_HIP_EINVAL, "intra frames: a malformed TU descriptor was skipped (size, mode, alignment or position)");
 	return 0;
 }
+
+#ifdef IF_STAMPS
+extern "C" int hevcasm_hip_debug_intra_stamps(unsigned long long *out8, int reset)
+{
+	if (out8) HEVC_HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(hevc::g_if_stamps), 64));
+	if (reset) { unsigned long long z[8] = {}; HEVC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hevc::g_if_stamps), z, 64)); }
+	return 0;
+}
+#endif
