@@ -161,8 +161,9 @@ __device__ __forceinline__ void transform_pass(const int16_t *in, int16_t *out, 
 // ---- one CTU's state in LDS ------------------------------------------------------------------------------------------------------------------------
 
 // ENCODE: the kernel is built twice.  The encoder's TU loop then holds no global LOAD at all: on this hardware loads and stores share one counter (vmcnt), and
-// the wait in front of a load's first use also waits for every store issued before it -- the previous TU's reconstruction and levels, about 800 cycles a TU
-// (SQ_WAIT_ANY, profiles/r06_intra_ctu_counters.txt).  The decoder fetches the CTU's levels into LDS with the rest of the CTU's inputs, for the same reason.
+// the wait in front of a load's first use also waits for every store issued before it -- the previous TU's reconstruction and levels (with one kernel for both
+// directions the compiler put such a wait on the encoder's path too, to guard the register the decoder loads into: 4x4 TU 0.79 -> 0.72 us without it).  The
+// decoder fetches the CTU's levels into LDS with the rest of the CTU's inputs, for the same reason; and every `if (encode)` is decided at compile time.
 template <bool ENCODE> struct CtuLds
 {
 	Tables tables;
@@ -633,6 +634,157 @@ __device__ __forceinline__ void reconstruct_tu4(CtuLds<ENCODE> &L, const CtuView
 	IF_STAMP(3);
 }
 
+// ---- 8x8 TUs: neighbours and prediction in registers, one pixel per lane (round 6) -------------------------------------------------------------------
+//
+// The same idea one size up: lane 8 y + x owns pixel (x, y); lane j <= 32 reads neighbour sample j (0 .. 15 left column bottom-up, 16 corner, 17 .. 32 top row).
+// 8x8 TUs can be smoothed (8.4.4.2.3), so the substituted record is materialised first -- sample j in lane j, by ds_bpermute from its stand-in -- smoothed
+// with the two neighbouring lanes (DPP wave_shr / wave_shl), and the pixels gather their two samples from that: three LDS round trips where the general path
+// has about ten (record, reference array, transposing tile).  The transforms stay the general path's LDS passes (a row of 8 does not fit a DPP pattern);
+// residual, quantiser and reconstruction are one element per lane.
+struct Tu8Lane
+{
+	int x, y, j;               // the lane's pixel; its neighbour sample min(lane, 32)
+	int ndx, ndy;              // that sample relative to the TU's origin
+	ptrdiff_t at;              // the pixel's offset from the TU's first in the reconstructed plane
+};
+
+__device__ __forceinline__ Tu8Lane make_tu8_lane(int lane, ptrdiff_t stride_recon)
+{
+	Tu8Lane K;
+	K.x = lane & 7; K.y = lane >> 3; K.j = min(lane, 32);
+	K.ndx = K.j <= 16 ? -1 : K.j - 17;
+	K.ndy = K.j < 16 ? 15 - K.j : -1;
+	K.at = K.y * stride_recon + K.x;
+	return K;
+}
+
+template <bool ENCODE>
+__device__ __forceinline__ void reconstruct_tu8(CtuLds<ENCODE> &L, const CtuView &v, const IntraFramesArgs &A, const Tu8Lane &K, uint8_t *recon, uint8_t *pred_out,
+	int tx, int ty, int mode, uint32_t angles, int16_t *lev, int *cbf_out, int lane)
+{
+	constexpr bool encode = ENCODE;
+	constexpr int N = 8, P = N + 4;
+	const bool luma = A.cIdx == 0;
+	const hevcasm_hip_intra_qp q = A.qp[1];
+
+	// round trip 1: neighbour sample, its availability, the source pixel
+	const int px = tx + K.ndx, py = ty + K.ndy;
+	const bool in_picture = (unsigned)(v.x0 + px) < (unsigned)v.frame_w & (unsigned)(v.y0 + py) < (unsigned)v.frame_h;
+	const bool above = py < 0, beside = !above & (px < 0) & (py < v.ctu), inside = !above & (px >= 0) & (px < v.ctu) & (py < v.ctu);
+	const int nb = tile_at(L, px, py);
+	const int src_px = encode ? L.srcs[(ty + K.y) * 64 + tx + K.x] : 0;
+	const int cell_done = L.done[inside ? (py >> 2) * 16 + (px >> 2) : 0];
+	__builtin_amdgcn_sched_barrier(0);
+	const bool have = in_picture & (above | beside | (inside & (cell_done != 0))) & (lane <= 32);
+	const unsigned long long m = __ballot(have);      // 33 bits
+	const uint32_t m_lo = (uint32_t)m;
+	const bool last_there = (m >> 32) != 0;
+
+	// round trip 2: the substituted record (8.4.4.2.2, per sample as in reconstruct_tu4), sample j in lane j; then 8.4.4.2.3 on it
+	const uint32_t t = m_lo & ((2u << min(K.j, 31)) - 1u);
+	int stand_in = t ? 31 - (int)__clz(t) : (m_lo ? __builtin_ctz(m_lo) : 32);
+	stand_in = (K.j == 32 & last_there) ? 32 : stand_in;
+	int sample = __builtin_amdgcn_ds_bpermute(stand_in << 2, nb) & 0xff;
+	sample = m ? sample : 128;
+	const int dist = min(abs(mode - 26), abs(mode - 10));
+	const bool filter = luma & (mode != 1) & (dist > 7);      // filterFlag for 8x8 luma: planar and the three diagonals
+	const int smooth = (dpp<0x138>(sample) /* wave_shr:1 = lane j - 1 */ + 2 * sample + dpp<0x130>(sample) /* wave_shl:1 = lane j + 1 */ + 2) >> 2;
+	const int use = (filter & (K.j != 0) & (K.j != 32)) ? smooth : sample;
+
+	// round trip 3: each pixel's two samples
+	auto fetch = [&](int i) { return __builtin_amdgcn_ds_bpermute(i << 2, use) & 0xff; };
+	int pred;
+	if (mode >= 2)
+	{
+		const int angle = (int)(int16_t)(angles & 0xffffu), inv = (int)angles >> 16;
+		const bool vertical = mode >= 18;
+		const int fv = vertical ? K.y : K.x, fu = vertical ? K.x : K.y;
+		const int tt = (fv + 1) * angle, idx = tt >> 5, f = tt & 31;
+		const int r = fu + idx + 1;
+		auto record = [&](int r)
+		{
+			const int k = min((__mul24(r, inv) + 128) >> 8, 16), along = r >= 0 ? r : -k;
+			return min(max(16 + (vertical ? along : -along), 0), 32);
+		};
+		const int a = fetch(record(r));
+		const int b = fetch(angle == 0 ? 16 - (vertical ? fv + 1 : -(fv + 1)) : record(r + 1));
+		pred = ((32 - f) * a + f * b + 16) >> 5;
+		if (luma && angle == 0)
+		{
+			const int corner = __builtin_amdgcn_readlane(use, 16) & 0xff;
+			pred = fu == 0 ? clip3(0, 255, a + ((b - corner) >> 1)) : pred;
+		}
+	}
+	else if (mode == 0)
+	{
+		const int left = fetch(15 - K.y), top = fetch(17 + K.x), tn = __builtin_amdgcn_readlane(use, 25) & 0xff, ln = __builtin_amdgcn_readlane(use, 7) & 0xff;
+		pred = ((7 - K.x) * left + (K.x + 1) * tn + (7 - K.y) * top + (K.y + 1) * ln + 8) >> 4;
+	}
+	else
+	{
+		const int top = fetch(17 + K.x), left = fetch(15 - K.y);
+		int st = top + dpp<0xb1>(top);       // top depends on x only: quad, then the other quad of the row of 8
+		st += dpp<0x4e>(st);
+		st += dpp<0x141>(st);                // row_half_mirror
+		int sl = left + dpp<0x128>(left);    // left depends on y only: the row's other half (y ^ 1), then the four rows of 16
+		sl = __builtin_amdgcn_readlane(sl, 0) + __builtin_amdgcn_readlane(sl, 16) + __builtin_amdgcn_readlane(sl, 32) + __builtin_amdgcn_readlane(sl, 48);
+		const int dc = (st + sl + 8) >> 4;
+		pred = dc;
+		if (luma)
+		{
+			const int edge = K.y == 0 ? top : left;
+			const int filtered = (K.x == 0 & K.y == 0) ? (left + 2 * dc + top + 2) >> 2 : (edge + 3 * dc + 2) >> 2;
+			pred = (K.x == 0 | K.y == 0) ? filtered : dc;
+		}
+	}
+
+	uint32_t w[N / 2];
+	if (encode)
+	{
+		L.buf_a[K.y * P + K.x] = (int16_t)(src_px - pred);
+		load_weights<N>(L.tables, false, false, lane % N, w);
+		wave_sync();
+		transform_pass<N, false, true>(L.buf_a, L.buf_b, w, 2, lane);
+		wave_sync();
+		transform_pass<N, false, true>(L.buf_b, L.buf_a, w, 9, lane);
+		wave_sync();
+	}
+	int level, cbf = 0;
+	if (encode)
+	{
+		int x = L.buf_a[K.y * P + K.x];
+		const bool neg = x < 0;
+		x = neg ? -x : x;
+		x = (__mul24(x, q.q_scale) + (q.q_offset << (q.q_shift - 16))) >> q.q_shift;
+		x = neg ? -x : x;
+		level = clip3(-32768, 32767, x);
+		lev[lane] = (int16_t)level;
+		cbf = level;
+	}
+	else level = lev[lane];
+	L.buf_b[K.x * P + K.y] = (int16_t)clip3(-32768, 32767, (__mul24(level, q.dq_scale) + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+	if (encode && cbf_out)
+	{
+		cbf = wave_or(cbf);
+		if (lane == 0) *cbf_out = cbf;
+	}
+	load_weights<N>(L.tables, true, false, lane % N, w);
+	wave_sync();
+	transform_pass<N, true, true>(L.buf_b, L.buf_a, w, 7, lane);
+	wave_sync();
+	transform_pass<N, true, false>(L.buf_a, L.buf_b, w, 12, lane);
+	wave_sync();
+
+	const int res = L.buf_b[K.y * P + K.x];
+	const int rec = clip3(0, 255, (int)(int16_t)(pred + res));
+	tile_at(L, tx + K.x, ty + K.y) = (uint8_t)rec;
+	const ptrdiff_t at = (ptrdiff_t)(v.y0 + ty) * A.stride_recon + (v.x0 + tx) + K.at;
+	recon[at] = (uint8_t)rec;
+	if (pred_out) pred_out[at] = (uint8_t)pred;
+	if (lane < 4) L.done[((ty >> 2) + lane / 2) * 16 + (tx >> 2) + lane % 2] = 1;
+	wave_sync();
+}
+
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 typedef __attribute__((address_space(1))) uint32_t gu32;
 
@@ -671,6 +823,7 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 	build_tables(L.tables, lane);
 	wave_sync();
 	const Tu4Lane K4 = make_tu4_lane(lane, A.cIdx == 0, A.stride_recon);      // trType 1 (DST-VII) for 4x4 luma blocks of intra CUs
+	const Tu8Lane K8 = make_tu8_lane(lane, A.stride_recon);
 
 	for (;;)
 	{
@@ -807,7 +960,11 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 #else
 			case 2: reconstruct_tu<4, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;      // (A/B switch: the general path for 4x4 too)
 #endif
+#ifndef IF_TU8_GENERAL
+			case 3: reconstruct_tu8<ENCODE>(L, v, A, K8, recon, pred_out, tx, ty, mode, angles, lev, cbf_out, lane); break;
+#else
 			case 3: reconstruct_tu<8, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
+#endif
 			case 4: reconstruct_tu<16, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
 			default: reconstruct_tu<32, ENCODE>(L, v, A, recon, pred_out, tx, ty, mode, lev, cbf_out, lane); break;
 			}
