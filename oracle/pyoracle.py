@@ -27,6 +27,14 @@ def lib():
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)
+        # The drivers are OpenMP loops.  A GPU box shows the process every core of its host but grants a share of them (a CPU quota): one thread per VISIBLE
+        # core then costs a scheduler period per parallel region -- 0.12 s per call whatever its size, which was 500 of the GPU suite's 550 seconds.  Eight
+        # threads are plenty for test-sized inputs; an explicit OMP_NUM_THREADS wins.  (dlsym through the library's own handle finds its OpenMP runtime.)
+        if "OMP_NUM_THREADS" not in os.environ:
+            try:
+                _LIB.omp_set_num_threads(C.c_int(min(8, os.cpu_count() or 8)))
+            except AttributeError:
+                pass
     return _LIB
 
 

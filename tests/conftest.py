@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The oracle (oracle/liboracle.so) is OpenMP code, and so is part of torch.  On the GPU box the process sees every core of the host but may use a share of
+# them (a CPU quota): a parallel region of one thread per VISIBLE core then runs into the quota and every oracle call costs a scheduler period (measured:
+# 0.12 s per call whatever its size; the GPU suite took 550 s with it and takes 40 s without).  Eight threads are plenty for test-sized inputs.  Set before
+# anything loads an OpenMP runtime; an explicit OMP_NUM_THREADS in the environment wins.  (oracle/pyoracle.py also sets the count through the runtime's API.)
+os.environ.setdefault("OMP_NUM_THREADS", "8")
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
