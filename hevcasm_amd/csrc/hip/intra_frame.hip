@@ -813,7 +813,7 @@ __global__ __launch_bounds__(256) void intra_frames_order_kernel(uint32_t *order
 }
 
 template <bool ENCODE>
-__global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesArgs A)
+__device__ __forceinline__ void intra_frames_body(const IntraFramesArgs &A)
 {
 	__shared__ __attribute__((aligned(16))) CtuLds<ENCODE> L;
 	const int lane = (int)threadIdx.x;
@@ -992,6 +992,22 @@ __global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesA
 	}
 }
 
+// Two builds of the loop.  The encoder's needs 271 registers (256 + 15 spilled to accumulation registers): ONE wave per SIMD, four workgroups per CU -- the fastest
+// form of a wave, and enough waves whenever the wavefront offers at most 4 x CUs CTUs at a time (64 frames of 1080p: 960).  `dense` holds the same code to 256
+// registers (13 spills to scratch, 3 - 6 % slower per wave) so that two waves share a SIMD and six workgroups a CU: what a call of hundreds of frames wants
+// (256 frames of 1080p: 9.2 -> 7.2 ms; 64 frames 4.4 -> 4.7 ms, hence not always: profiles/r06_intra_waves_ab.txt).  The host picks by the call's concurrency.
+template <bool ENCODE>
+__global__ __launch_bounds__(kLanes) void intra_frames_kernel(const IntraFramesArgs A)
+{
+	intra_frames_body<ENCODE>(A);
+}
+
+template <bool ENCODE>
+__global__ __launch_bounds__(kLanes) __attribute__((amdgpu_waves_per_eu(2, 2))) void intra_frames_dense_kernel(const IntraFramesArgs A)
+{
+	intra_frames_body<ENCODE>(A);
+}
+
 }  // namespace hevc
 
 using namespace hevc;
@@ -1070,9 +1086,16 @@ extern "C" int hevcasm_hip_intra_reconstruct_frames(
 	HEVC_HIP_TRY(hipMemsetAsync(ws, 0, w.order, st));      // ticket counter, status, abort word and every granule's tag: zero before every launch
 	hipLaunchKernelGGL(intra_frames_order_kernel, dim3(ceil_div(w.n_items, 256)), dim3(256), 0, st, a.order, w.cols, w.rows, a.n_frames);
 	if (int e = launch_status("intra_frames_order_kernel")) return e;
-	// single-wave workgroups, 23.4 KiB of LDS each (decoder: 27.4): six (five) per CU; any grid size is correct (tickets), more than the work is pointless
-	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, (size_t)device_cus() * (src ? 6 : 5));
-	if (src) hipLaunchKernelGGL(intra_frames_kernel<true>, dim3(grid), dim3(kLanes), 0, st, a);
+	// Single-wave workgroups, 22.4 KiB of LDS each (decoder: 26.4); any grid size is correct (tickets), more than the work is pointless.  The wavefront offers
+	// min(rows, ceil(cols / 2)) CTUs of a frame at a time: when all frames' together fit one wave per SIMD that is the grid (and the one-wave build of the loop),
+	// otherwise every workgroup slot of the device (six per CU, decoder five) with the two-waves-per-SIMD build.
+	const size_t cus = (size_t)device_cus();
+	const size_t concurrency = n_frames * (size_t)std::min(w.rows, (w.cols + 1) / 2);
+	const bool dense = concurrency > 4 * cus;
+	const uint32_t grid = (uint32_t)std::min<size_t>(w.n_items, cus * (dense ? (src ? 6 : 5) : 4));
+	if (src && dense) hipLaunchKernelGGL(intra_frames_dense_kernel<true>, dim3(grid), dim3(kLanes), 0, st, a);
+	else if (src) hipLaunchKernelGGL(intra_frames_kernel<true>, dim3(grid), dim3(kLanes), 0, st, a);
+	else if (dense) hipLaunchKernelGGL(intra_frames_dense_kernel<false>, dim3(grid), dim3(kLanes), 0, st, a);
 	else hipLaunchKernelGGL(intra_frames_kernel<false>, dim3(grid), dim3(kLanes), 0, st, a);
 	return launch_status("intra_frames_kernel");
 }
