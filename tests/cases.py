@@ -548,6 +548,17 @@ def intra_frame_mixed_cases(seed=1800):
     out.append(("iframe_mixed_decode_200x136", "intra_frame", _intra_frame_case(200, 136, 64, seed + 9, "mixed", decode=True, strong=1)))
     for m in (2, 10, 18, 26, 34):
         out.append(("iframe_mode%d_128x64" % m, "intra_frame", _intra_frame_case(128, 64, 64, seed + 10 + m, m, qp=24)))
+    # the register paths of 4x4 and 8x8 TUs (round 6, third form) on their own: every mode, luma (DST / smoothing / edge filters) and chroma, extreme content at
+    # QP 0 (the 4x4 path leaves out the forward passes' int16 casts as provable identities), ragged picture edges, the decoder's half
+    all4, all8 = (1.0, 1.0, 1.0, 1.0), (1.0, 1.0, 1.0, 0.0)
+    out.append(("iframe_mixed_all8x8_noise_136x72", "intra_frame", _intra_frame_case(136, 72, 64, seed + 50, "mixed", split=all8, kind="noise", qp=20)))
+    out.append(("iframe_mixed_all8x8_flat_128x64", "intra_frame", _intra_frame_case(128, 64, 64, seed + 51, "mixed", split=all8, kind="flat", qp=32)))
+    out.append(("iframe_angular_all8x8_chroma_96x72_ctu32", "intra_frame", _intra_frame_case(96, 72, 32, seed + 52, "angular", cidx=1, split=(1.0, 1.0, 0.0))))
+    out.append(("iframe_mixed_all8x8_decode_136x72", "intra_frame", _intra_frame_case(136, 72, 64, seed + 53, "mixed", split=all8, decode=True)))
+    out.append(("iframe_mixed_all4x4_max_qp0_72x40", "intra_frame", _intra_frame_case(72, 40, 64, seed + 54, "mixed", split=all4, kind="max", qp=0)))
+    out.append(("iframe_mixed_all4x4_noise_qp4_100x52_ctu16", "intra_frame", _intra_frame_case(100, 52, 16, seed + 55, "mixed", split=(1.0, 1.0, 1.0), kind="noise", qp=4)))
+    out.append(("iframe_angular_all4x4_chroma_72x40_ctu32", "intra_frame", _intra_frame_case(72, 40, 32, seed + 56, "angular", cidx=1, split=(1.0, 1.0, 1.0))))
+    out.append(("iframe_mixed_all4x4_decode_72x40", "intra_frame", _intra_frame_case(72, 40, 64, seed + 57, "mixed", split=all4, decode=True, qp=12)))
     return out
 
 

@@ -20,14 +20,17 @@ def _oracle_frame(oracle_lib, c, **kw):
                                               c["ctu"], c["cidx"], c["strong"], **kw)
 
 
-@pytest.mark.parametrize("name", ["mixed_strong", "dc", "chroma", "ctu16", "decode"])
+@pytest.mark.parametrize("name", ["mixed_strong", "dc", "chroma", "ctu16", "decode", "all4x4_max_qp0", "all8x8_noise", "all4x4_chroma"])
 def test_oracle_frame_loop_equals_the_python_restatement(name, oracle_lib):
     """Availability, substitution, the smoothing decision, the bi-linear form, DST / edge-filter conditions and the level layout, written twice."""
     c = dict(mixed_strong=lambda: cases._intra_frame_case(96, 72, 64, 11, "mixed", strong=1, split=(1.0, 0.4, 0.5, 0.4), qp=30),
              dc=lambda: cases._intra_frame_case(72, 40, 64, 12, "dc", qp=20),
              chroma=lambda: cases._intra_frame_case(48, 40, 32, 13, "mixed", cidx=1, qp=33),
              ctu16=lambda: cases._intra_frame_case(52, 36, 16, 14, "mixed", qp=26),
-             decode=lambda: cases._intra_frame_case(72, 72, 64, 15, "mixed", decode=True, strong=1))[name]()
+             decode=lambda: cases._intra_frame_case(72, 72, 64, 15, "mixed", decode=True, strong=1),
+             all4x4_max_qp0=lambda: cases._intra_frame_case(40, 24, 64, 16, "mixed", split=(1.0, 1.0, 1.0, 1.0), kind="max", qp=0),
+             all8x8_noise=lambda: cases._intra_frame_case(72, 40, 64, 17, "mixed", split=(1.0, 1.0, 1.0, 0.0), kind="noise", qp=22),
+             all4x4_chroma=lambda: cases._intra_frame_case(40, 24, 32, 18, "angular", cidx=1, split=(1.0, 1.0, 1.0)))[name]()
     enc = c["src"].size > 0
     got = _oracle_frame(oracle_lib, c)
     tus = c["tus"].view(wl.INTRA_TU_DTYPE).reshape(-1)
@@ -37,6 +40,22 @@ def test_oracle_frame_loop_equals_the_python_restatement(name, oracle_lib):
     assert np.array_equal(got[1], lev)
     if enc:
         assert np.array_equal(got[2] != 0, cbf != 0) and np.array_equal(got[2], cbf)
+
+
+def test_forward_4x4_intermediates_fit_int16():
+    """intra_frame.hip's register path for 4x4 TUs leaves out the int16 casts the reference applies to both forward intermediates (residual_decode.c:631-634),
+    as identities.  The bound behind that: |residual| <= 255 for 8-bit video, so |pass 1| <= (A * 255 + 1) >> 1 and |pass 2| <= (A * that + 128) >> 8 with A the
+    largest absolute row sum of the matrix -- both must stay inside int16 for the DST and the DCT."""
+    dst = np.array([[29, 55, 74, 84], [74, 74, 0, -74], [84, -29, -74, 55], [55, -84, 74, -29]])
+    dct = np.array([[64, 64, 64, 64], [83, 36, -36, -83], [64, -64, -64, 64], [36, -83, 83, -36]])
+    for m in (dst, dct):
+        a = int(np.abs(m).sum(axis=1).max())
+        first = (a * 255 + 1) >> 1
+        second = (a * first + 128) >> 8
+        assert first <= 32767 and second <= 32767, (a, first, second)
+        # and the extremes really are reached by sign patterns of +-255 (so the bound is the right one to check)
+        worst = max(abs(int((m[r] * np.sign(m[r]) * 255).sum())) for r in range(4))
+        assert worst == a * 255
 
 
 def test_substitution_against_a_scan(oracle_lib):
