@@ -227,7 +227,22 @@ __device__ __forceinline__ void me_search_workgroup(
 				const uint32_t *wrow = reinterpret_cast<const uint32_t *>(s_win + (y + cy) * win_stride + cx0);
 				const uint32_t *srow = s_src + y * wd;
 				uint32_t lo = wrow[0];
-				for (int j = 0; j < wd; ++j)
+				int j = 0;
+				// four source dwords a trip: one 16-byte read of the source row and the next four window dwords (dword-aligned: two ds_read2_b32) for four v_qsad --
+				// a dword at a time it was two LDS reads per v_qsad, and searches of a few hundred candidates (a partition's +-8, the frame chain's +-16) run
+				// entirely on this path (one or two 16-candidate groups per row: no whole round of full items)
+				for (; j + 4 <= wd; j += 4)
+				{
+					typedef u32x4 u32x4_dword_aligned __attribute__((aligned(4)));
+					const u32x4 s4 = *reinterpret_cast<const u32x4 *>(srow + j);
+					const u32x4 w4 = *reinterpret_cast<const u32x4_dword_aligned *>(wrow + j + 1);
+					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w4.x << 32) | lo, s4.x, pk);
+					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w4.y << 32) | w4.x, s4.y, pk);
+					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w4.z << 32) | w4.y, s4.z, pk);
+					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)w4.w << 32) | w4.z, s4.w, pk);
+					lo = w4.w;
+				}
+				for (; j < wd; ++j)
 				{
 					const uint32_t hi = wrow[j + 1];
 					pk = __builtin_amdgcn_qsad_pk_u16_u8(((unsigned long long)hi << 32) | lo, srow[j], pk);
