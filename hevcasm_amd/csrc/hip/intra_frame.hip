@@ -273,7 +273,9 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds<ENCODE> &L, const CtuView 
 	int tx, int ty, int mode, int16_t *lev, int *cbf_out, int lane)
 {
 	constexpr bool encode = ENCODE;
-	constexpr int PX = IntraGeom<N>::PX, LPB = IntraGeom<N>::LPB, LOG2 = IntraGeom<N>::LOG2, P = N + 4;
+	// pixels per lane: a 16x16 TU over all 64 lanes (4 each: the flat kernel's deal of 16 lanes x 16 pixels left three quarters of this wave idle through the
+	// prediction, the residual and the reconstruction -- a third of a 16x16 TU's time)
+	constexpr int PX = N == 16 ? 4 : IntraGeom<N>::PX, LPB = N * N / PX, LOG2 = IntraGeom<N>::LOG2, P = N + 4;
 	const bool luma = A.cIdx == 0;
 
 #ifndef IF_KNOCK_NB
@@ -294,7 +296,7 @@ __device__ __forceinline__ void reconstruct_tu(CtuLds<ENCODE> &L, const CtuView 
 	}
 	Chunk<PX> pred;
 #ifndef IF_KNOCK_PRED
-	intra_predict_block<N, kLanes>(filter ? L.flt : L.raw, L.ref, L.ptile, lane, mode, luma && N < 32, wave_sync, pred);
+	intra_predict_block<N, kLanes, PX>(filter ? L.flt : L.raw, L.ref, L.ptile, lane, mode, luma && N < 32, wave_sync, pred);
 #else
 	for (int k = 0; k < PX / 4; ++k) pred.d[k] = (uint32_t)mode * 0x01010101u;
 #endif

@@ -56,11 +56,14 @@ template <int N> struct IntraGeom
 // as aligned dwords + v_alignbyte, and the blend ((32 - f) a + f b + 16) >> 5 runs on even / odd bytes with v_pk_mad_u16 (11 instructions per 4 pixels;
 // f = 0 gives a exactly, so no branch).  Vertical modes store the 16 bytes as they are; horizontal modes scatter them transposed into an LDS tile and
 // read their row-major 16 bytes back.  Planar and DC stay per pixel (few operations each).
-template <int N, int STRIDE, typename Sync>
+// PXO: output bytes per lane (a multiple of 4 that divides N; N * N / PXO lanes compute).  The flat kernel uses IntraGeom's deal -- many blocks per workgroup, few
+// lanes each; the frame pipeline, whose wave works on ONE block, deals a 16x16 block over all 64 lanes (PXO = 4).
+template <int N, int STRIDE, int PXO = IntraGeom<N>::PX, typename Sync>
 __device__ __forceinline__ void intra_predict_block(const uint8_t *raw, uint8_t *ref, uint8_t *tile, const int j, const int mode, const int edge, Sync &&block_sync,
-	Chunk<IntraGeom<N>::PX> &out)
+	Chunk<PXO> &out)
 {
-	constexpr int PX = IntraGeom<N>::PX, LPB = IntraGeom<N>::LPB, LOG2 = IntraGeom<N>::LOG2, L = PX;
+	constexpr int PX = PXO, LPB = N * N / PXO, LOG2 = IntraGeom<N>::LOG2, L = PX;
+	static_assert(PXO % 4 == 0 && N % PXO == 0 && LPB <= STRIDE, "a lane's bytes are whole dwords of one row");
 	const bool computes = STRIDE == LPB || j < LPB;
 	auto top_at = [&](int x) { return (int)raw[2 * N + x]; };          // p[x][-1]
 	auto left_at = [&](int y) { return (int)raw[2 * N - 1 - y]; };     // p[-1][y]
