@@ -223,6 +223,44 @@ def test_hip_batches_of_frames_uneven_load_and_relaunch_on_one_workspace(oracle_
 
 
 @pytest.mark.gpu
+def test_hip_hundreds_of_frames_take_the_two_waves_per_simd_build(oracle_lib):
+    """The loop exists twice (intra_frame.hip: intra_frames_kernel at one wave per SIMD, intra_frames_dense_kernel held to 256 registers for two); the host takes the
+    second when the call's concurrency -- frames x min(rows, ceil(cols / 2)) -- exceeds 4 x CUs.  Every other test stays below that, so: 560 frames of 256x128
+    (2 CTUs of a frame at a time: 1120 > 1024 on a 256-CU device), eight distinct frames repeated, encoder then decoder, every frame against the oracle."""
+    import torch
+    from hevcasm_amd import batch as B
+    w, h, ctu, F = 256, 128, 64, 560
+    kinds = [cases._intra_frame_case(w, h, ctu, 3000 + k, "mixed", strong=1, qp=24, kind=["video", "noise"][k % 2],      # (one QP and smoothing flag per call)
+                                     split=[(1.0, 0.7, 0.5, 0.35), (1.0, 1.0, 1.0, 0.5), (1.0, 0.3, 0.9, 0.9), (1.0, 1.0, 0.2, 0.2)][k % 4]) for k in range(8)]
+    cs = [kinds[(f * 5 + f // 8) % 8] for f in range(F)]
+    job = _frames_job(cs)
+    assert F * min(job.rows, (job.cols + 1) // 2) > 4 * torch.cuda.get_device_properties(0).multi_processor_count
+    src = torch.cat([B.u8(k["src"]) for k in kinds])
+    plane = kinds[0]["stride"] * h
+    src_all = torch.cat([src[((f * 5 + f // 8) % 8) * plane:((f * 5 + f // 8) % 8 + 1) * plane] for f in range(F)])
+    job.run(src_all)
+    torch.cuda.synchronize()
+    job.status()
+    want = [_oracle_frame(oracle_lib, k) for k in kinds]
+    rec, lev, cbf = job.recon.cpu().numpy(), job.levels.cpu().numpy(), job.cbf.cpu().numpy()
+    per_frame = lev.size // F
+    t0 = 0
+    for f in range(F):
+        k = (f * 5 + f // 8) % 8
+        assert np.array_equal(rec[f * plane:(f + 1) * plane], want[k][0]), "frame %d (kind %d): reconstruction" % (f, k)
+        assert np.array_equal(lev[f * per_frame:(f + 1) * per_frame], want[k][1]), "frame %d: levels" % f
+        n = len(kinds[k]["tus"])
+        assert np.array_equal(cbf[t0:t0 + n], want[k][2]), "frame %d: cbf" % f
+        t0 += n
+    enc = job.recon.clone()
+    job.recon.zero_()
+    job.run(None)                 # the decoder's build of the same loop, on the levels just written
+    torch.cuda.synchronize()
+    job.status()
+    assert torch.equal(job.recon, enc)
+
+
+@pytest.mark.gpu
 def test_hip_intra_frames_replay_as_a_hip_graph(oracle_lib):
     """The call only enqueues (memset node + two launches): captured once, replayed on new content of the resident planes."""
     import torch
