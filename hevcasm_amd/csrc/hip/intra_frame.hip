@@ -641,14 +641,33 @@ __device__ __forceinline__ void reconstruct_tu4(CtuLds<ENCODE> &L, const CtuView
 // The same idea one size up: lane 8 y + x owns pixel (x, y); lane j <= 32 reads neighbour sample j (0 .. 15 left column bottom-up, 16 corner, 17 .. 32 top row).
 // 8x8 TUs can be smoothed (8.4.4.2.3), so the substituted record is materialised first -- sample j in lane j, by ds_bpermute from its stand-in -- smoothed
 // with the two neighbouring lanes (DPP wave_shr / wave_shl), and the pixels gather their two samples from that: three LDS round trips where the general path
-// has about ten (record, reference array, transposing tile).  The transforms stay the general path's LDS passes (a row of 8 does not fit a DPP pattern);
+// has about ten (record, reference array, transposing tile).  The transforms are register passes too (dct8_forward / dct8_inverse below);
 // residual, quantiser and reconstruction are one element per lane.
 struct Tu8Lane
 {
 	int x, y, j;               // the lane's pixel; its neighbour sample min(lane, 32)
 	int ndx, ndy;              // that sample relative to the TU's origin
 	ptrdiff_t at;              // the pixel's offset from the TU's first in the reconstructed plane
+	// the 8-point passes in registers (dct8_forward / dct8_inverse): weights by the lane's place in its row of 8, the transposing lane, the lane's coefficient
+	int wf[4], wi[4];
+	int transposed;            // lane 8 x + y
+	int coefficient;           // after the forward passes the lane (row p, column q) holds coefficient (vertical frequency f(q), horizontal f(p)): 8 f(q) + f(p)
 };
+
+// The 8-point DCT along a row of 8 lanes by its even / odd halves (residual_decode.c:305-348 has the same structure): with m = the mirrored lane's value, lanes
+// 0 .. 3 form e[x] = v[x] + v[7 - x] and lanes 4 .. 7 o[7 - x] = v[7 - x] - v[x]; even outputs are a 4-point transform of e, odd ones of o, and each quad holds
+// exactly the four values its outputs need: four quad_perm broadcasts.  Output k of quad 0 is frequency 2 k, of quad 1 frequency 2 k + 1: f(place) below.
+__device__ __forceinline__ int dct8_forward(int v, const int (&w)[4], bool upper, int add, int shift)
+{
+	const int m = dpp<0x141>(v);      // row_half_mirror
+	return (quad_dot(upper ? m - v : v + m, w) + add) >> shift;
+}
+// the inverse: quad 0 turns the even frequencies it holds into ee[x], quad 1 the odd ones into oo[7 - x]; sample x = ee[x] + oo[x], sample 7 - x = ee[x] - oo[x]
+__device__ __forceinline__ int dct8_inverse(int v, const int (&w)[4], bool upper, int add, int shift)
+{
+	const int s = quad_dot(v, w), m = dpp<0x141>(s);
+	return clip3(-32768, 32767, ((upper ? m - s : s + m) + add) >> shift);
+}
 
 __device__ __forceinline__ Tu8Lane make_tu8_lane(int lane, ptrdiff_t stride_recon)
 {
@@ -657,6 +676,17 @@ __device__ __forceinline__ Tu8Lane make_tu8_lane(int lane, ptrdiff_t stride_reco
 	K.ndx = K.j <= 16 ? -1 : K.j - 17;
 	K.ndy = K.j < 16 ? 15 - K.j : -1;
 	K.at = K.y * stride_recon + K.x;
+	auto M = [&](int b, int i) { return (int)(signed char)kDctDevice.m[4 * b][i]; };      // the 8-point matrix: every fourth row of the 32-point one
+	auto f = [](int place) { return place < 4 ? 2 * place : 2 * (place - 4) + 1; };
+	const int place = K.x, k = place & 3;
+#pragma unroll
+	for (int q = 0; q < 4; ++q)
+	{
+		K.wf[q] = place < 4 ? M(2 * k, q) : M(2 * k + 1, 3 - q);          // quad 1's lane q holds o[3 - q]
+		K.wi[q] = place < 4 ? M(2 * q, k) : M(2 * q + 1, 3 - k);          // quad 1's lane k computes oo[3 - k]
+	}
+	K.transposed = 8 * K.x + K.y;
+	K.coefficient = 8 * f(K.x) + f(K.y);
 	return K;
 }
 
@@ -740,44 +770,35 @@ __device__ __forceinline__ void reconstruct_tu8(CtuLds<ENCODE> &L, const CtuView
 		}
 	}
 
-	uint32_t w[N / 2];
-	if (encode)
-	{
-		L.buf_a[K.y * P + K.x] = (int16_t)(src_px - pred);
-		load_weights<N>(L.tables, false, false, lane % N, w);
-		wave_sync();
-		transform_pass<N, false, true>(L.buf_a, L.buf_b, w, 2, lane);
-		wave_sync();
-		transform_pass<N, false, true>(L.buf_b, L.buf_a, w, 9, lane);
-		wave_sync();
-	}
+	// Residual -> coefficients -> levels -> residual, all in registers.  Forward (residual_decode.c:855-892): along the rows with shift 2, transpose (one
+	// ds_bpermute), along what were the columns with shift 9; the reference's int16 stores of both intermediates are identities here as for 4x4 blocks (largest
+	// absolute row sum of the 8-point matrix 512: |first| <= (512 * 255 + 2) >> 2 = 32640, |second| <= (512 * 32640 + 256) >> 9 = 32640).  The lane (row p,
+	// column q) then holds the coefficient of vertical frequency f(q) and horizontal f(p).  Inverse (:371-413): along q (the columns of the block) with shift 7,
+	// transpose, along p with shift 12, both clipped: the lanes are pixels again.
+	const bool upper = (lane & 4) != 0;
 	int level, cbf = 0;
 	if (encode)
 	{
-		int x = L.buf_a[K.y * P + K.x];
-		const bool neg = x < 0;
-		x = neg ? -x : x;
+		const int t1 = dct8_forward(src_px - pred, K.wf, upper, 2, 2);
+		const int c = dct8_forward(__builtin_amdgcn_ds_bpermute(K.transposed << 2, t1), K.wf, upper, 256, 9);
+		const bool neg = c < 0;
+		int x = neg ? -c : c;
 		x = (__mul24(x, q.q_scale) + (q.q_offset << (q.q_shift - 16))) >> q.q_shift;
 		x = neg ? -x : x;
 		level = clip3(-32768, 32767, x);
-		lev[lane] = (int16_t)level;
+		lev[K.coefficient] = (int16_t)level;
 		cbf = level;
 	}
-	else level = lev[lane];
-	L.buf_b[K.x * P + K.y] = (int16_t)clip3(-32768, 32767, (__mul24(level, q.dq_scale) + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+	else level = lev[K.coefficient];
+	const int d = clip3(-32768, 32767, (__mul24(level, q.dq_scale) + (1 << (q.dq_shift - 1))) >> q.dq_shift);
+	const int x1 = dct8_inverse(d, K.wi, upper, 64, 7);
+	const int res = dct8_inverse(__builtin_amdgcn_ds_bpermute(K.transposed << 2, x1), K.wi, upper, 2048, 12);
 	if (encode && cbf_out)
 	{
 		cbf = wave_or(cbf);
 		if (lane == 0) *cbf_out = cbf;
 	}
-	load_weights<N>(L.tables, true, false, lane % N, w);
-	wave_sync();
-	transform_pass<N, true, true>(L.buf_b, L.buf_a, w, 7, lane);
-	wave_sync();
-	transform_pass<N, true, false>(L.buf_a, L.buf_b, w, 12, lane);
-	wave_sync();
 
-	const int res = L.buf_b[K.y * P + K.x];
 	const int rec = clip3(0, 255, (int)(int16_t)(pred + res));
 	tile_at(L, tx + K.x, ty + K.y) = (uint8_t)rec;
 	const ptrdiff_t at = (ptrdiff_t)(v.y0 + ty) * A.stride_recon + (v.x0 + tx) + K.at;
