@@ -178,6 +178,38 @@ def quantize_reconstruct(rec, stride_rec, pred, stride_pred, rec_off, pred_off, 
     return rec
 
 
+def _tu_runs(runs):
+    runs = np.ascontiguousarray(runs)
+    assert runs.dtype.itemsize == 28, "runs must be workload.TU_RUN_DTYPE (hevcasm_hip_tu_run, 28 bytes)"
+    return runs
+
+
+def transform_runs(src, src_stride, src_off, runs, n_coeffs, out=None):
+    """hevcasm_hip_transform_runs: the forward transforms of a frame's TUs (runs: numpy workload.TU_RUN_DTYPE, host) in ONE launch -> int16 [n_coeffs]."""
+    runs = _tu_runs(runs)
+    out = torch.empty(n_coeffs, dtype=torch.int16, device=src.device) if out is None else out
+    check(lib().hevcasm_hip_transform_runs(out.data_ptr(), src.data_ptr(), src_stride, src_off.data_ptr(), runs.ctypes.data, len(runs), _stream()), "transform_runs")
+    return out
+
+
+def quantize_runs(src, runs, n_tus, out=None, cbf=None):
+    """hevcasm_hip_quantize_runs: the quantiser over a frame's TUs with each run's (scale, shift, offset) in ONE launch -> (levels, cbf per TU)."""
+    runs = _tu_runs(runs)
+    out = torch.empty_like(src) if out is None else out
+    cbf = torch.empty(n_tus, dtype=torch.int32, device=src.device) if cbf is None else cbf
+    check(lib().hevcasm_hip_quantize_runs(out.data_ptr(), src.data_ptr(), cbf.data_ptr(), runs.ctypes.data, len(runs), _stream()), "quantize_runs")
+    return out, cbf
+
+
+def inverse_transform_add_runs(dst, stride_dst, pred, stride_pred, dst_off, pred_off, coeffs, runs, dequant=False):
+    """hevcasm_hip_inverse_transform_add_runs / (dequant) hevcasm_hip_dequant_inverse_transform_add_runs: ONE launch for a frame's TUs."""
+    runs = _tu_runs(runs)
+    fn = lib().hevcasm_hip_dequant_inverse_transform_add_runs if dequant else lib().hevcasm_hip_inverse_transform_add_runs
+    check(fn(dst.data_ptr(), stride_dst, pred.data_ptr(), stride_pred, dst_off.data_ptr(), pred_off.data_ptr(), coeffs.data_ptr(), runs.ctypes.data, len(runs), _stream()),
+          "dequant_inverse_transform_add_runs" if dequant else "inverse_transform_add_runs")
+    return dst
+
+
 def _result_rows(out, n, like):
     """The (dx, dy, cost) table of n answers: allocated, or the caller's, checked -- the entry points write 12 n bytes through a raw pointer
     (and, for small launches, memset them first), so a short, strided, int64 or other-device `out` would be overrun or silently misread."""

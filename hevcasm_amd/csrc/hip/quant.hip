@@ -10,6 +10,7 @@
 // across the lanes that share a block, done with wave shuffles.
 
 #include "common.hpp"
+#include "tu_runs.hpp"
 
 namespace hevc {
 
@@ -58,37 +59,9 @@ __global__ __launch_bounds__(kThreads) void quantize_kernel(
 	int16_t *__restrict__ dst, const int16_t *__restrict__ src, int scale, int shift, int offset,
 	int *__restrict__ cbf, uint32_t n_blocks)
 {
-	constexpr int LPB = NPB / 8 < kWave ? NPB / 8 : kWave;  // lanes per block
-	constexpr int TRIPS = NPB / (8 * LPB);
-	const int round = offset << (shift - 16);
-	scale = (scale << 8) >> 8;   // 0 <= scale < 2^15 (entry point): v_mad_u32_u24 instead of v_mul_lo_u32
-
-	const size_t lane_global = (size_t)blockIdx.x * kThreads + threadIdx.x;
-	size_t blk = lane_global / LPB;
-	const uint32_t part = (uint32_t)(lane_global % LPB);
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;
-
-	int any = 0;
-#pragma unroll
-	for (int t = 0; t < TRIPS; ++t)
-	{
-		const size_t e = blk * NPB + (size_t)(t * LPB + part) * 8;
-		Chunk<16> c;
-		c.load(reinterpret_cast<const uint8_t *>(src + e));
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-		{
-			const int lo = quant1(sext_lo(c.d[k]), scale, round, shift);
-			const int hi = quant1(sext_hi(c.d[k]), scale, round, shift);
-			any |= lo | hi;
-			c.d[k] = pack16(lo, hi);
-		}
-		if (live) c.store_stream(reinterpret_cast<uint8_t *>(dst + e));
-	}
-#pragma unroll
-	for (int d = LPB / 2; d >= 1; d >>= 1) any |= __shfl_xor(any, d, kWave);
-	if (live && part == 0) cbf[blk] = any;
+#define HEVC_WG blockIdx.x
+#include "quant_quantize.inc"
+#undef HEVC_WG
 }
 
 // quantize.c:292-302.  A lane owns PX = min(8, N) horizontally adjacent pixels; 256 / (N * N / PX) blocks per workgroup.
@@ -165,9 +138,72 @@ __global__ __launch_bounds__(kThreads) void reconstruct4_lane_kernel(
 	}
 }
 
+// ---- one launch for the quantiser of a frame's transform units (round 6; tu_runs.hpp): the body above per run, with the run's parameters ----------------
+template <int NPB>
+__device__ __forceinline__ void quantize_workgroup(
+	int16_t *__restrict__ dst, const int16_t *__restrict__ src, int scale, int shift, int offset, int *__restrict__ cbf, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "quant_quantize.inc"
+#undef HEVC_WG
+}
+
+// blocks per workgroup by variant (= log2TrafoSize - 2): NPB / 8 lanes share a block, a whole wave above 512 coefficients
+constexpr uint32_t kQuantizeRunBlocksPerWg[4] = { kThreads / 2, kThreads / 8, kThreads / 32, kThreads / 64 };
+
+struct QuantizeRunsArgs
+{
+	int16_t *dst;
+	const int16_t *src;
+	int *cbf;
+	TuRunTable table;
+};
+
+__global__ __launch_bounds__(kThreads) void quantize_runs_kernel(const QuantizeRunsArgs a)
+{
+	uint32_t wg;
+	const TuRunDev r = find_tu_run(a.table, wg);
+	int16_t *d = a.dst + r.coeff_first;
+	const int16_t *s = a.src + r.coeff_first;
+	int *cbf = a.cbf + r.first;
+	switch (r.variant)
+	{
+	case 0: quantize_workgroup<16>(d, s, r.scale, r.shift, r.offset, cbf, r.count, wg); break;
+	case 1: quantize_workgroup<64>(d, s, r.scale, r.shift, r.offset, cbf, r.count, wg); break;
+	case 2: quantize_workgroup<256>(d, s, r.scale, r.shift, r.offset, cbf, r.count, wg); break;
+	case 3: quantize_workgroup<1024>(d, s, r.scale, r.shift, r.offset, cbf, r.count, wg); break;
+	default: break;
+	}
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_quantize_runs(int16_t *dst, const int16_t *src, int *cbf, const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs || !dst || !src || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<TuRunTable> tables;
+	std::vector<uint32_t> grids;
+	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.reserved) return set_error(HEVCASM_HIP_EINVAL, "run: log2TrafoSize must be 2..5 (16, 64, 256 or 1024 coefficients per block), reserved 0");
+			// the domain of hevcasm_hip_quantize_batch (quantize.c:162-168)
+			if (r.scale < 0 || r.scale >= 0x8000 || r.offset < 0 || r.offset >= 0x8000 || r.shift < 16 || r.shift > 27)
+				return set_error(HEVCASM_HIP_EINVAL, "run: scale/offset/shift outside the reference's domain (0 <= scale, offset < 0x8000; 16 <= shift <= 27)");
+			variant = (uint32_t)r.log2TrafoSize - 2u;
+			bpwg = kQuantizeRunBlocksPerWg[variant];
+			return 0; }, tables, grids)) return e;
+	for (size_t i = 0; i < tables.size(); ++i)
+	{
+		QuantizeRunsArgs a = { dst, src, cbf, tables[i] };
+		hipLaunchKernelGGL(quantize_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("quantize_runs_kernel")) return e;
+	}
+	return 0;
+}
 
 extern "C" int hevcasm_hip_quantize_inverse(int16_t *dst, const int16_t *src, int scale, int shift, size_t n, void *stream)
 {

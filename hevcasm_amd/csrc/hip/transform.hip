@@ -19,6 +19,7 @@
 
 #include "common.hpp"
 #include "dct_matrix.hpp"
+#include "tu_runs.hpp"
 
 namespace hevc {
 
@@ -299,160 +300,9 @@ __global__ __launch_bounds__(kThreads) void inverse_transform_add_kernel(
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {
-	typedef InverseTiles<N> T;
-	constexpr int BPWG = kThreads / N;
-	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-	__shared__ __attribute__((aligned(16))) uint32_t tiles[BPWG * T::DWORDS];
-
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t local = threadIdx.x / N, t = threadIdx.x % N;
-	uint32_t blk = wg * BPWG + local;
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;
-	uint32_t *p1 = tiles + local * T::DWORDS;
-	uint32_t *p2 = p1;
-	const uint32_t my_pair_bytes = kPairBytes.at[LOG2 - 2][t];   // where row / column t sits in a pair-ordered row
-
-	int v[N], w[N];
-	uint32_t p[N / 2];
-
-	// The add stage's lane deal (below: consecutive lanes hold the SAME row of consecutive blocks) is known now, so its
-	// offsets and prediction bytes are fetched now, behind the coefficients: where the add stage uses them they would be
-	// two more memory round trips at the very end of every workgroup.
-	const uint32_t local2 = threadIdx.x % BPWG, t2 = threadIdx.x / BPWG;
-	uint32_t blk2 = wg * BPWG + local2;
-	const bool live2 = blk2 < n_blocks;
-	if (!live2) blk2 = n_blocks - 1;
-	// (round 4: the workgroup's offsets by scalar loads + v_cndmask, as the SAD kernels fetch their descriptors, measured -5 ... +6 % by kernel and
-	// size, nothing on balance: profiles/r04_scalar_offsets_elsewhere_ab.txt -- these kernels run at the rate of their access mix)
-	const uint32_t po = pred_off[blk2], dof = dst_off[blk2];
-	const uint8_t *pp = pred + po + t2 * stride_pred;
-	uint8_t *d = dst + dof + t2 * stride_dst;
-	constexpr int CB = N >= 16 ? 16 : N;
-	Chunk<CB> pr[N / CB];
-
-	// row t of the coefficient block -> column-major pairs in P1 (dequantised on the way when fused)
-	// coefficients are read once: as streaming loads at 16x16 (-4 %); at 32x32 two lanes share each line and it costs 8 %
-	// (the op_sel form of the fused dequantisation only at 32x32: at 16x16 it measured +2 % / +6 % at 2^26 / 2^28 coefficients, twice, same box:
-	// profiles/r04_transform_valu_trim_ab.txt -- that kernel is not VALU-bound and liked the older instruction mix better)
-	constexpr bool DEQ_OPSEL = DEQUANT && N == 32;
-	uint32_t raw[N / 2];
-	if (DEQ_OPSEL) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw);
-	else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v);
-#pragma unroll
-	for (int q = 0; q < N / CB; ++q) pr[q].load(pp + q * CB);
-	__builtin_amdgcn_sched_barrier(0);
-	{
-		// element (row t, column x) -> P1[pair_of(t)][x], half_of(t)
-		int16_t *row = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p1) + (my_pair_bytes >> 2) * (T::S1 * 4) + (my_pair_bytes & 2));
-		if (DEQ_OPSEL)
-		{
-			// quantize.c:53-62: clip16((level * scale + round) >> shift).  scale < 2^15 (checked by the entry point) and the levels are int16, so the
-			// product is v_mad_i32_i16, which picks either half of the loaded dword by op_sel (no unpacking of the pair) and adds the rounding
-			// constant; the clip to int16 is the saturating pack.  2.5 vector instructions per level (was 3.5: r04_fused_dct32_order.txt has the
-			// before / after; the fused kernel is VALU-bound at large launches, its extra instructions are what it costs over the plain one)
-			typedef short s16x2v __attribute__((ext_vector_type(2)));
-			const int round = 1 << (shift - 1);
-#pragma unroll
-			for (int k = 0; k < N / 2; ++k)
-			{
-				int lo, hi;
-				asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(lo) : "v"(raw[k]), "s"(scale), "v"(round));
-				asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(hi) : "v"(raw[k]), "s"(scale), "v"(round));
-				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo >> shift, hi >> shift));   // v_cvt_pk_i16_i32 saturates
-				row[4 * k] = (int16_t)two;                 // ds_write_b16
-				row[4 * k + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
-			}
-		}
-		else if (DEQUANT)
-		{
-			// telling the compiler that scale fits 24 bits turns a quarter-rate v_mul_lo_u32 per coefficient into a full-rate v_mad_i32_i24
-			typedef short s16x2v __attribute__((ext_vector_type(2)));
-			const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;
-#pragma unroll
-			for (int x = 0; x < N; x += 2)
-			{
-				const int a = (v[x] * scale24 + round) >> shift, b = (v[x + 1] * scale24 + round) >> shift;
-				const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(a, b));   // v_cvt_pk_i16_i32 saturates: the clip to int16
-				row[2 * x] = (int16_t)two;                 // ds_write_b16
-				row[2 * x + 2] = (int16_t)(two >> 16);     // ds_write_b16_d16_hi
-			}
-		}
-		else
-		{
-#pragma unroll
-			for (int x = 0; x < N; ++x) row[2 * x] = (int16_t)v[x];
-		}
-	}
-	__syncthreads();
-
-	// first stage: column t, shift 7, clip to int16; result row y, column t -> P2[y][pair_of(t)], half_of(t)
-#pragma unroll
-	for (int q = 0; q < N / 2; ++q) p[q] = p1[q * T::S1 + t];
-	__syncthreads();   // P1 fully consumed: its storage becomes P2
-	inverse_packed<N, DST>(p, 64, w);
-	{
-		int16_t *col = reinterpret_cast<int16_t *>(reinterpret_cast<uint8_t *>(p2) + my_pair_bytes);
-		// the clip to int16 is the saturating pack of two rows' values; its halves go out as ds_write_b16 / ds_write_b16_d16_hi
-		typedef short s16x2w __attribute__((ext_vector_type(2)));
-#pragma unroll
-		for (int y = 0; y < N; y += 2)
-		{
-			const uint32_t two = __builtin_bit_cast(uint32_t, (s16x2w)__builtin_amdgcn_cvt_pk_i16(w[y] >> 7, w[y + 1] >> 7));
-			col[y * (T::S2 * 2)] = (int16_t)two;
-			col[(y + 1) * (T::S2 * 2)] = (int16_t)(two >> 16);
-		}
-	}
-	__syncthreads();
-
-	// Second stage + add.  The lanes are re-dealt so that consecutive lanes hold the SAME row of
-	// consecutive blocks: with blocks in raster order their prediction / destination rows are then
-	// contiguous in memory (one 64..256-byte run per row instead of N-byte pieces a stride apart).
-	{
-		const uint32_t *row = tiles + local2 * T::DWORDS + t2 * T::S2;
-		if constexpr (N >= 8)
-		{
-#pragma unroll
-			for (int q = 0; q < N / 8; ++q)
-			{
-				const u32x4 d = *reinterpret_cast<const u32x4 *>(row + 4 * q);
-				p[4 * q + 0] = d.x; p[4 * q + 1] = d.y; p[4 * q + 2] = d.z; p[4 * q + 3] = d.w;
-			}
-		}
-		else
-		{
-			const u32x2 d = *reinterpret_cast<const u32x2 *>(row);
-			p[0] = d.x; p[1] = d.y;
-		}
-	}
-	inverse_packed<N, DST>(p, 2048, w);
-
-	// Add to the prediction row and saturate to 8 bits.  The reference clips the second-stage result
-	// to int16 and narrows pred + residual to int16 before the 8-bit clip (residual_decode.c:350-368).
-	// Neither can ever act here: the second stage's inputs are int16 and every column of the
-	// transform matrix has sum |M| <= 64 + 31 * 90 = 2854, so |(sum + 2048) >> 12| <= 22834 and
-	// pred + residual stays inside int16.  Hence clip8(pred + ((w) >> 12)) == sat_u8((w + (pred << 12)) >> 12)
-	// (w already carries the rounding constant; adding a multiple of 4096 commutes with the shift),
-	// which is one v_lshl_add per pixel and one v_ashr_pk_u8_i32 per two pixels.
-	if (live2)
-	{
-#pragma unroll
-		for (int q = 0; q < N / CB; ++q)
-		{
-			Chunk<CB> c = pr[q];
-#pragma unroll
-			for (int k = 0; k < CB / 4; ++k)
-			{
-				int tt[4];
-#pragma unroll
-				for (int b = 0; b < 4; ++b) tt[b] = w[q * CB + 4 * k + b] + (int)(((c.d[k] >> (8 * b)) & 0xff) << 12);
-				const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
-				const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
-				c.d[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-			}
-			c.store(d + q * CB);
-		}
-	}
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "transform_inverse_tile.inc"
+#undef HEVC_WG
 }
 
 // ---- 4x4 / 8x8 inverse transform + add, one lane per block ------------------------------------
@@ -470,90 +320,9 @@ __global__ __launch_bounds__(kThreads) void inverse_lane_kernel(
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks)
 {
-	typedef short s16x2v __attribute__((ext_vector_type(2)));
-	constexpr PairOrder<N> order = make_pair_order<N>();
-	constexpr int RD = N / 2;   // dwords per coefficient row
-	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	if (blk >= n_blocks) return;
-
-	// r[k * RD + j] = (c[k][2j], c[k][2j + 1])
-	uint32_t r[N * RD];
-	{
-		const uint8_t *p = reinterpret_cast<const uint8_t *>(coeffs + (size_t)blk * (N * N));
-#pragma unroll
-		for (int i = 0; i < N * RD / 4; ++i)
-		{
-			Chunk<16> c;
-			c.load(p + 16 * i);
-#pragma unroll
-			for (int j = 0; j < 4; ++j) r[4 * i + j] = c.d[j];
-		}
-	}
-	// The prediction rows (and the offsets they hang off) are fetched now, behind the coefficients, not where the row pass
-	// needs them: left to the compiler they were issued after the column pass -- three memory round trips in a row per wave.
-	const uint8_t *pp = pred + pred_off[blk];
-	uint8_t *d = dst + dst_off[blk];
-	Chunk<N> pr[N];
-#pragma unroll
-	for (int y = 0; y < N; ++y) pr[y].load(pp + y * stride_pred);
-	__builtin_amdgcn_sched_barrier(0);
-	if (DEQUANT)
-	{
-		const int round = 1 << (shift - 1), scale24 = (scale << 8) >> 8;   // 24-bit operands: v_mad_i32_i24, not v_mul_lo_u32
-#pragma unroll
-		for (int i = 0; i < N * RD; ++i)
-		{
-			const int lo = ((int)(short)(r[i] & 0xffff) * scale24 + round) >> shift;   // quantize.c:53-62;
-			const int hi = (((int)r[i] >> 16) * scale24 + round) >> shift;             // v_cvt_pk_i16_i32 is the clip
-			r[i] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(lo, hi));
-		}
-	}
-
-	// column pass.  q[p * N + y] = (e[y][first[p]], e[y][second[p]]), e = clip16(sum >> 7): row y of the
-	// intermediate block, already in the pair order the row pass consumes.
-	uint32_t q[RD * N];
-#pragma unroll
-	for (int cp = 0; cp < RD; ++cp)
-	{
-		int w[2][N];
-#pragma unroll
-		for (int side = 0; side < 2; ++side)
-		{
-			const int x = side ? order.second[cp] : order.first[cp];
-			const uint32_t sel = (x & 1) ? 0x07060302u : 0x05040100u;    // high / low halves of (second, first)
-			uint32_t p[RD];
-#pragma unroll
-			for (int k = 0; k < RD; ++k)
-				p[k] = __builtin_amdgcn_perm(r[order.second[k] * RD + (x >> 1)], r[order.first[k] * RD + (x >> 1)], sel);
-			inverse_packed<N, DST>(p, 64, w[side]);
-		}
-#pragma unroll
-		for (int y = 0; y < N; ++y)
-			q[cp * N + y] = __builtin_bit_cast(uint32_t, (s16x2v)__builtin_amdgcn_cvt_pk_i16(w[0][y] >> 7, w[1][y] >> 7));
-	}
-
-	// row pass + prediction + saturate
-#pragma unroll
-	for (int y = 0; y < N; ++y)
-	{
-		uint32_t p[RD];
-#pragma unroll
-		for (int k = 0; k < RD; ++k) p[k] = q[k * N + y];
-		int w2[N];
-		inverse_packed<N, DST>(p, 2048, w2);
-		Chunk<N> c = pr[y];
-#pragma unroll
-		for (int k = 0; k < N / 4; ++k)
-		{
-			int tt[4];
-#pragma unroll
-			for (int b = 0; b < 4; ++b) tt[b] = w2[4 * k + b] + (int)(((c.d[k] >> (8 * b)) & 0xff) << 12);   // exact: see the N x N kernel
-			const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(tt[0], tt[1], 12);
-			const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(tt[2], tt[3], 12);
-			c.d[k] = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-		}
-		c.store(d + y * stride_dst);
-	}
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "transform_inverse_lane.inc"
+#undef HEVC_WG
 }
 
 // ---- forward transform ----------------------------------------------------------------------
@@ -563,52 +332,9 @@ __global__ __launch_bounds__(kThreads) void forward_transform_kernel(
 	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride,
 	const uint32_t *__restrict__ src_off, uint32_t n_blocks)
 {
-	constexpr int BPWG = kThreads / N;
-	constexpr int S = Tile<N>::S;
-	constexpr int LOG2 = N == 4 ? 2 : N == 8 ? 3 : N == 16 ? 4 : 5;
-	constexpr int S1 = LOG2 - 1, S2 = LOG2 + 6;  // residual_decode.c:855-892
-	__shared__ __attribute__((aligned(16))) int16_t tiles[BPWG * Tile<N>::HALFWORDS];
-
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const uint32_t local = threadIdx.x / N, t = threadIdx.x % N;
-	uint32_t blk = wg * BPWG + local;
-	const bool live = blk < n_blocks;
-	if (!live) blk = n_blocks - 1;
-	int16_t *tile = tiles + local * Tile<N>::HALFWORDS;
-
-	int v[N], w[N];
-
-	// first stage: one residual row per lane; result (truncated to int16) stored transposed.  Lanes
-	// are dealt row-major across blocks here (same row of consecutive blocks in consecutive lanes)
-	// so that raster-ordered blocks read contiguous runs of the residual plane.
-	{
-		// (measured: the re-deal pays at N = 4 and 32; at 8 and 16 the transposed LDS store it implies conflicts more than the loads gain)
-		constexpr bool REDEAL = N == 4 || N == 32;
-		const uint32_t local1 = REDEAL ? threadIdx.x % BPWG : local, t1 = REDEAL ? threadIdx.x / BPWG : t;
-		uint32_t blk1 = wg * BPWG + local1;
-		if (blk1 >= n_blocks) blk1 = n_blocks - 1;
-		int16_t *tile1 = tiles + local1 * Tile<N>::HALFWORDS;
-		const uint32_t off1 = src_off[blk1];
-		global_row_load<N>(src + off1 + (ptrdiff_t)t1 * src_stride, v);
-		forward_1d<N, DST>(v, w);
-#pragma unroll
-		for (int k = 0; k < N; ++k) tile1[k * S + t1] = (int16_t)((w[k] + (1 << (S1 - 1))) >> S1);
-	}
-	__syncthreads();
-
-	// second stage: lane t holds horizontal frequency t across all rows; output column t
-	row_to_regs<N>(tile + t * S, v);
-	forward_1d<N, DST>(v, w);
-	__syncthreads();
-#pragma unroll
-	for (int k = 0; k < N; ++k) tile[k * S + t] = (int16_t)((w[k] + (1 << (S2 - 1))) >> S2);
-	__syncthreads();
-
-	// coalesced write-out: lane t stores output row t (2N contiguous bytes)
-	row_to_regs<N>(tile + t * S, v);
-	// written once, a lane a whole row: streaming stores (8x8 -8 %, 16x16 -9 %; the 4x4 lane kernel, whose four 8-byte
-	// stores per lane share lines across instructions, loses 17 % with them)
-	if (live) global_row_store<N, true>(coeffs + (size_t)blk * (N * N) + t * N, v);
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "transform_forward_tile.inc"
+#undef HEVC_WG
 }
 
 // 4x4 forward transform, one lane per block: as inverse_lane_kernel, everything in registers.
@@ -619,32 +345,9 @@ __global__ __launch_bounds__(kThreads) void forward4_lane_kernel(
 	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride,
 	const uint32_t *__restrict__ src_off, uint32_t n_blocks)
 {
-	constexpr int N = 4, S1 = 1, S2 = 8;   // residual_decode.c:855-892
-	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	if (blk >= n_blocks) return;
-	const int16_t *p = src + src_off[blk];
-
-	int a[N][N];   // a[k][y]: horizontal frequency k of residual row y
-#pragma unroll
-	for (int y = 0; y < N; ++y)
-	{
-		int v[N], w[N];
-		global_row_load<N>(p + (ptrdiff_t)y * src_stride, v);
-		forward_1d<N, DST>(v, w);
-#pragma unroll
-		for (int k = 0; k < N; ++k) a[k][y] = (int)(int16_t)((w[k] + (1 << (S1 - 1))) >> S1);
-	}
-	int o[N][N];   // o[k][t]: vertical frequency k, horizontal frequency t
-#pragma unroll
-	for (int t = 0; t < N; ++t)
-	{
-		int w[N];
-		forward_1d<N, DST>(a[t], w);
-#pragma unroll
-		for (int k = 0; k < N; ++k) o[k][t] = (w[k] + (1 << (S2 - 1))) >> S2;
-	}
-#pragma unroll
-	for (int k = 0; k < N; ++k) global_row_store<N>(coeffs + (size_t)blk * (N * N) + k * N, o[k]);
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "transform_forward4_lane.inc"
+#undef HEVC_WG
 }
 
 // ---- 32x32 forward transform on the matrix cores ---------------------------------------------
@@ -708,100 +411,9 @@ __global__ __launch_bounds__(kThreads) void forward32_mfma_kernel(
 	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride,
 	const uint32_t *__restrict__ src_off, uint32_t n_blocks)
 {
-	constexpr int S1 = 4, S2 = 11;   // residual_decode.c:855-892 for N = 32, 8-bit video
-	constexpr int BPW = kFwd32BlocksPerWave;
-	// a wave walks BPW consecutive blocks; the next block's residuals are in flight while this one is
-	// transformed, and the constant operands are fetched once
-	const uint32_t wave = __builtin_amdgcn_readfirstlane(xcd_contiguous(blockIdx.x, gridDim.x) * (kThreads / kWave) + (threadIdx.x >> 6));
-	const uint32_t first = wave * BPW;
-	if (first >= n_blocks) return;
-	const int count = (int)min((uint32_t)BPW, n_blocks - first);
-	const int l = threadIdx.x & 63, r = l & 31, h = l >> 5;
-
-	const v4i32 b1 = { (int)kFwd32.b1[l][0], (int)kFwd32.b1[l][1], (int)kFwd32.b1[l][2], (int)kFwd32.b1[l][3] };
-	const v4i32 a2 = { (int)kFwd32.a2[l][0], (int)kFwd32.a2[l][1], (int)kFwd32.a2[l][2], (int)kFwd32.a2[l][3] };
-	const int bias1 = 128 * kFwd32.rowsum[r] + (1 << (S1 - 1));
-	int bias2[16];
-#pragma unroll
-	for (int i = 0; i < 16; ++i) bias2[i] = 128 * kFwd32.rowsum[(i & 3) + 8 * (i >> 2) + 4 * h] + (1 << (S2 - 1));
-
-	// this lane's 16 residuals of a block: row r, columns 16 h .. 16 h + 15
-	const ptrdiff_t lane_off = (ptrdiff_t)r * src_stride + 16 * h;
-	auto load_block = [&](uint32_t blk, uint32_t (&x)[8])
-	{
-		const uint8_t *p = reinterpret_cast<const uint8_t *>(src + src_off[blk] + lane_off);
-		Chunk<16> c0, c1;
-		c0.load(p);
-		c1.load(p + 16);
-#pragma unroll
-		for (int i = 0; i < 4; ++i) { x[i] = c0.d[i]; x[4 + i] = c1.d[i]; }
-	};
-	uint32_t x[8], xn[8];
-	load_block(first, x);
-
-	for (int b = 0; b < count; ++b)
-	{
-		const uint32_t blk = first + b;
-		if (b + 1 < count) load_block(blk + 1, xn);
-
-		v4i32 a_lo, a_hi;
-		{
-			uint32_t lo[2], hi[2];
-			split_bytes({ x[0], x[1], x[2], x[3] }, lo, hi);
-			a_lo.x = lo[0]; a_lo.y = lo[1]; a_hi.x = hi[0]; a_hi.y = hi[1];
-			split_bytes({ x[4], x[5], x[6], x[7] }, lo, hi);
-			a_lo.z = lo[0]; a_lo.w = lo[1]; a_hi.z = hi[0]; a_hi.w = hi[1];
-		}
-
-		// stage 1: this lane ends up with T[row][k = r] for its 16 rows
-		v16i32 t_lo, t_hi = { 0 };
-#pragma unroll
-		for (int i = 0; i < 16; ++i) t_lo[i] = bias1;
-		t_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_lo, b1, t_lo, 0, 0, 0);
-		t_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a_hi, b1, t_hi, 0, 0, 0);
-
-		// intermediate, truncated to int16 as the reference's int16 array does; paired for the byte split
-		uint32_t pair[8];
-#pragma unroll
-		for (int i = 0; i < 16; i += 2)
-		{
-			const int v0 = ((t_hi[i] << 8) + t_lo[i]) >> S1, v1 = ((t_hi[i + 1] << 8) + t_lo[i + 1]) >> S1;
-			pair[i / 2] = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)v0, 0x05040100);
-		}
-		v4i32 b_lo, b_hi;
-		{
-			uint32_t lo[2], hi[2];
-			split_bytes({ pair[0], pair[1], pair[2], pair[3] }, lo, hi);
-			b_lo.x = lo[0]; b_lo.y = lo[1]; b_hi.x = hi[0]; b_hi.y = hi[1];
-			split_bytes({ pair[4], pair[5], pair[6], pair[7] }, lo, hi);
-			b_lo.z = lo[0]; b_lo.w = lo[1]; b_hi.z = hi[0]; b_hi.w = hi[1];
-		}
-
-		// stage 2: Out[m][k = r] for this lane's 16 output rows m = (i & 3) + 8 (i >> 2) + 4 h
-		v16i32 o_lo, o_hi = { 0 };
-#pragma unroll
-		for (int i = 0; i < 16; ++i) o_lo[i] = bias2[i];
-		o_lo = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_lo, o_lo, 0, 0, 0);
-		o_hi = __builtin_amdgcn_mfma_i32_32x32x32_i8(a2, b_hi, o_hi, 0, 0, 0);
-
-		// Two neighbouring columns per dword store, and every lane stores: for a pair of output rows (i, i + 1) the even lanes
-		// write columns (r, r + 1) of row i (the odd lane's value comes by DPP) and the odd lanes columns (r - 1, r) of row
-		// i + 1 -- 8 store instructions of 64 dwords instead of 16 of 32 (-2.7 %).
-		int16_t *out = coeffs + (size_t)blk * 1024 + (r & ~1);
-#pragma unroll
-		for (int i = 0; i < 16; i += 2)
-		{
-			const int v0 = ((o_hi[i] << 8) + o_lo[i]) >> S2, v1 = ((o_hi[i + 1] << 8) + o_lo[i + 1]) >> S2;
-			const int from_next = __builtin_amdgcn_mov_dpp(v0, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);   // even lanes: row i, column r + 1
-			const int from_prev = __builtin_amdgcn_mov_dpp(v1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);   // odd lanes: row i + 1, column r - 1
-			const uint32_t even_pair = __builtin_amdgcn_perm((uint32_t)from_next, (uint32_t)v0, 0x05040100);
-			const uint32_t odd_pair = __builtin_amdgcn_perm((uint32_t)v1, (uint32_t)from_prev, 0x05040100);
-			const int m0 = (i & 3) + 8 * (i >> 2) + 4 * h, m1 = ((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * h;
-			*reinterpret_cast<uint32_t *>(out + 32 * ((l & 1) ? m1 : m0)) = (l & 1) ? odd_pair : even_pair;
-		}
-#pragma unroll
-		for (int i = 0; i < 8; ++i) x[i] = xn[i];
-	}
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "transform_forward32_mfma.inc"
+#undef HEVC_WG
 }
 
 template <int N, bool DST, bool DEQUANT>
@@ -849,9 +461,185 @@ static int launch_forward(int16_t *coeffs, const int16_t *src, ptrdiff_t ss, con
 	return launch_status("forward_transform_kernel");
 }
 
+// ---- one launch for a frame's transform units: runs of equally sized TUs (round 6; tu_runs.hpp) ----------------------------------------------------
+//
+// The workgroup bodies above once more, as functions of (batch, workgroup index inside the batch); the one-size kernels keep their own copies of the same text
+// (an inlined function is optimised before it meets its kernel's launch bounds and came out scheduled differently: the measured kernels stay as they were).
+template <int N, bool DST, bool DEQUANT>
+__device__ __forceinline__ void inverse_tile_workgroup(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "transform_inverse_tile.inc"
+#undef HEVC_WG
+}
+template <int N, bool DST, bool DEQUANT>
+__device__ __forceinline__ void inverse_lane_workgroup(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "transform_inverse_lane.inc"
+#undef HEVC_WG
+}
+template <int N, bool DST>
+__device__ __forceinline__ void forward_tile_workgroup(
+	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride, const uint32_t *__restrict__ src_off, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "transform_forward_tile.inc"
+#undef HEVC_WG
+}
+template <bool DST>
+__device__ __forceinline__ void forward4_lane_workgroup(
+	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride, const uint32_t *__restrict__ src_off, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "transform_forward4_lane.inc"
+#undef HEVC_WG
+}
+__device__ __forceinline__ void forward32_mfma_workgroup(
+	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride, const uint32_t *__restrict__ src_off, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "transform_forward32_mfma.inc"
+#undef HEVC_WG
+}
+
+// variant = 0: 4x4 DST, 1: 4x4 DCT, 2: 8x8, 3: 16x16, 4: 32x32 (both directions); blocks per workgroup of each body
+constexpr uint32_t kInverseRunBlocksPerWg[5] = { kThreads, kThreads, kThreads, kThreads / 16, kThreads / 32 };
+constexpr uint32_t kForwardRunBlocksPerWg[5] = { kThreads, kThreads, kThreads / 8, kThreads / 16, (kThreads / kWave) * kFwd32BlocksPerWave };
+
+struct InverseRunsArgs
+{
+	uint8_t *dst;
+	const uint8_t *pred;
+	ptrdiff_t stride_dst, stride_pred;
+	const uint32_t *dst_off, *pred_off;
+	const int16_t *coeffs;
+	TuRunTable table;
+};
+struct ForwardRunsArgs
+{
+	int16_t *coeffs;
+	const int16_t *src;
+	ptrdiff_t src_stride;
+	const uint32_t *src_off;
+	TuRunTable table;
+};
+
+template <bool DEQUANT>
+__global__ __launch_bounds__(kThreads) void inverse_runs_kernel(const InverseRunsArgs a)
+{
+	uint32_t wg;
+	const TuRunDev r = find_tu_run(a.table, wg);
+	const uint32_t *dof = a.dst_off + r.first, *pof = a.pred_off + r.first;
+	const int16_t *c = a.coeffs + r.coeff_first;
+	switch (r.variant)
+	{
+	case 0: inverse_lane_workgroup<4, true, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 1: inverse_lane_workgroup<4, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 2: inverse_lane_workgroup<8, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 3: inverse_tile_workgroup<16, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 4: inverse_tile_workgroup<32, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	default: break;
+	}
+}
+
+__global__ __launch_bounds__(kThreads) void forward_runs_kernel(const ForwardRunsArgs a)
+{
+	uint32_t wg;
+	const TuRunDev r = find_tu_run(a.table, wg);
+	int16_t *c = a.coeffs + r.coeff_first;
+	const uint32_t *sof = a.src_off + r.first;
+	switch (r.variant)
+	{
+	case 0: forward4_lane_workgroup<true>(c, a.src, a.src_stride, sof, r.count, wg); break;
+	case 1: forward4_lane_workgroup<false>(c, a.src, a.src_stride, sof, r.count, wg); break;
+	case 2: forward_tile_workgroup<8, false>(c, a.src, a.src_stride, sof, r.count, wg); break;
+	case 3: forward_tile_workgroup<16, false>(c, a.src, a.src_stride, sof, r.count, wg); break;
+	case 4: forward32_mfma_workgroup(c, a.src, a.src_stride, sof, r.count, wg); break;
+	default: break;
+	}
+}
+
+// a run's size and type -> variant; the checks of the one-size entry points
+static int tu_variant(const hevcasm_hip_tu_run &r, uint32_t &variant)
+{
+	if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.trType > 1 || (r.trType && r.log2TrafoSize != 2) || r.reserved)
+		return set_error(HEVCASM_HIP_EINVAL, "run: transform size/type not supported by the reference (log2TrafoSize 2..5, trType 1 only at 2, reserved 0)");
+	variant = r.log2TrafoSize == 2 ? (r.trType ? 0u : 1u) : (uint32_t)r.log2TrafoSize - 1u;
+	return 0;
+}
+
+template <bool DEQUANT>
+static int inverse_runs_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, ptrdiff_t sp, const uint32_t *dof, const uint32_t *pof,
+		const int16_t *c, const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs || !dst || !pred || !dof || !pof || !c) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<TuRunTable> tables;
+	std::vector<uint32_t> grids;
+	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+			if (int e = tu_variant(r, variant)) return e;
+			if (DEQUANT && (r.shift < 1 || r.shift > 31)) return set_error(HEVCASM_HIP_EINVAL, "run: shift out of range");
+			if (DEQUANT && (r.scale < -32768 || r.scale > 32767)) return set_error(HEVCASM_HIP_EINVAL, "run: scale must fit int16 (the reference's SIMD path multiplies with pmaddwd, quantize_a.asm:53-109)");
+			bpwg = kInverseRunBlocksPerWg[variant];
+			return 0; }, tables, grids)) return e;
+	for (size_t i = 0; i < tables.size(); ++i)
+	{
+		InverseRunsArgs a = { dst, pred, sd, sp, dof, pof, c, tables[i] };
+		hipLaunchKernelGGL((inverse_runs_kernel<DEQUANT>), dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("inverse_runs_kernel")) return e;
+	}
+	return 0;
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_inverse_transform_add_runs(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *coeffs,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	return inverse_runs_entry<false>(dst, stride_dst, pred, stride_pred, dst_off, pred_off, coeffs, runs, n_runs, stream);
+}
+
+extern "C" int hevcasm_hip_dequant_inverse_transform_add_runs(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *levels,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	return inverse_runs_entry<true>(dst, stride_dst, pred, stride_pred, dst_off, pred_off, levels, runs, n_runs, stream);
+}
+
+extern "C" int hevcasm_hip_transform_runs(
+	int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride, const uint32_t *src_off,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs || !coeffs || !src || !src_off) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<TuRunTable> tables;
+	std::vector<uint32_t> grids;
+	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+			if (int e = tu_variant(r, variant)) return e;
+			bpwg = kForwardRunBlocksPerWg[variant];
+			return 0; }, tables, grids)) return e;
+	for (size_t i = 0; i < tables.size(); ++i)
+	{
+		ForwardRunsArgs a = { coeffs, src, src_stride, src_off, tables[i] };
+		hipLaunchKernelGGL(forward_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("forward_runs_kernel")) return e;
+	}
+	return 0;
+}
 
 extern "C" int hevcasm_hip_inverse_transform_add_batch(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,

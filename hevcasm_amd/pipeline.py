@@ -58,12 +58,34 @@ def partition_grid(pus, stride_cur, stride_ref, pad):
     return cur_off, ref_base, sizes, order
 
 
-def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1):
+def tu_grid(tus, stride, qp):
+    """A plane's transform units [(x, y, log2, tr_type)] (hevcasm_amd.workload.tu_partition) sorted by (size, type) -> (offsets in that order, sizes =
+    [(log2, tr_type, first, count, coeff_first, (q_scale, q_shift, q_offset, dq_scale, dq_shift))] with the parameters HEVC uses for the size at `qp`, order)."""
+    from . import workload as wl
+    t = np.asarray(tus, dtype=np.int64).reshape(-1, 4)
+    order = np.lexsort((np.arange(len(t)), -t[:, 3], t[:, 2]))
+    t = t[order]
+    off = (t[:, 1] * stride + t[:, 0]).astype(np.uint32)
+    q = wl.intra_qp(qp)
+    sizes, start, coeff = [], 0, 0
+    for i in range(1, len(t) + 1):
+        if i == len(t) or (t[i, 2:] != t[start, 2:]).any():
+            log2 = int(t[start, 2])
+            sizes.append((log2, int(t[start, 3]), start, i - start, coeff, tuple(int(v) for v in q[log2 - 2])))
+            coeff += (i - start) << (2 * log2)
+            start = i
+    return off, sizes, order
+
+
+def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1, tus=None, qp=27):
     """The same chain on a REAL partition (round 6): the frame cut into prediction units of many sizes (`pus`, any of the 24 of
     pred_inter.c:438-444), transform units on a uniform tu x tu grid (HEVC's transform tree is independent of the PU boundaries inside a CU).
     Every stage is ONE launch for the whole frame: hevcasm_hip_me_full_search_runs, hevcasm_hip_subpel_refine_runs, hevcasm_hip_pred_uni_8to8_runs,
     hevcasm_hip_sad_runs (the PUs' prediction cost -- which must be the refinement's winning cost), the transform stages on the TU grid,
-    hevcasm_hip_ssd_runs per PU.  -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
+    hevcasm_hip_ssd_runs per PU.  With `tus` (a residual quad-tree over the four transform sizes, hevcasm_amd.workload.tu_partition) the transform stages run on
+    THAT partition instead, one launch each as well (hevcasm_hip_transform_runs, _quantize_runs, _dequant_inverse_transform_add_runs), every size with the
+    (de)quantiser parameters HEVC gives it at `qp`; coefficients and levels are then in run order (tu_grid).
+    -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
     w, h, pad = frame["w"], frame["h"], frame["pad"]
     sc, sr = frame["stride_cur"], frame["stride_ref"]
     log2n = tu.bit_length() - 1
@@ -75,9 +97,15 @@ def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshif
     pred = ops.pred_uni_runs(w * h, sc, ref, sr, cur_off, ref_sub, frac, sizes)                 # every PU size, one launch
     pu_sad = ops.cost_runs("sad", cur, sc, pred, sc, cur_off, cur_off, sizes)                   # one launch; == qmv[:, 2]
     residual = ops.residual(cur, pred)
-    coeffs = ops.transform(residual, sc, tu_off, 0, log2n)
-    levels, cbf = ops.quantize(coeffs, qscale, qshift, qoffset, tu * tu)
-    recon = ops.dequant_inverse_transform_add(w * h, sc, pred, sc, tu_off, tu_off, levels, dqscale, dqshift, 0, log2n)
+    if tus is None:
+        coeffs = ops.transform(residual, sc, tu_off, 0, log2n)
+        levels, cbf = ops.quantize(coeffs, qscale, qshift, qoffset, tu * tu)
+        recon = ops.dequant_inverse_transform_add(w * h, sc, pred, sc, tu_off, tu_off, levels, dqscale, dqshift, 0, log2n)
+    else:
+        tu_off, tu_sizes = ops.plan_tus(frame, tus, qp)
+        coeffs = ops.transform_runs(residual, sc, tu_off, tu_sizes, w * h)                       # every TU size, one launch
+        levels, cbf = ops.quantize_runs(coeffs, tu_sizes, len(tus))                              # one launch
+        recon = ops.dequant_inverse_transform_add_runs(w * h, sc, pred, sc, tu_off, tu_sizes, levels)   # one launch
     pu_ssd = ops.cost_runs("ssd", cur, sc, recon, sc, cur_off, cur_off, sizes)                  # one launch
     frame_sse = ops.frame_sse(cur, sc, recon, sc, w, h)
     return dict(mv=mv, qmv=qmv, pred=pred, pu_sad=pu_sad, residual=residual, coeffs=coeffs, levels=levels, cbf=cbf, recon=recon, pu_ssd=pu_ssd, frame_sse=frame_sse, order=order)
@@ -133,6 +161,31 @@ class HipOps:
         p = self._partitions[key]
         self._pred_runs, self._cost_runs = p[5], p[6]
         return cur, ref, p[1], p[2], p[3], p[4], tu_off
+
+    def plan_tus(self, frame, tus, qp):
+        """The TU partition's descriptor array (device) and run tables (host), cached with the frame's planes."""
+        key = (id(frame["cur"]), id(frame["ref"]), "tus", id(tus), qp)
+        if key not in self._partitions:
+            from . import workload as wl
+            off, sizes, _ = tu_grid(tus, frame["stride_cur"], qp)
+            while len(self._partitions) >= self.MAX_PLANS:
+                self._partitions.pop(next(iter(self._partitions)))
+            self._partitions[key] = (tus, self.B.off32(off), sizes,
+                                     np.array([(f, n, cf, l2, tr, 0, q[0], q[1], q[2]) for (l2, tr, f, n, cf, q) in sizes], dtype=wl.TU_RUN_DTYPE),
+                                     np.array([(f, n, cf, l2, tr, 0, q[3], q[4], 0) for (l2, tr, f, n, cf, q) in sizes], dtype=wl.TU_RUN_DTYPE))
+        p = self._partitions[key]
+        self._tu_runs_q, self._tu_runs_dq = p[3], p[4]
+        return p[1], p[2]
+
+    def transform_runs(self, residual, stride, off, tu_sizes, n_coeffs):
+        return self.B.transform_runs(residual, stride, off, self._tu_runs_q, n_coeffs)
+
+    def quantize_runs(self, coeffs, tu_sizes, n_tus):
+        return self.B.quantize_runs(coeffs, self._tu_runs_q, n_tus)
+
+    def dequant_inverse_transform_add_runs(self, dst_bytes, sd, pred, sp, off, tu_sizes, levels):
+        dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)
+        return self.B.inverse_transform_add_runs(dst, sd, pred, sp, off, off, levels, self._tu_runs_dq, dequant=True)
 
     def me_full_search_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes, search_range):
         return self.B.me_full_search_runs(cur, sc, ref, sr, cur_off, ref_off, self._cost_runs, search_range)

@@ -418,3 +418,60 @@ def cost_frame_case(w, h, seed, border=80, kind="noise", search=7):
     return dict(w=w, h=h, src=fill_u8(stride_src * h, seed + 20, kind), stride_src=stride_src, ref=fill_u8(stride_ref * (h + 2 * border), seed + 21, kind), stride_ref=stride_ref,
                 src_off=src_off.astype(np.uint32), ref_off=np.ascontiguousarray(ref_off4[:, 0]).astype(np.uint32), ref_off4=np.ascontiguousarray(ref_off4).astype(np.uint32).reshape(-1),
                 runs=np.array(runs, dtype=COST_RUN_DTYPE), sizes=sizes, n_pus=len(pus))
+
+
+# ---------------------------------------------------------------------------------------------
+# a frame's transform units: the four sizes of the reference's transform tables (residual_decode.h:54, :82), one launch per stage (hevcasm_hip_*_runs over
+# hevcasm_hip_tu_run: transform, quantize, inverse_transform_add, dequant_inverse_transform_add)
+
+TU_RUN_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("coeff_first", "<u4"), ("log2", "u1"), ("tr_type", "u1"), ("reserved", "<u2"),
+                         ("scale", "<i4"), ("shift", "<i4"), ("offset", "<i4")])      # = hevcasm_hip_tu_run, 28 bytes
+
+
+def tu_partition(w, h, seed, split=(0.8, 0.6, 0.45), dst_share=0.3):
+    """Cuts a w x h plane (multiples of 4) into transform units by a random quad-tree from 32x32 down to 4x4 (an inter CU's residual quad-tree; forced splits at
+    the plane's edges); a share of the 4x4 units takes the DST (HEVC: intra luma 4x4).  -> list of (x, y, log2, tr_type) in z-scan order."""
+    assert w % 4 == 0 and h % 4 == 0
+    rng = np.random.default_rng(seed)
+    tus = []
+
+    def walk(x, y, s, depth):
+        if x >= w or y >= h:
+            return
+        must = x + s > w or y + s > h
+        if s > 4 and (must or rng.random() < split[min(depth, len(split) - 1)]):
+            for (dx, dy) in ((0, 0), (s // 2, 0), (0, s // 2), (s // 2, s // 2)):
+                walk(x + dx, y + dy, s // 2, depth + 1)
+        else:
+            tus.append((x, y, s.bit_length() - 1, int(s == 4 and rng.random() < dst_share)))
+
+    for ty in range(0, h, 32):
+        for tx in range(0, w, 32):
+            walk(tx, ty, 32, 0)
+    return tus
+
+
+def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0):
+    """One plane's TUs (tu_partition) as RUNS for the four transform-stage entry points: an int16 residual plane and 8-bit prediction / destination planes (stride
+    w + pad; offsets in elements of each), the TUs sorted by (size, type) with z-scan order inside a run, coefficients of the runs laid end to end (w x h in all),
+    every run with the (de)quantiser parameters HEVC uses for its size at `qp` (intra_qp).  Keys: residual, pred, stride, off (uint32, shared by all planes),
+    runs_q / runs_dq (TU_RUN_DTYPE with the quantiser's / the dequantiser's parameters), sizes [(log2, tr_type, first, count, coeff_first)], n_tus, n_coeffs."""
+    tus = np.array(tu_partition(w, h, seed), dtype=np.int64)
+    order = np.lexsort((np.arange(len(tus)), -tus[:, 3], tus[:, 2]))      # 4x4 DST, 4x4 DCT, 8x8, 16x16, 32x32
+    tus = tus[order]
+    stride = w + pad
+    off = (tus[:, 1] * stride + tus[:, 0]).astype(np.uint32)
+    q = intra_qp(qp)
+    runs_q, runs_dq, sizes, start, coeff = [], [], [], 0, 0
+    for i in range(1, len(tus) + 1):
+        if i == len(tus) or (tus[i, 2:] != tus[start, 2:]).any():
+            log2, tr = int(tus[start, 2]), int(tus[start, 3])
+            qs, qsh, qo, ds, dsh = (int(v) for v in q[log2 - 2])
+            runs_q.append((start, i - start, coeff, log2, tr, 0, qs, qsh, qo))
+            runs_dq.append((start, i - start, coeff, log2, tr, 0, ds, dsh, 0))
+            sizes.append((log2, tr, start, i - start, coeff))
+            coeff += (i - start) << (2 * log2)
+            start = i
+    assert coeff == w * h
+    return dict(w=w, h=h, stride=stride, residual=fill_i16(stride * h, seed + 30, residual), pred=fill_u8(stride * h, seed + 31, kind), off=off,
+                runs_q=np.array(runs_q, dtype=TU_RUN_DTYPE), runs_dq=np.array(runs_dq, dtype=TU_RUN_DTYPE), sizes=sizes, n_tus=len(tus), n_coeffs=coeff, tus=tus)

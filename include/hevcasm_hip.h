@@ -381,6 +381,41 @@ int hevcasm_hip_quantize_reconstruct_batch(
 	const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res,
 	int nCbS, size_t n_blocks, void *stream);
 
+/* ONE launch per stage for a frame's transform units (round 6): TUs of the four sizes the reference's tables hold (residual_decode.h:54, :82: 4x4 DST or DCT,
+ * 8x8, 16x16, 32x32) listed as RUNS, as the prediction and block-cost `_runs` entry points list PUs.  Run i = `count` consecutive entries, from `first`, of the
+ * offset arrays (and of cbf[]), all of one size; its coefficients are `count` consecutive N x N int16 blocks starting at element `coeff_first` of the
+ * coefficient array (for TUs that tile a frame, runs laid end to end: frame_w x frame_h elements in all).  scale / shift / offset are the run's (de)quantiser
+ * parameters -- HEVC's shifts depend on the TU size -- read by hevcasm_hip_quantize_runs (all three) and hevcasm_hip_dequant_inverse_transform_add_runs (scale,
+ * shift), ignored by the other two.  `runs` is a HOST array read during the call (32 runs per launch; more = more launches, made by the call).  Per TU exactly
+ * the result of the one-size call (hevcasm_hip_transform_batch, _quantize_batch, _inverse_transform_add_batch, _dequant_inverse_transform_add_batch) with the
+ * run's size and parameters, which also gives the domain of every field; a bad run refuses the whole call (HEVCASM_HIP_EINVAL) before anything is launched.
+ * Offsets are relative to ONE base pointer and stride per call: planes that share a stride (Cb and Cr; or all three of a frame kept at the luma stride) go in one
+ * call when they lie in one allocation. */
+typedef struct
+{
+	uint32_t first, count;       /* descriptor entries [first, first + count) */
+	uint32_t coeff_first;        /* first int16 element of the run's coefficient / level blocks */
+	uint8_t log2TrafoSize;       /* 2..5 */
+	uint8_t trType;              /* 1 = the 4x4 DST (log2TrafoSize 2 only) */
+	uint16_t reserved;           /* 0 */
+	int32_t scale, shift, offset;
+} hevcasm_hip_tu_run;
+
+int hevcasm_hip_transform_runs(
+	int16_t *coeffs, const int16_t *src, ptrdiff_t src_stride, const uint32_t *src_off,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
+int hevcasm_hip_quantize_runs(
+	int16_t *dst, const int16_t *src, int *cbf,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
+int hevcasm_hip_inverse_transform_add_runs(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *coeffs,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
+int hevcasm_hip_dequant_inverse_transform_add_runs(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *levels,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
+
 /* The same two calls for TWO planes that share one PU list -- Cb and Cr of a 4:2:0 frame: same geometry, same motion
  * vectors, same fractions -- in one launch: plane a and plane b of the destination and of each reference have the same
  * stride and take the same offsets.  Results are exactly those of two single-plane calls; a frame's chroma launches are

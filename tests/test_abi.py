@@ -258,6 +258,25 @@ def test_inter_chain_example_tables_equal_the_four_device_calls(tmp_path):
     assert " 0 moved" not in r.stdout and " 0 with a fractional" not in r.stdout, r.stdout      # the case exercises motion and fractional prediction
 
 
+def test_tu_chain_example_compiles_and_refuses_without_a_gpu(tmp_path):
+    """examples/tu_chain.c (round 6): a C codec's residual loop for a plane of transform units of every size through the function-pointer tables (transform,
+    quantise, dequantise, inverse + add per TU), then the same plane as three device calls (the TU `_runs` entry points, each size with its own parameters)."""
+    import subprocess
+    import torch
+    exe = _build_example(tmp_path, "tu_chain")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the gpu-marked test")
+    assert subprocess.run([exe], capture_output=True).returncode == 77
+
+
+@pytest.mark.gpu
+def test_tu_chain_example_tables_equal_the_three_device_calls(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_example(tmp_path, "tu_chain")], capture_output=True, text=True)
+    assert r.returncode == 0 and "levels identical, 0 coded-block flags differ, reconstructed plane identical" in r.stdout, r.stdout + r.stderr
+    assert "(0 coded)" not in r.stdout and " in 5 runs " in r.stdout, r.stdout      # the case has coded and uncoded TUs of all five kinds
+
+
 def test_multi_gpu_example_compiles_and_refuses_without_a_gpu(tmp_path):
     """examples/multi_gpu_sad.c (one process, a thread + stream per device, contiguous block ranges, no exchange) is plain C + pthreads."""
     import subprocess

@@ -74,6 +74,25 @@ class OracleOps:
         return np.concatenate([fn(a, sa, b, sb, a_off[f:f + n], b_off[f:f + n], w, h) for (w, h, f, n) in sizes])
 
 
+    # the transform stages on a residual quad-tree (stages_partition(tus=...)): every run through the oracle's one-size batches with the run's parameters
+    def plan_tus(self, frame, tus, qp):
+        off, sizes, _ = pipeline.tu_grid(tus, frame["stride_cur"], qp)
+        return off, sizes
+
+    def transform_runs(self, residual, stride, off, tu_sizes, n_coeffs):
+        return np.concatenate([pyoracle.transform_batch(tr, l2, residual, stride, off[f:f + n]) for (l2, tr, f, n, cf, q) in tu_sizes])
+
+    def quantize_runs(self, coeffs, tu_sizes, n_tus):
+        parts = [pyoracle.quantize_batch(coeffs[cf:cf + (n << (2 * l2))], q[0], q[1], q[2], 1 << (2 * l2)) for (l2, tr, f, n, cf, q) in tu_sizes]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+    def dequant_inverse_transform_add_runs(self, dst_bytes, sd, pred, sp, off, tu_sizes, levels):
+        dst = np.zeros(dst_bytes, dtype=np.uint8)
+        for (l2, tr, f, n, cf, q) in tu_sizes:
+            dst |= pyoracle.dequant_inverse_transform_add_batch(tr, l2, dst_bytes, sd, pred, sp, off[f:f + n], off[f:f + n], levels[cf:cf + (n << (2 * l2))], q[3], q[4])      # TUs tile the plane
+        return dst
+
+
 def _with_half_pel_motion(frame):
     """The generator moves blocks by whole pixels; here the lower half of the current frame becomes the mean of itself and its right-hand neighbour,
     i.e. content half a pixel away from anything in the reference, so that the refinement has fractional winners."""
@@ -171,6 +190,37 @@ def test_partition_chain_hip_equals_oracle_stage_by_stage(w, h, tu, rng):
     got = pipeline.HipOps.to_numpy(pipeline.stages_partition(frame, pipeline.HipOps(), pus, tu=tu, search_range=rng))
     _same_partition_stages(got, want)
     assert np.array_equal(got["pu_sad"], got["qmv"][:, 2])
+
+
+def test_partition_chain_with_a_tu_quad_tree_on_the_oracle(oracle_lib):
+    """CPU: the chain with the transform stages on a residual quad-tree (4x4 DST / DCT ... 32x32, each size with its own quantiser parameters): the levels of a
+    run are what the one-size chain gives for that run's TUs, the cbf flags say which TUs have levels, and the reconstruction is a sane encode."""
+    from hevcasm_amd import workload as wl
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(192, 128, 16, seed=5, ctu=16, max_motion=6))
+    pus, tus = wl.inter_partition(192, 128, 3), wl.tu_partition(192, 128, 4)
+    r = pipeline.stages_partition(frame, OracleOps(), pus, search_range=8, tus=tus, qp=22)
+    off, sizes, order = pipeline.tu_grid(tus, 192, 22)
+    assert len(sizes) == 5 and r["coeffs"].size == 192 * 128 == r["levels"].size and r["cbf"].size == len(tus)
+    for (l2, tr, f, n, cf, q) in sizes:
+        assert np.array_equal(r["cbf"][f:f + n] != 0, (r["levels"][cf:cf + (n << (2 * l2))].reshape(n, -1) != 0).any(axis=1))
+    assert int(r["pu_ssd"].astype(np.int64).sum()) == int(r["frame_sse"][0]) and pipeline.psnr(int(r["frame_sse"][0]), 192, 128) > 32.0
+    assert r["cbf"].any() and not r["cbf"].all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,rng,qp", [(960, 576, 8, 27), (384, 256, 6, 12)])
+def test_partition_chain_with_a_tu_quad_tree_hip_equals_oracle(w, h, rng, qp):
+    """The last per-size stages of the inter chain as ONE launch each: PUs of every size AND transform units of every size, stage by stage == the oracle."""
+    from hevcasm_amd import workload as wl
+    frame = _with_half_pel_motion(me_frame.synthetic_frame_pair(w, h, rng + 8, seed=w + 3, ctu=16, max_motion=rng - 2))
+    pus, tus = wl.inter_partition(w, h, w + 1), wl.tu_partition(w, h, w + 2)
+    want = pipeline.stages_partition(frame, OracleOps(), pus, search_range=rng, tus=tus, qp=qp)
+    ops = pipeline.HipOps()
+    got = pipeline.HipOps.to_numpy(pipeline.stages_partition(frame, ops, pus, search_range=rng, tus=tus, qp=qp))
+    _same_partition_stages(got, want)
+    graph, results = ops.capture(frame, pus=pus, search_range=rng, tus=tus, qp=qp)          # and as one HIP graph
+    graph.replay()
+    _same_partition_stages(pipeline.HipOps.to_numpy(results), want)
 
 
 @pytest.mark.gpu

@@ -1,0 +1,185 @@
+"""ONE launch per stage for a frame's transform units (round 6): hevcasm_hip_transform_runs / _quantize_runs / _inverse_transform_add_runs /
+_dequant_inverse_transform_add_runs on a residual quad-tree over the four sizes of the reference's tables (residual_decode.h:54, :82: 4x4 DST and DCT, 8x8,
+16x16, 32x32), each run with the (de)quantiser parameters of its size, against the oracle's one-size batches per run (residual_decode.c:69-413, :592-892,
+quantize.c:53-62, :160-186: pinned, oracle == refdrv on every size)."""
+import numpy as np
+import pytest
+
+from hevcasm_amd import capi, workload as wl
+
+STAGES = ("forward", "quantize", "inverse", "dequant_inverse")
+
+
+def _coeffs(c, seed, kind="full"):
+    return wl.fill_i16(c["n_coeffs"], seed, kind)
+
+
+def _oracle(oracle_lib, c, stage, coeffs=None):
+    """The stage per run through the oracle's one-size batch calls."""
+    if stage == "forward":
+        out = np.zeros(c["n_coeffs"], dtype=np.int16)
+        for (log2, tr, first, count, cf) in c["sizes"]:
+            out[cf:cf + (count << (2 * log2))] = oracle_lib.transform_batch(tr, log2, c["residual"], c["stride"], c["off"][first:first + count])
+        return (out,)
+    if stage == "quantize":
+        out, cbf = np.zeros(c["n_coeffs"], dtype=np.int16), np.zeros(c["n_tus"], dtype=np.int32)
+        for (log2, tr, first, count, cf), r in zip(c["sizes"], c["runs_q"]):
+            e = cf + (count << (2 * log2))
+            out[cf:e], cbf[first:first + count] = oracle_lib.quantize_batch(coeffs[cf:e], int(r["scale"]), int(r["shift"]), int(r["offset"]), 1 << (2 * log2))
+        return out, cbf
+    dst = np.zeros(c["stride"] * c["h"], dtype=np.uint8)
+    for (log2, tr, first, count, cf), r in zip(c["sizes"], c["runs_dq"]):
+        o, e = c["off"][first:first + count], cf + (count << (2 * log2))
+        if stage == "inverse":
+            part = oracle_lib.inverse_transform_add_batch(tr, log2, dst.size, c["stride"], c["pred"], c["stride"], o, o, coeffs[cf:e])
+        else:
+            part = oracle_lib.dequant_inverse_transform_add_batch(tr, log2, dst.size, c["stride"], c["pred"], c["stride"], o, o, coeffs[cf:e], int(r["scale"]), int(r["shift"]))
+        dst |= part          # the runs' TUs are disjoint and each call starts from zeros
+    return (dst,)
+
+
+def _hip(c, stage, coeffs=None, runs=None, in_place=False):
+    import torch
+    from hevcasm_amd import batch as B
+    off = B.off32(c["off"])
+    if stage == "forward":
+        out = (B.transform_runs(torch.from_numpy(c["residual"]).cuda(), c["stride"], off, c["runs_q"] if runs is None else runs, c["n_coeffs"],
+                                out=torch.zeros(c["n_coeffs"], dtype=torch.int16, device="cuda")),)
+    elif stage == "quantize":
+        out = B.quantize_runs(torch.from_numpy(coeffs).cuda(), c["runs_q"] if runs is None else runs, c["n_tus"],
+                              out=torch.zeros(c["n_coeffs"], dtype=torch.int16, device="cuda"), cbf=torch.zeros(c["n_tus"], dtype=torch.int32, device="cuda"))
+    else:
+        pred = B.u8(c["pred"])
+        dst = pred if in_place else torch.zeros(c["stride"] * c["h"], dtype=torch.uint8, device="cuda")
+        out = (B.inverse_transform_add_runs(dst, c["stride"], pred, c["stride"], off, off, torch.from_numpy(coeffs).cuda(), c["runs_dq"] if runs is None else runs,
+                                            dequant=stage == "dequant_inverse"),)
+    torch.cuda.synchronize()
+    return tuple(t.cpu().numpy() for t in out)
+
+
+def _mask(c):
+    """Bytes of the destination plane the TUs cover (everything but the row padding)."""
+    m = np.zeros((c["h"], c["stride"]), dtype=bool)
+    m[:, :c["w"]] = True
+    return m.reshape(-1)
+
+
+def test_tu_case_tiles_the_plane_with_every_size():
+    c = wl.tu_frame_case(1920, 1080, 5)
+    assert {(s[0], s[1]) for s in c["sizes"]} == {(2, 1), (2, 0), (3, 0), (4, 0), (5, 0)}
+    assert sum(n << (2 * log2) for (log2, _, _, n, _) in c["sizes"]) == 1920 * 1080 == c["n_coeffs"]
+    cover = np.zeros((1080, 1920), dtype=np.int32)
+    for (x, y, log2, _) in c["tus"]:
+        cover[y:y + (1 << log2), x:x + (1 << log2)] += 1
+    assert (cover == 1).all()
+    assert wl.TU_RUN_DTYPE.itemsize == 28 and c["runs_q"]["count"].sum() == c["n_tus"]
+    # the parameters are inside the reference's asserts (quantize.c:162-168) for every size at every QP
+    for qp in range(52):
+        q = wl.intra_qp(qp)
+        assert (q[:, 0] < 0x8000).all() and (q[:, 1] >= 16).all() and (q[:, 1] <= 27).all() and (q[:, 3] < 0x8000).all() and (q[:, 4] >= 1).all()
+
+
+def test_tu_run_struct_is_28_bytes_in_c(tmp_path):
+    import os
+    import subprocess
+    src = tmp_path / "s.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "hevcasm_hip.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(hevcasm_hip_tu_run), '
+                   'offsetof(hevcasm_hip_tu_run, coeff_first), offsetof(hevcasm_hip_tu_run, log2TrafoSize), offsetof(hevcasm_hip_tu_run, scale));return 0;}\n')
+    exe = tmp_path / "s"
+    subprocess.run(["gcc", "-I", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split() == ["28", "8", "12", "16"]
+    assert [wl.TU_RUN_DTYPE.fields[k][1] for k in ("coeff_first", "log2", "scale")] == [8, 12, 16]
+
+
+def test_tu_runs_entry_points_refuse_without_a_gpu():
+    L = capi.lib()
+    if not L.hevcasm_hip_available():
+        assert L.hevcasm_hip_transform_runs(None, None, 0, None, None, 1, None) == capi.ENODEV
+        assert L.hevcasm_hip_quantize_runs(None, None, None, None, 1, None) == capi.ENODEV
+        for f in (L.hevcasm_hip_inverse_transform_add_runs, L.hevcasm_hip_dequant_inverse_transform_add_runs):
+            assert f(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", STAGES)
+def test_hip_one_launch_for_a_1080p_frames_tus_equals_the_oracle(stage, oracle_lib):
+    c = wl.tu_frame_case(1920, 1080, 41, pad=64)
+    coeffs = None if stage == "forward" else _coeffs(c, 7, "natural" if stage == "dequant_inverse" else "full")
+    got, want = _hip(c, stage, coeffs), _oracle(oracle_lib, c, stage, coeffs)
+    keep = _mask(c) if stage in ("inverse", "dequant_inverse") else slice(None)
+    for g, w in zip(got, want):
+        assert np.array_equal(g[keep] if g.size == c["stride"] * c["h"] else g, w[keep] if w.size == c["stride"] * c["h"] else w), \
+            "%s: %d of %d differ" % (stage, int((g != w).sum()), w.size)
+    if stage in ("inverse", "dequant_inverse"):
+        assert not got[0][~_mask(c)].any(), "bytes outside the TUs were written"
+
+
+@pytest.mark.gpu
+def test_hip_tu_chain_small_frames_extremes_in_place(oracle_lib):
+    """forward -> quantise -> dequantise + inverse + add, every stage one launch, on ragged small planes and extreme content; the last stage also in place."""
+    for (w, h, qp, residual, kind) in ((200, 136, 27, "residual9", "video"), (64, 64, 0, "full", "max"), (132, 76, 51, "min", "zeros"), (96, 160, 22, "max", "noise")):
+        c = wl.tu_frame_case(w, h, 60 + w, qp=qp, kind=kind, residual=residual)
+        (coeffs,), (want_c,) = _hip(c, "forward"), _oracle(oracle_lib, c, "forward")
+        assert np.array_equal(coeffs, want_c), (w, h, "forward")
+        (levels, cbf), (want_l, want_cbf) = _hip(c, "quantize", coeffs), _oracle(oracle_lib, c, "quantize", coeffs)
+        assert np.array_equal(levels, want_l) and np.array_equal(cbf != 0, want_cbf != 0), (w, h, "quantize")
+        for stage in ("inverse", "dequant_inverse"):
+            (want,) = _oracle(oracle_lib, c, stage, levels)
+            assert np.array_equal(_hip(c, stage, levels)[0], want), (w, h, stage)
+            assert np.array_equal(_hip(c, stage, levels, in_place=True)[0], want), (w, h, stage, "in place")
+
+
+@pytest.mark.gpu
+def test_hip_tu_runs_many_runs_one_size_calls_and_bad_arguments(oracle_lib):
+    import torch
+    from hevcasm_amd import batch as B
+    c = wl.tu_frame_case(256, 192, 77)
+    # more runs than one launch's table holds (pieces of 3 TUs), with empty ones in between
+    def pieces(runs):
+        out = []
+        for r in runs:
+            n2 = 1 << (2 * int(r["log2"]))
+            for s in range(0, int(r["count"]), 3):
+                out.append((int(r["first"]) + s, min(3, int(r["count"]) - s), int(r["coeff_first"]) + s * n2, r["log2"], r["tr_type"], 0, r["scale"], r["shift"], r["offset"]))
+                out.append((0, 0, 0, 3, 0, 0, r["scale"], r["shift"], r["offset"]))
+        return np.array(out, dtype=wl.TU_RUN_DTYPE)
+    pq, pdq = pieces(c["runs_q"]), pieces(c["runs_dq"])
+    assert int((pq["count"] > 0).sum()) > 64
+    coeffs = _coeffs(c, 9)
+    assert np.array_equal(_hip(c, "forward", runs=pq)[0], _oracle(oracle_lib, c, "forward")[0])
+    for g, w in zip(_hip(c, "quantize", coeffs, runs=pq), _oracle(oracle_lib, c, "quantize", coeffs)):
+        assert np.array_equal(g, w)
+    for stage in ("inverse", "dequant_inverse"):
+        assert np.array_equal(_hip(c, stage, coeffs, runs=pdq)[0], _oracle(oracle_lib, c, stage, coeffs)[0]), stage
+    # a run through the runs entry == the one-size batch call
+    (log2, tr, first, count, cf) = c["sizes"][2]
+    one = B.transform(torch.from_numpy(c["residual"]).cuda(), c["stride"], B.off32(c["off"][first:first + count]), tr, log2)
+    assert np.array_equal(one.cpu().numpy(), _hip(c, "forward")[0][cf:cf + (count << (2 * log2))])
+    # argument checks: nothing is launched for a call with a bad run
+    L = capi.lib()
+    dev = torch.zeros(1 << 16, dtype=torch.int16, device="cuda")
+    off = B.off32(np.zeros(4, dtype=np.uint32))
+    def run(**kw):
+        r = np.zeros(1, dtype=wl.TU_RUN_DTYPE)
+        r["count"], r["log2"], r["scale"], r["shift"], r["offset"] = 1, 3, 100, 20, 100
+        for k, v in kw.items():
+            r[k] = v
+        return r
+    fwd = lambda r, n=1: L.hevcasm_hip_transform_runs(dev.data_ptr(), dev.data_ptr(), 64, off.data_ptr(), r.ctypes.data, n, None)
+    qnt = lambda r: L.hevcasm_hip_quantize_runs(dev.data_ptr(), dev.data_ptr(), dev.data_ptr(), r.ctypes.data, 1, None)
+    inv = lambda r, f=L.hevcasm_hip_inverse_transform_add_runs: f(dev.data_ptr(), 64, dev.data_ptr(), 64, off.data_ptr(), off.data_ptr(), dev.data_ptr(), r.ctypes.data, 1, None)
+    deq = lambda r: inv(r, L.hevcasm_hip_dequant_inverse_transform_add_runs)
+    assert fwd(run()) == 0 and qnt(run()) == 0 and inv(run()) == 0 and deq(run(shift=5)) == 0
+    assert fwd(run(), 0) == 0 and fwd(run(count=0)) == 0
+    for bad in (run(log2=1), run(log2=6), run(tr_type=1), run(tr_type=2, log2=2), run(reserved=1)):
+        assert fwd(bad) == capi.EINVAL and inv(bad) == capi.EINVAL and deq(bad) == capi.EINVAL
+    assert fwd(run(), -1) == capi.EINVAL
+    assert L.hevcasm_hip_transform_runs(dev.data_ptr(), None, 64, off.data_ptr(), run().ctypes.data, 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_transform_runs(dev.data_ptr(), dev.data_ptr(), 64, off.data_ptr(), None, 1, None) == capi.EINVAL
+    for bad in (run(shift=15), run(shift=28), run(scale=0x8000), run(scale=-1), run(offset=0x8000), run(offset=-1), run(log2=6), run(reserved=2)):
+        assert qnt(bad) == capi.EINVAL
+    for bad in (run(shift=0), run(shift=32), run(scale=40000), run(scale=-40000)):
+        assert deq(bad) == capi.EINVAL
+    assert inv(run(shift=0, scale=40000)) == 0          # the plain inverse ignores the quantiser fields
+    assert fwd(run(first=0xffffffff, count=2)) == capi.EINVAL and fwd(run(coeff_first=0xffffff00, count=8)) == capi.EINVAL
+    torch.cuda.synchronize()

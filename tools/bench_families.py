@@ -293,6 +293,70 @@ def bench_cost_latency(reps=30):
     torch.cuda.empty_cache()
 
 
+def bench_tu_latency(reps=30):
+    """Round 6: the transform stages of ONE 1080p frame's residual quad-tree (4x4 DST / DCT, 8x8, 16x16, 32x32; each size with its HEVC quantiser parameters) as
+    ONE launch per stage (hevcasm_hip_transform_runs, _quantize_runs, _dequant_inverse_transform_add_runs) next to what they replace: a launch per size and stage.
+    Three frames rotate."""
+    frames3 = []
+    for k in range(3):
+        c = wl.tu_frame_case(1920, 1080, 970 + k, pad=64)
+        frames3.append((c, dict(res=torch.from_numpy(c["residual"]).cuda(), pred=B.u8(c["pred"]), off=B.off32(c["off"]), coeffs=torch.zeros(c["n_coeffs"], dtype=torch.int16, device="cuda"),
+                                levels=torch.zeros(c["n_coeffs"], dtype=torch.int16, device="cuda"), cbf=torch.zeros(c["n_tus"], dtype=torch.int32, device="cuda"),
+                                dst=torch.zeros(c["stride"] * c["h"], dtype=torch.uint8, device="cuda"))))
+    c0 = frames3[0][0]
+
+    def stage_runs(stage):
+        def fn(i):
+            c, d = frames3[i % 3]
+            if stage == "transform":
+                B.transform_runs(d["res"], c["stride"], d["off"], c["runs_q"], c["n_coeffs"], out=d["coeffs"])
+            elif stage == "quantize":
+                B.quantize_runs(d["coeffs"], c["runs_q"], c["n_tus"], out=d["levels"], cbf=d["cbf"])
+            else:
+                B.inverse_transform_add_runs(d["dst"], c["stride"], d["pred"], c["stride"], d["off"], d["off"], d["levels"], c["runs_dq"], dequant=True)
+        return fn
+
+    def stage_per_size(stage):
+        def fn(i):
+            c, d = frames3[i % 3]
+            for (log2, tr, first, count, cf), rq, rd in zip(c["sizes"], c["runs_q"], c["runs_dq"]):
+                e = cf + (count << (2 * log2))
+                if stage == "transform":
+                    B.transform(d["res"], c["stride"], d["off"][first:first + count], tr, log2, out=d["coeffs"][cf:e])
+                elif stage == "quantize":
+                    B.quantize(d["coeffs"][cf:e], int(rq["scale"]), int(rq["shift"]), int(rq["offset"]), 1 << (2 * log2), out=d["levels"][cf:e], cbf=d["cbf"][first:first + count])
+                else:
+                    B.dequant_inverse_transform_add(d["dst"], c["stride"], d["pred"], c["stride"], d["off"][first:first + count], d["off"][first:first + count], d["levels"][cf:e],
+                                                    int(rd["scale"]), int(rd["shift"]), tr, log2)
+        return fn
+
+    def chain(per_size):
+        fns = [(stage_per_size if per_size else stage_runs)(s) for s in ("transform", "quantize", "dequant_inverse")]
+        def fn(i):
+            for f in fns:
+                f(i)
+        return fn
+
+    px = 1920 * 1080
+    rows = [("transform", 4 * px + 4 * c0["n_tus"]), ("quantize", 4 * px + 4 * c0["n_tus"]), ("dequant_inverse_transform_add", 4 * px + 8 * c0["n_tus"])]
+    for (stage, bytes_frame) in rows:
+        key = "dequant_inverse" if stage.startswith("dequant") else stage
+        for name, fn, launches in (("frame TUs, one launch", stage_runs(key), 1), ("frame TUs, a launch per size", stage_per_size(key), len(c0["sizes"]))):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            report("%s %s" % (stage, name), c0["n_tus"], bytes_frame // c0["n_tus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=launches,
+                   note="one 1080p frame's residual quad-tree (%d TUs); HIP events around the frame" % c0["n_tus"])
+    for name, fn, launches in (("three stages, one launch each", chain(False), 3), ("three stages, a launch per size and stage", chain(True), 3 * len(c0["sizes"]))):
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        report("transform+quantize+dequant_inverse %s" % name, c0["n_tus"], 12 * px // c0["n_tus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=launches,
+               note="forward transform -> quantise -> dequantise + inverse + add of one 1080p frame's TUs")
+    del frames3
+    torch.cuda.empty_cache()
+
+
 def bench_transform(coeffs_per_launch=1 << 26, only=None, label=""):
     for tr, lg in wl.TRANSFORMS:
         if only and (tr, lg) not in only:
@@ -592,4 +656,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, predlat=bench_pred_latency, costlat=bench_cost_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, costlat=bench_cost_latency, tulat=bench_tu_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
