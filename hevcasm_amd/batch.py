@@ -210,6 +210,19 @@ def inverse_transform_add_runs(dst, stride_dst, pred, stride_pred, dst_off, pred
     return dst
 
 
+def transform_quantize_reconstruct_runs(rec, stride_rec, src, stride_src, pred, stride_pred, rec_off, src_off, pred_off, runs_q, runs_dq, n_coeffs, n_tus, levels=None, cbf=None):
+    """hevcasm_hip_transform_quantize_reconstruct_runs: src - pred -> transform -> quantise -> dequantise -> inverse + add for a frame's TUs in ONE launch
+    -> (rec, levels, cbf)."""
+    runs_q, runs_dq = _tu_runs(runs_q), _tu_runs(runs_dq)
+    assert len(runs_q) == len(runs_dq)
+    levels = torch.empty(n_coeffs, dtype=torch.int16, device=src.device) if levels is None else levels
+    cbf = torch.empty(n_tus, dtype=torch.int32, device=src.device) if cbf is None else cbf
+    check(lib().hevcasm_hip_transform_quantize_reconstruct_runs(rec.data_ptr(), stride_rec, src.data_ptr(), stride_src, pred.data_ptr(), stride_pred, rec_off.data_ptr(), src_off.data_ptr(),
+                                                                pred_off.data_ptr(), levels.data_ptr(), cbf.data_ptr(), runs_q.ctypes.data, runs_dq.ctypes.data, len(runs_q), _stream()),
+          "transform_quantize_reconstruct_runs")
+    return rec, levels, cbf
+
+
 def _result_rows(out, n, like):
     """The (dx, dy, cost) table of n answers: allocated, or the caller's, checked -- the entry points write 12 n bytes through a raw pointer
     (and, for small launches, memset them first), so a short, strided, int64 or other-device `out` would be overrun or silently misread."""

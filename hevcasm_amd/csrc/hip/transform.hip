@@ -598,9 +598,227 @@ static int inverse_runs_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, p
 	return 0;
 }
 
+// ---- the residual loop of a frame's TUs in ONE launch: source - prediction -> transform -> quantise -> dequantise -> inverse + add (round 6) ---------------
+//
+// An encoder reconstructs every TU it codes: hevcasm_transform, hevcasm_quantize, hevcasm_quantize_inverse, hevcasm_inverse_transform_add (residual_decode.h:82,
+// quantize.h:78, :57, residual_decode.h:54) back to back.  As three launches the residual, the coefficients and the levels each cross HBM twice (16 bytes per
+// pixel all told); here they never leave the workgroup: 5 bytes per pixel (source, prediction, reconstruction in, 2-byte levels out) + the descriptors.  What
+// makes it cheap to write: in the forward bodies a lane ends holding ROW t of its block's coefficients -- exactly what the inverse bodies start from (4x4: a
+// lane holds the whole block in both) -- so the fused body is the forward body fed from source - prediction, the quantiser and dequantiser on that row in
+// registers (levels stored, the flag OR-ed over the block's lanes), and the inverse body from behind its loads.  The bodies are the .inc files above through
+// their hooks; 8x8 takes the tile form of the inverse (the lane form wants a lane per block, the forward tile has a lane per row); 32x32 the VALU form of the
+// forward transform (the matrix-core form leaves a lane with a column).  One 20 KiB LDS buffer serves forward and inverse tiles of every size in turn.
+constexpr int kFusedLdsDwords = 8 * InverseTiles<32>::DWORDS;      // the largest tenant: eight 32x32 blocks' inverse tiles
+static_assert(kFusedLdsDwords * 4 >= (kThreads / 32) * Tile<32>::HALFWORDS * 2 && kFusedLdsDwords * 4 >= (kThreads / 16) * Tile<16>::HALFWORDS * 2 &&
+		kFusedLdsDwords >= (kThreads / 16) * InverseTiles<16>::DWORDS && kFusedLdsDwords >= (kThreads / 8) * InverseTiles<8>::DWORDS, "fused LDS buffer too small");
+
+// N source bytes minus N prediction bytes
+template <int N> __device__ __forceinline__ void residual_row(const uint8_t *c, const uint8_t *p, int (&v)[N])
+{
+	constexpr int CB = N >= 16 ? 16 : N;
+#pragma unroll
+	for (int q = 0; q < N / CB; ++q)
+	{
+		Chunk<CB> a, b;
+		a.load(c + q * CB);
+		b.load(p + q * CB);
+#pragma unroll
+		for (int k = 0; k < CB; ++k) v[q * CB + k] = (int)((a.d[k / 4] >> (8 * (k % 4))) & 0xff) - (int)((b.d[k / 4] >> (8 * (k % 4))) & 0xff);
+	}
+}
+
+// quantize.c:160-186 (abs() in int, so -32768 becomes 32768) and quantize.c:53-62, as quant.hip has them; scale24 / dscale24 carry 24 significant bits
+__device__ __forceinline__ int fused_quantize(int v, int scale24, int round, int shift)
+{
+	const int mag = ((v < 0 ? -v : v) * scale24 + round) >> shift;
+	return clip3(-32768, 32767, v < 0 ? -mag : mag);
+}
+__device__ __forceinline__ int fused_dequantize(int level, int dscale24, int dround, int dshift) { return clip3(-32768, 32767, (level * dscale24 + dround) >> dshift); }
+
+template <int N>
+__device__ __forceinline__ void fused_tile_workgroup(uint32_t *lds,
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ cur_off, const uint32_t *__restrict__ pred_off,
+	int16_t *__restrict__ levels, int *__restrict__ cbf, int qscale, int qshift, int qoffset, int dscale, int dshift, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+	constexpr bool DST = false;
+	int row[N];
+	uint32_t row_blk = 0, row_t = 0;
+	bool row_live = false;
+#define HEVC_WG wg_in_batch
+	{
+		const uint32_t *src_off = cur_off;
+#define HEVC_FWD_TILES_DECL int16_t *tiles = reinterpret_cast<int16_t *>(lds)
+#define HEVC_FWD_ROW_IN(off1, t1, v) residual_row<N>(cur + off1 + (ptrdiff_t)t1 * stride_cur, pred + pred_off[blk1] + (ptrdiff_t)t1 * stride_pred, v)
+#define HEVC_FWD_ROW_OUT(blk, t, v, live) \
+		{ \
+			_Pragma("unroll") \
+			for (int k = 0; k < N; ++k) row[k] = v[k]; \
+			row_blk = blk; row_t = t; row_live = live; \
+		}
+#include "transform_forward_tile.inc"
+#undef HEVC_FWD_TILES_DECL
+#undef HEVC_FWD_ROW_IN
+#undef HEVC_FWD_ROW_OUT
+	}
+	{
+		const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+		const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
+		int lev[N], any = 0;
+#pragma unroll
+		for (int k = 0; k < N; ++k)
+		{
+			lev[k] = fused_quantize(row[k], scale24, qround, qshift);
+			any |= lev[k];
+			row[k] = fused_dequantize(lev[k], dscale24, dround, dshift);
+		}
+		if (row_live) global_row_store<N, true>(levels + (size_t)row_blk * (N * N) + row_t * N, lev);
+#pragma unroll
+		for (int d = N / 2; d >= 1; d >>= 1) any |= __shfl_xor(any, d, kWave);      // the block's N lanes are neighbours inside one wave
+		if (row_live && row_t == 0) cbf[row_blk] = any;
+	}
+	__syncthreads();      // the forward tiles have been read: their storage becomes the inverse tiles
+	{
+		constexpr bool DEQUANT = false;
+		const int scale = 0, shift = 1;
+#define HEVC_INV_TILES_DECL uint32_t *tiles = lds
+#define HEVC_INV_ROW_IN(blk, t, v, raw) \
+		{ \
+			_Pragma("unroll") \
+			for (int k = 0; k < N; ++k) v[k] = row[k]; \
+		}
+#include "transform_inverse_tile.inc"
+#undef HEVC_INV_TILES_DECL
+#undef HEVC_INV_ROW_IN
+	}
+#undef HEVC_WG
+}
+
+template <bool DST>
+__device__ __forceinline__ void fused_lane4_workgroup(
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ cur_off, const uint32_t *__restrict__ pred_off,
+	int16_t *__restrict__ levels, int *__restrict__ cbf, int qscale, int qshift, int qoffset, int dscale, int dshift, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+	const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+	const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
+	uint32_t lev_pairs[8], deq_pairs[8];      // row k, columns (2j, 2j + 1) in dword 2k + j, low half first: the coefficient block as it lies in memory
+	int any = 0;
+#define HEVC_WG wg_in_batch
+	{
+		const int16_t *src = reinterpret_cast<const int16_t *>(cur);      // only the hooks read memory
+		const uint32_t *src_off = cur_off;
+#define HEVC_FWD4_ROW_IN(p, y, v) { (void)p; residual_row<4>(cur + cur_off[blk] + (ptrdiff_t)y * stride_cur, pred + pred_off[blk] + (ptrdiff_t)y * stride_pred, v); }
+#define HEVC_FWD4_ROW_OUT(blk, k, coef) \
+		{ \
+			int l_[4], d_[4]; \
+			_Pragma("unroll") \
+			for (int x = 0; x < 4; ++x) \
+			{ \
+				l_[x] = fused_quantize(coef[x], scale24, qround, qshift); \
+				any |= l_[x]; \
+				d_[x] = fused_dequantize(l_[x], dscale24, dround, dshift); \
+			} \
+			lev_pairs[2 * k] = ((uint32_t)l_[0] & 0xffffu) | ((uint32_t)l_[1] << 16); lev_pairs[2 * k + 1] = ((uint32_t)l_[2] & 0xffffu) | ((uint32_t)l_[3] << 16); \
+			deq_pairs[2 * k] = ((uint32_t)d_[0] & 0xffffu) | ((uint32_t)d_[1] << 16); deq_pairs[2 * k + 1] = ((uint32_t)d_[2] & 0xffffu) | ((uint32_t)d_[3] << 16); \
+		}
+#include "transform_forward4_lane.inc"
+#undef HEVC_FWD4_ROW_IN
+#undef HEVC_FWD4_ROW_OUT
+	}
+	{
+		const uint32_t blk = wg_in_batch * kThreads + threadIdx.x;      // (the forward body has returned for lanes beyond the batch)
+		Chunk<16> c0, c1;
+#pragma unroll
+		for (int i = 0; i < 4; ++i) { c0.d[i] = lev_pairs[i]; c1.d[i] = lev_pairs[4 + i]; }
+		uint8_t *out = reinterpret_cast<uint8_t *>(levels + (size_t)blk * 16);
+		c0.store(out);
+		c1.store(out + 16);
+		cbf[blk] = any;
+	}
+	{
+		constexpr int N = 4;
+		constexpr bool DEQUANT = false;
+		const int scale = 0, shift = 1;
+#define HEVC_INVLANE_IN(blk, r) \
+		{ \
+			_Pragma("unroll") \
+			for (int i = 0; i < 8; ++i) r[i] = deq_pairs[i]; \
+		}
+#include "transform_inverse_lane.inc"
+#undef HEVC_INVLANE_IN
+	}
+#undef HEVC_WG
+}
+
+constexpr uint32_t kFusedRunBlocksPerWg[5] = { kThreads, kThreads, kThreads / 8, kThreads / 16, kThreads / 32 };
+
+struct FusedRunsArgs
+{
+	uint8_t *dst;
+	const uint8_t *cur, *pred;
+	ptrdiff_t stride_dst, stride_cur, stride_pred;
+	const uint32_t *dst_off, *cur_off, *pred_off;
+	int16_t *levels;
+	int *cbf;
+	TuRunTable table;
+};
+
+__global__ __launch_bounds__(kThreads) void fused_tu_runs_kernel(const FusedRunsArgs a)
+{
+	__shared__ __attribute__((aligned(16))) uint32_t lds[kFusedLdsDwords];
+	uint32_t wg;
+	const TuRunDev r = find_tu_run(a.table, wg);
+	const uint32_t *dof = a.dst_off + r.first, *cof = a.cur_off + r.first, *pof = a.pred_off + r.first;
+	int16_t *lv = a.levels + r.coeff_first;
+	int *cbf = a.cbf + r.first;
+#define HEVC_FUSED_ARGS a.dst, a.stride_dst, a.cur, a.stride_cur, a.pred, a.stride_pred, dof, cof, pof, lv, cbf, r.scale, r.shift, r.offset, r.dscale, r.dshift, r.count, wg
+	switch (r.variant)
+	{
+	case 0: fused_lane4_workgroup<true>(HEVC_FUSED_ARGS); break;
+	case 1: fused_lane4_workgroup<false>(HEVC_FUSED_ARGS); break;
+	case 2: fused_tile_workgroup<8>(lds, HEVC_FUSED_ARGS); break;
+	case 3: fused_tile_workgroup<16>(lds, HEVC_FUSED_ARGS); break;
+	case 4: fused_tile_workgroup<32>(lds, HEVC_FUSED_ARGS); break;
+	default: break;
+	}
+#undef HEVC_FUSED_ARGS
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
+	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs_quantize || !runs_dequantize || !rec || !src || !pred || !rec_off || !src_off || !pred_off || !levels || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<TuRunTable> tables;
+	std::vector<uint32_t> grids;
+	if (int e = build_tu_tables(runs_quantize, n_runs, [=](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+			if (int e = tu_variant(r, variant)) return e;
+			const hevcasm_hip_tu_run &d = runs_dequantize[&r - runs_quantize];
+			if (d.first != r.first || d.count != r.count || d.coeff_first != r.coeff_first || d.log2TrafoSize != r.log2TrafoSize || d.trType != r.trType || d.reserved)
+				return set_error(HEVCASM_HIP_EINVAL, "run: the dequantiser's run must describe the same units as the quantiser's");
+			// the domains of hevcasm_hip_quantize_batch (quantize.c:162-168) and of hevcasm_hip_dequant_inverse_transform_add_batch
+			if (r.scale < 0 || r.scale >= 0x8000 || r.offset < 0 || r.offset >= 0x8000 || r.shift < 16 || r.shift > 27)
+				return set_error(HEVCASM_HIP_EINVAL, "run: quantiser scale/offset/shift outside the reference's domain (0 <= scale, offset < 0x8000; 16 <= shift <= 27)");
+			if (d.shift < 1 || d.shift > 31 || d.scale < -32768 || d.scale > 32767) return set_error(HEVCASM_HIP_EINVAL, "run: dequantiser shift out of range or scale beyond int16");
+			bpwg = kFusedRunBlocksPerWg[variant];
+			return 0; }, tables, grids, runs_dequantize)) return e;
+	for (size_t i = 0; i < tables.size(); ++i)
+	{
+		FusedRunsArgs a = { rec, src, pred, stride_rec, stride_src, stride_pred, rec_off, src_off, pred_off, levels, cbf, tables[i] };
+		hipLaunchKernelGGL(fused_tu_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("fused_tu_runs_kernel")) return e;
+	}
+	return 0;
+}
 
 extern "C" int hevcasm_hip_inverse_transform_add_runs(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,

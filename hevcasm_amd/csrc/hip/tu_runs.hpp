@@ -21,6 +21,7 @@ struct TuRunDev
 	uint32_t first, count;         // descriptor entries
 	uint32_t coeff_first;          // first int16 element of the run's coefficient blocks
 	int scale, shift, offset;      // the run's (de)quantiser parameters
+	int dscale, dshift;            // the dequantiser's beside the quantiser's (the fused transform + quantise + reconstruct kernel only)
 	uint32_t variant;              // which workgroup body
 };
 
@@ -49,7 +50,8 @@ __device__ __forceinline__ TuRunDev find_tu_run(const TuRunTable &t, uint32_t &w
 // host: the caller's runs -> device tables of at most kMaxTuRuns runs each, LARGEST units first (the launch ends when its last wave does, and a 32x32
 // unit that starts in the last generation of workgroups would be the whole tail).  `variant_of(run, &blocks_per_wg)` validates a run and names its body.
 template <class VariantOf>
-static int build_tu_tables(const hevcasm_hip_tu_run *runs, int n_runs, VariantOf variant_of, std::vector<TuRunTable> &tables, std::vector<uint32_t> &grids)
+static int build_tu_tables(const hevcasm_hip_tu_run *runs, int n_runs, VariantOf variant_of, std::vector<TuRunTable> &tables, std::vector<uint32_t> &grids,
+		const hevcasm_hip_tu_run *dequant_runs = nullptr)
 {
 	std::vector<TuRunDev> all;
 	all.reserve((size_t)n_runs);
@@ -65,6 +67,7 @@ static int build_tu_tables(const hevcasm_hip_tu_run *runs, int n_runs, VariantOf
 		d.wg_count = ceil_div(runs[i].count, blocks_per_wg);
 		d.first = runs[i].first; d.count = runs[i].count; d.coeff_first = runs[i].coeff_first;
 		d.scale = runs[i].scale; d.shift = runs[i].shift; d.offset = runs[i].offset;
+		d.dscale = dequant_runs ? dequant_runs[i].scale : 0; d.dshift = dequant_runs ? dequant_runs[i].shift : 0;
 		d.variant = variant;
 		all.push_back(d);
 	}

@@ -451,10 +451,10 @@ def tu_partition(w, h, seed, split=(0.8, 0.6, 0.45), dst_share=0.3):
     return tus
 
 
-def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0):
+def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0, src_kind=None):
     """One plane's TUs (tu_partition) as RUNS for the four transform-stage entry points: an int16 residual plane and 8-bit prediction / destination planes (stride
     w + pad; offsets in elements of each), the TUs sorted by (size, type) with z-scan order inside a run, coefficients of the runs laid end to end (w x h in all),
-    every run with the (de)quantiser parameters HEVC uses for its size at `qp` (intra_qp).  Keys: residual, pred, stride, off (uint32, shared by all planes),
+    every run with the (de)quantiser parameters HEVC uses for its size at `qp` (intra_qp).  Keys: residual, pred, src, stride, off (uint32, shared by all planes),
     runs_q / runs_dq (TU_RUN_DTYPE with the quantiser's / the dequantiser's parameters), sizes [(log2, tr_type, first, count, coeff_first)], n_tus, n_coeffs."""
     tus = np.array(tu_partition(w, h, seed), dtype=np.int64)
     order = np.lexsort((np.arange(len(tus)), -tus[:, 3], tus[:, 2]))      # 4x4 DST, 4x4 DCT, 8x8, 16x16, 32x32
@@ -474,4 +474,5 @@ def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0):
             start = i
     assert coeff == w * h
     return dict(w=w, h=h, stride=stride, residual=fill_i16(stride * h, seed + 30, residual), pred=fill_u8(stride * h, seed + 31, kind), off=off,
+                src=fill_u8(stride * h, seed + 32, kind if src_kind is None else src_kind),      # a source plane for the fused residual loop (src - pred is its residual)
                 runs_q=np.array(runs_q, dtype=TU_RUN_DTYPE), runs_dq=np.array(runs_dq, dtype=TU_RUN_DTYPE), sizes=sizes, n_tus=len(tus), n_coeffs=coeff, tus=tus)

@@ -416,6 +416,18 @@ int hevcasm_hip_dequant_inverse_transform_add_runs(
 	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *levels,
 	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
 
+/* An encoder's residual loop for a frame's TUs in ONE launch (round 6): per TU  src - pred  ->  hevcasm_transform  ->  hevcasm_quantize  (levels and cbf out)
+ * ->  hevcasm_quantize_inverse  ->  hevcasm_inverse_transform_add  (residual_decode.h:82, quantize.h:78, :57, residual_decode.h:54), exactly the results of
+ * hevcasm_hip_transform_runs on the int16 plane src - pred, hevcasm_hip_quantize_runs with runs_quantize, and hevcasm_hip_dequant_inverse_transform_add_runs
+ * with runs_dequantize -- without the residual, the coefficients or the dequantised coefficients ever reaching memory (5 bytes per pixel cross HBM instead of
+ * 16).  runs_quantize[i] and runs_dequantize[i] describe the same units (first, count, coeff_first, size, type: checked) and carry the quantiser's (scale,
+ * shift, offset) and the dequantiser's (scale, shift); levels and cbf are laid out as for hevcasm_hip_quantize_runs.  rec may equal pred with the same offsets
+ * and stride (in-place reconstruction); offsets are in bytes of their planes. */
+int hevcasm_hip_transform_quantize_reconstruct_runs(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
+	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream);
+
 /* The same two calls for TWO planes that share one PU list -- Cb and Cr of a 4:2:0 frame: same geometry, same motion
  * vectors, same fractions -- in one launch: plane a and plane b of the destination and of each reference have the same
  * stride and take the same offsets.  Results are exactly those of two single-plane calls; a frame's chroma launches are

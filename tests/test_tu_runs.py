@@ -98,6 +98,7 @@ def test_tu_runs_entry_points_refuse_without_a_gpu():
         assert L.hevcasm_hip_quantize_runs(None, None, None, None, 1, None) == capi.ENODEV
         for f in (L.hevcasm_hip_inverse_transform_add_runs, L.hevcasm_hip_dequant_inverse_transform_add_runs):
             assert f(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
+        assert L.hevcasm_hip_transform_quantize_reconstruct_runs(None, 0, None, 0, None, 0, None, None, None, None, None, None, None, 1, None) == capi.ENODEV
 
 
 @pytest.mark.gpu
@@ -127,6 +128,81 @@ def test_hip_tu_chain_small_frames_extremes_in_place(oracle_lib):
             (want,) = _oracle(oracle_lib, c, stage, levels)
             assert np.array_equal(_hip(c, stage, levels)[0], want), (w, h, stage)
             assert np.array_equal(_hip(c, stage, levels, in_place=True)[0], want), (w, h, stage, "in place")
+
+
+def _fused_oracle(oracle_lib, c):
+    """src - pred through the oracle's one-size batches, run by run: (levels, cbf, reconstruction)."""
+    c2 = dict(c, residual=(c["src"].astype(np.int16) - c["pred"].astype(np.int16)))
+    (coeffs,) = _oracle(oracle_lib, c2, "forward")
+    levels, cbf = _oracle(oracle_lib, c2, "quantize", coeffs)
+    (rec,) = _oracle(oracle_lib, c2, "dequant_inverse", levels)
+    return levels, cbf, rec
+
+
+def _fused_hip(c, in_place=False, runs_q=None, runs_dq=None):
+    import torch
+    from hevcasm_amd import batch as B
+    off, pred = B.off32(c["off"]), B.u8(c["pred"])
+    rec = pred if in_place else torch.zeros(c["stride"] * c["h"], dtype=torch.uint8, device="cuda")
+    out = B.transform_quantize_reconstruct_runs(rec, c["stride"], B.u8(c["src"]), c["stride"], pred, c["stride"], off, off, off, c["runs_q"] if runs_q is None else runs_q,
+                                                c["runs_dq"] if runs_dq is None else runs_dq, c["n_coeffs"], c["n_tus"],
+                                                levels=torch.zeros(c["n_coeffs"], dtype=torch.int16, device="cuda"), cbf=torch.zeros(c["n_tus"], dtype=torch.int32, device="cuda"))
+    torch.cuda.synchronize()
+    rec, levels, cbf = (t.cpu().numpy() for t in out)
+    return levels, cbf, rec
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,qp,kind,src_kind,pad", [(1920, 1080, 27, "video", None, 64), (200, 136, 12, "noise", None, 0), (64, 64, 0, "zeros", "max", 0),
+                                                      (132, 76, 51, "max", "zeros", 8), (96, 160, 30, "video", "noise", 0), (256, 192, 4, "video", None, 0)])
+def test_hip_fused_residual_loop_equals_the_oracles_four_functions(w, h, qp, kind, src_kind, pad, oracle_lib):
+    """hevcasm_hip_transform_quantize_reconstruct_runs == transform -> quantise -> dequantise -> inverse + add of src - pred through the oracle, every TU size,
+    each with its parameters: the levels, the flags, the reconstruction; nothing outside the TUs written; also in place (rec == pred)."""
+    c = wl.tu_frame_case(w, h, 80 + w, qp=qp, kind=kind, src_kind=src_kind, pad=pad)
+    want_levels, want_cbf, want_rec = _fused_oracle(oracle_lib, c)
+    for in_place in (False, True):
+        levels, cbf, rec = _fused_hip(c, in_place=in_place)
+        assert np.array_equal(levels, want_levels), "levels: %d of %d differ" % (int((levels != want_levels).sum()), levels.size)
+        assert np.array_equal(cbf, want_cbf), "cbf"
+        m = _mask(c)
+        assert np.array_equal(rec[m], want_rec[m]), "reconstruction: %d of %d differ" % (int((rec[m] != want_rec[m]).sum()), int(m.sum()))
+        assert np.array_equal(rec[~m], c["pred"][~m] if in_place else np.zeros_like(rec[~m])), "bytes outside the TUs were written"
+    assert want_cbf.any() or qp > 40
+
+
+@pytest.mark.gpu
+def test_hip_fused_residual_loop_equals_the_three_launches_and_refuses_bad_runs():
+    import torch
+    from hevcasm_amd import batch as B
+    c = wl.tu_frame_case(640, 360, 13, qp=20, pad=16)
+    levels, cbf, rec = _fused_hip(c)
+    res = torch.from_numpy(c["src"].astype(np.int16) - c["pred"].astype(np.int16)).cuda()
+    off, pred = B.off32(c["off"]), B.u8(c["pred"])
+    coeffs = B.transform_runs(res, c["stride"], off, c["runs_q"], c["n_coeffs"])
+    l3, f3 = B.quantize_runs(coeffs, c["runs_q"], c["n_tus"])
+    r3 = B.inverse_transform_add_runs(torch.zeros(c["stride"] * c["h"], dtype=torch.uint8, device="cuda"), c["stride"], pred, c["stride"], off, off, l3, c["runs_dq"], dequant=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(levels, l3.cpu().numpy()) and np.array_equal(cbf, f3.cpu().numpy()) and np.array_equal(rec, r3.cpu().numpy())
+    # the two run arrays must describe the same units; both parameter sets are checked
+    L = capi.lib()
+    def call(rq, rdq, n=None):
+        z = torch.zeros(1 << 16, dtype=torch.int16, device="cuda")
+        return L.hevcasm_hip_transform_quantize_reconstruct_runs(z.data_ptr(), 64, z.data_ptr(), 64, z.data_ptr(), 64, off.data_ptr(), off.data_ptr(), off.data_ptr(), z.data_ptr(), z.data_ptr(),
+                                                                 rq.ctypes.data, rdq.ctypes.data, len(rq) if n is None else n, None)
+    rq, rdq = c["runs_q"][:1].copy(), c["runs_dq"][:1].copy()
+    rq["count"] = rdq["count"] = 1
+    assert call(rq, rdq) == 0 and call(rq, rdq, 0) == 0
+    for field, value in (("count", 2), ("first", 1), ("coeff_first", 16), ("log2", 3), ("tr_type", 0), ("reserved", 1)):
+        bad = rdq.copy(); bad[field] = value
+        assert call(rq, bad) == capi.EINVAL, field
+    for field, value in (("shift", 15), ("shift", 28), ("scale", 0x8000), ("offset", -1)):
+        bad = rq.copy(); bad[field] = value
+        assert call(bad, rdq) == capi.EINVAL, field
+    for field, value in (("shift", 0), ("shift", 32), ("scale", 40000)):
+        bad = rdq.copy(); bad[field] = value
+        assert call(rq, bad) == capi.EINVAL, field
+    assert call(rq, rdq, -1) == capi.EINVAL
+    torch.cuda.synchronize()
 
 
 @pytest.mark.gpu

@@ -347,13 +347,84 @@ def bench_tu_latency(reps=30):
             torch.cuda.synchronize()
             report("%s %s" % (stage, name), c0["n_tus"], bytes_frame // c0["n_tus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=launches,
                    note="one 1080p frame's residual quad-tree (%d TUs); HIP events around the frame" % c0["n_tus"])
+    srcs = [B.u8(c["src"]) for c, _ in frames3]
+
+    def fused(i):
+        c, d = frames3[i % 3]
+        B.transform_quantize_reconstruct_runs(d["dst"], c["stride"], srcs[i % 3], c["stride"], d["pred"], c["stride"], d["off"], d["off"], d["off"], c["runs_q"], c["runs_dq"], c["n_coeffs"], c["n_tus"],
+                                              levels=d["levels"], cbf=d["cbf"])
+
+    def residual_then_chain(i):
+        c, d = frames3[i % 3]
+        d["res"] = srcs[i % 3].to(torch.int16) - d["pred"].to(torch.int16)      # the step a codec does itself in front of hevcasm_transform
+        chain_runs(i)
+
+    chain_runs = chain(False)
+    for i in range(3):
+        fused(i)
+    torch.cuda.synchronize()
+    report("transform_quantize_reconstruct frame TUs, ONE launch (fused: residual, coefficients, levels stay in the workgroup)", c0["n_tus"], (5 * px + 16 * c0["n_tus"]) // c0["n_tus"], timed(fused, reps),
+           size="%d sizes" % len(c0["sizes"]), frames=1, launches=1, note="source - prediction -> transform -> quantise -> dequantise -> inverse + add of one 1080p frame's TUs; 5 bytes per pixel")
+    for i in range(3):
+        residual_then_chain(i)
+    torch.cuda.synchronize()
+    report("residual (torch) + three stages, one launch each", c0["n_tus"], 16 * px // c0["n_tus"], timed(residual_then_chain, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=6,
+           note="what the fused launch replaces: int16 residual plane, coefficients and levels each cross HBM twice: 16 bytes per pixel")
     for name, fn, launches in (("three stages, one launch each", chain(False), 3), ("three stages, a launch per size and stage", chain(True), 3 * len(c0["sizes"]))):
         for i in range(3):
             fn(i)
         torch.cuda.synchronize()
         report("transform+quantize+dequant_inverse %s" % name, c0["n_tus"], 12 * px // c0["n_tus"], timed(fn, reps), size="%d sizes" % len(c0["sizes"]), frames=1, launches=launches,
                note="forward transform -> quantise -> dequantise + inverse + add of one 1080p frame's TUs")
-    del frames3
+    del frames3, srcs
+    torch.cuda.empty_cache()
+    # throughput: the TUs of F frames in one call (a run per size over all frames), cold planes rotating
+    F, c = 32, c0
+    plane = c["stride"] * c["h"]
+    off_parts, runs_q, runs_dq, first, coeff = [], [], [], 0, 0
+    for (log2, tr, f0, count, cf), rq, rd in zip(c["sizes"], c["runs_q"], c["runs_dq"]):
+        off_parts.append((c["off"][f0:f0 + count][None, :].astype(np.int64) + (np.arange(F, dtype=np.int64) * plane)[:, None]).reshape(-1))
+        runs_q.append((first, count * F, coeff, log2, tr, 0, rq["scale"], rq["shift"], rq["offset"]))
+        runs_dq.append((first, count * F, coeff, log2, tr, 0, rd["scale"], rd["shift"], 0))
+        first += count * F
+        coeff += (count * F) << (2 * log2)
+    off = B.off32(np.concatenate(off_parts).astype(np.uint32))
+    runs_q, runs_dq = np.array(runs_q, dtype=wl.TU_RUN_DTYPE), np.array(runs_dq, dtype=wl.TU_RUN_DTYPE)
+    n_tus, n_coeffs = c["n_tus"] * F, c["n_coeffs"] * F
+    sets = []
+    for k in range(3):
+        g = torch.Generator(device="cuda"); g.manual_seed(500 + k)
+        src = torch.randint(0, 256, (plane * F,), generator=g, device="cuda", dtype=torch.uint8)
+        pred = (src.to(torch.int16) + torch.randint(-12, 13, (plane * F,), generator=g, device="cuda", dtype=torch.int16)).clamp_(0, 255).to(torch.uint8)
+        sets.append(dict(src=src, pred=pred, dst=torch.zeros(plane * F, dtype=torch.uint8, device="cuda"), res=torch.zeros(plane * F, dtype=torch.int16, device="cuda"),
+                         coeffs=torch.zeros(n_coeffs, dtype=torch.int16, device="cuda"), levels=torch.zeros(n_coeffs, dtype=torch.int16, device="cuda"), cbf=torch.zeros(n_tus, dtype=torch.int32, device="cuda")))
+
+    def fused_many(i):
+        d = sets[i % 3]
+        B.transform_quantize_reconstruct_runs(d["dst"], c["stride"], d["src"], c["stride"], d["pred"], c["stride"], off, off, off, runs_q, runs_dq, n_coeffs, n_tus, levels=d["levels"], cbf=d["cbf"])
+
+    def stages_many(i):
+        d = sets[i % 3]
+        B.transform_runs(d["res"], c["stride"], off, runs_q, n_coeffs, out=d["coeffs"])
+        B.quantize_runs(d["coeffs"], runs_q, n_tus, out=d["levels"], cbf=d["cbf"])
+        B.inverse_transform_add_runs(d["dst"], c["stride"], d["pred"], c["stride"], off, off, d["levels"], runs_dq, dequant=True)
+
+    def residual_stages_many(i):
+        d = sets[i % 3]
+        torch.sub(d["src"].to(torch.int16), d["pred"].to(torch.int16), out=d["res"])
+        stages_many(i)
+
+    pxF = px * F
+    for name, fn, bytes_all, launches in (("transform_quantize_reconstruct, ONE launch (fused)", fused_many, 5 * pxF + 16 * n_tus, 1),
+                                          ("three stages, one launch each (residual plane given)", stages_many, 12 * pxF + 16 * n_tus, 3),
+                                          ("residual (torch) + three stages", residual_stages_many, 16 * pxF + 16 * n_tus, 6)):
+        for i in range(3):
+            fn(i)
+        torch.cuda.synchronize()
+        ms = timed(fn, 9)
+        report("%d frames' TUs: %s" % (F, name), n_tus, bytes_all // n_tus, ms, size="%d sizes" % len(c["sizes"]), frames=F, launches=launches, mpixels_per_s=round(pxF / ms / 1e3, 1),
+               note="1080p residual quad-trees of %d frames in one call, cold planes; bytes = what that form moves through HBM" % F)
+    del sets
     torch.cuda.empty_cache()
 
 
