@@ -5,6 +5,10 @@
  *
  *     hevcasm_hip_transform_runs  ->  hevcasm_hip_quantize_runs  ->  hevcasm_hip_dequant_inverse_transform_add_runs
  *
+ * and once more as ONE call that starts from the source and prediction planes and keeps everything between them in the workgroup:
+ *
+ *     hevcasm_hip_transform_quantize_reconstruct_runs
+ *
  * Each size has its own quantiser parameters (HEVC's shifts depend on the transform size); they travel in the runs.  Levels, coded-block flags and the
  * reconstructed plane must agree bit for bit.
  *
@@ -50,10 +54,10 @@ static int by_size(const void *a, const void *b)
 	return p->y != q->y ? p->y - q->y : p->x - q->x;
 }
 
-static int16_t residual[W * H], coeffs[W * H], levels_cpu[W * H], levels_gpu[W * H];
-static uint8_t pred[W * H], rec_cpu[W * H], rec_gpu[W * H];
+static int16_t residual[W * H], coeffs[W * H], levels_cpu[W * H], levels_gpu[W * H], levels_one[W * H];
+static uint8_t src[W * H], pred[W * H], rec_cpu[W * H], rec_gpu[W * H], rec_one[W * H];
 static uint32_t off[MAX_TUS];
-static int cbf_cpu[MAX_TUS], cbf_gpu[MAX_TUS];
+static int cbf_cpu[MAX_TUS], cbf_gpu[MAX_TUS], cbf_one[MAX_TUS];
 static hevcasm_hip_tu_run runs_q[8], runs_dq[8];
 
 int main(void)
@@ -62,7 +66,12 @@ int main(void)
 	static const int quant_scales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 }, level_scale[6] = { 40, 45, 51, 57, 64, 72 };
 	srand(11);
 	for (int i = 0; i < W * H; ++i) pred[i] = (uint8_t)(rand() >> 7);
-	for (int i = 0; i < W * H; ++i) residual[i] = (int16_t)((rand() >> 6) % 61 - 30 + ((i / W) & 32 ? 40 : 0));
+	for (int i = 0; i < W * H; ++i)
+	{
+		const int v = pred[i] + (rand() >> 6) % 61 - 30 + ((i / W) & 32 ? 40 : 0);      /* the source: the prediction plus a residual with some structure */
+		src[i] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+		residual[i] = (int16_t)(src[i] - pred[i]);                                     /* the codec's own step in front of hevcasm_transform */
+	}
 	for (int y = 0; y < H; y += 32)
 		for (int x = 0; x < W; x += 32) walk(x, y, 32);
 	qsort(tus, (size_t)n_tus, sizeof(tu_t), by_size);
@@ -105,19 +114,27 @@ int main(void)
 		fprintf(stderr, "no gfx950 device: %s\n", hevcasm_hip_last_error());
 		return 77;
 	}
-	int16_t *d_res, *d_coeffs, *d_levels; uint8_t *d_pred, *d_rec; uint32_t *d_off; int *d_cbf; void *stream;
+	int16_t *d_res, *d_coeffs, *d_levels; uint8_t *d_pred, *d_rec, *d_src; uint32_t *d_off; int *d_cbf; void *stream;
 	int rc = hevcasm_hip_stream_create(&stream);
 	rc |= hevcasm_hip_malloc((void **)&d_res, sizeof(residual)); rc |= hevcasm_hip_malloc((void **)&d_coeffs, sizeof(coeffs)); rc |= hevcasm_hip_malloc((void **)&d_levels, sizeof(coeffs));
-	rc |= hevcasm_hip_malloc((void **)&d_pred, sizeof(pred)); rc |= hevcasm_hip_malloc((void **)&d_rec, sizeof(pred));
+	rc |= hevcasm_hip_malloc((void **)&d_pred, sizeof(pred)); rc |= hevcasm_hip_malloc((void **)&d_rec, sizeof(pred)); rc |= hevcasm_hip_malloc((void **)&d_src, sizeof(src));
 	rc |= hevcasm_hip_malloc((void **)&d_off, 4 * (size_t)n_tus); rc |= hevcasm_hip_malloc((void **)&d_cbf, 4 * (size_t)n_tus);
 	rc |= hevcasm_hip_upload(d_res, residual, sizeof(residual), stream); rc |= hevcasm_hip_upload(d_pred, pred, sizeof(pred), stream);
-	rc |= hevcasm_hip_upload(d_off, off, 4 * (size_t)n_tus, stream);
+	rc |= hevcasm_hip_upload(d_off, off, 4 * (size_t)n_tus, stream); rc |= hevcasm_hip_upload(d_src, src, sizeof(src), stream);
 	if (!rc) rc = hevcasm_hip_transform_runs(d_coeffs, d_res, W, d_off, runs_q, n_runs, stream);
 	if (!rc) rc = hevcasm_hip_quantize_runs(d_levels, d_coeffs, d_cbf, runs_q, n_runs, stream);
 	if (!rc) rc = hevcasm_hip_dequant_inverse_transform_add_runs(d_rec, W, d_pred, W, d_off, d_off, d_levels, runs_dq, n_runs, stream);
 	if (!rc) rc = hevcasm_hip_download(levels_gpu, d_levels, sizeof(levels_gpu), stream);
 	if (!rc) rc = hevcasm_hip_download(cbf_gpu, d_cbf, 4 * (size_t)n_tus, stream);
 	if (!rc) rc = hevcasm_hip_download(rec_gpu, d_rec, sizeof(rec_gpu), stream);
+	/* 3. and as one call from the source plane (outputs cleared first, so that nothing of step 2 can pass for its result) */
+	if (!rc) rc = hevcasm_hip_upload(d_levels, coeffs, sizeof(coeffs), stream);            /* coeffs[] is still all zero on the host */
+	if (!rc) rc = hevcasm_hip_upload(d_rec, (const uint8_t *)coeffs, sizeof(rec_one), stream);
+	if (!rc) rc = hevcasm_hip_upload(d_cbf, coeffs, 4 * (size_t)n_tus, stream);
+	if (!rc) rc = hevcasm_hip_transform_quantize_reconstruct_runs(d_rec, W, d_src, W, d_pred, W, d_off, d_off, d_off, d_levels, d_cbf, runs_q, runs_dq, n_runs, stream);
+	if (!rc) rc = hevcasm_hip_download(levels_one, d_levels, sizeof(levels_one), stream);
+	if (!rc) rc = hevcasm_hip_download(cbf_one, d_cbf, 4 * (size_t)n_tus, stream);
+	if (!rc) rc = hevcasm_hip_download(rec_one, d_rec, sizeof(rec_one), stream);
 	if (!rc) rc = hevcasm_hip_stream_synchronize(stream);
 	if (rc)
 	{
@@ -128,12 +145,14 @@ int main(void)
 	for (int i = 0; i < n_tus; ++i)
 	{
 		bad_cbf += (cbf_cpu[i] != 0) != (cbf_gpu[i] != 0);      /* zero / non-zero is the flag's meaning (quantize.c:257) */
+		bad_cbf += (cbf_cpu[i] != 0) != (cbf_one[i] != 0);
 		coded += cbf_cpu[i] != 0;
 	}
-	const int bad_levels = memcmp(levels_cpu, levels_gpu, sizeof(levels_cpu)) != 0, bad_rec = memcmp(rec_cpu, rec_gpu, sizeof(rec_cpu)) != 0;
-	printf("%d TUs in %d runs (%d coded): levels %s, %d coded-block flags differ, reconstructed plane %s\n",
+	const int bad_levels = memcmp(levels_cpu, levels_gpu, sizeof(levels_cpu)) != 0 || memcmp(levels_cpu, levels_one, sizeof(levels_cpu)) != 0;
+	const int bad_rec = memcmp(rec_cpu, rec_gpu, sizeof(rec_cpu)) != 0 || memcmp(rec_cpu, rec_one, sizeof(rec_cpu)) != 0;
+	printf("%d TUs in %d runs (%d coded), three calls and one call: levels %s, %d coded-block flags differ, reconstructed plane %s\n",
 		n_tus, n_runs, coded, bad_levels ? "DIFFER" : "identical", bad_cbf, bad_rec ? "DIFFERS" : "identical");
-	hevcasm_hip_free(d_res); hevcasm_hip_free(d_coeffs); hevcasm_hip_free(d_levels); hevcasm_hip_free(d_pred); hevcasm_hip_free(d_rec); hevcasm_hip_free(d_off); hevcasm_hip_free(d_cbf);
+	hevcasm_hip_free(d_res); hevcasm_hip_free(d_coeffs); hevcasm_hip_free(d_levels); hevcasm_hip_free(d_pred); hevcasm_hip_free(d_rec); hevcasm_hip_free(d_off); hevcasm_hip_free(d_cbf); hevcasm_hip_free(d_src);
 	hevcasm_hip_stream_destroy(stream);
 	return (bad_levels | bad_cbf | bad_rec) != 0;
 }

@@ -77,14 +77,15 @@ def tu_grid(tus, stride, qp):
     return off, sizes, order
 
 
-def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1, tus=None, qp=27):
+def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshift=21, qoffset=171 << 7, dqscale=160, dqshift=1, tus=None, qp=27, fused=False):
     """The same chain on a REAL partition (round 6): the frame cut into prediction units of many sizes (`pus`, any of the 24 of
     pred_inter.c:438-444), transform units on a uniform tu x tu grid (HEVC's transform tree is independent of the PU boundaries inside a CU).
     Every stage is ONE launch for the whole frame: hevcasm_hip_me_full_search_runs, hevcasm_hip_subpel_refine_runs, hevcasm_hip_pred_uni_8to8_runs,
     hevcasm_hip_sad_runs (the PUs' prediction cost -- which must be the refinement's winning cost), the transform stages on the TU grid,
     hevcasm_hip_ssd_runs per PU.  With `tus` (a residual quad-tree over the four transform sizes, hevcasm_amd.workload.tu_partition) the transform stages run on
     THAT partition instead, one launch each as well (hevcasm_hip_transform_runs, _quantize_runs, _dequant_inverse_transform_add_runs), every size with the
-    (de)quantiser parameters HEVC gives it at `qp`; coefficients and levels are then in run order (tu_grid).
+    (de)quantiser parameters HEVC gives it at `qp`; coefficients and levels are then in run order (tu_grid).  `fused` (with `tus`): the residual loop as ONE launch
+    from the current and predicted planes (hevcasm_hip_transform_quantize_reconstruct_runs); residual and coefficients then never exist (None in the result).
     -> dict of every intermediate; per-PU arrays are in size order (`order` maps them back to `pus`)."""
     w, h, pad = frame["w"], frame["h"], frame["pad"]
     sc, sr = frame["stride_cur"], frame["stride_ref"]
@@ -96,8 +97,12 @@ def stages_partition(frame, ops, pus, tu=16, search_range=8, qscale=26214, qshif
     ref_sub, frac = ops.subpel_descriptors(ref_int, qmv, sr)
     pred = ops.pred_uni_runs(w * h, sc, ref, sr, cur_off, ref_sub, frac, sizes)                 # every PU size, one launch
     pu_sad = ops.cost_runs("sad", cur, sc, pred, sc, cur_off, cur_off, sizes)                   # one launch; == qmv[:, 2]
-    residual = ops.residual(cur, pred)
-    if tus is None:
+    residual = None if fused else ops.residual(cur, pred)
+    if fused:
+        tu_off, tu_sizes = ops.plan_tus(frame, tus, qp)
+        coeffs = None
+        recon, levels, cbf = ops.transform_quantize_reconstruct_runs(w * h, sc, cur, pred, tu_off, tu_sizes, len(tus))   # one launch for the whole residual loop
+    elif tus is None:
         coeffs = ops.transform(residual, sc, tu_off, 0, log2n)
         levels, cbf = ops.quantize(coeffs, qscale, qshift, qoffset, tu * tu)
         recon = ops.dequant_inverse_transform_add(w * h, sc, pred, sc, tu_off, tu_off, levels, dqscale, dqshift, 0, log2n)
@@ -186,6 +191,10 @@ class HipOps:
     def dequant_inverse_transform_add_runs(self, dst_bytes, sd, pred, sp, off, tu_sizes, levels):
         dst = self.t.zeros(dst_bytes, dtype=self.t.uint8, device=self.device)
         return self.B.inverse_transform_add_runs(dst, sd, pred, sp, off, off, levels, self._tu_runs_dq, dequant=True)
+
+    def transform_quantize_reconstruct_runs(self, n_bytes, stride, cur, pred, off, tu_sizes, n_tus):
+        rec = self.t.zeros(n_bytes, dtype=self.t.uint8, device=self.device)
+        return self.B.transform_quantize_reconstruct_runs(rec, stride, cur, stride, pred, stride, off, off, off, self._tu_runs_q, self._tu_runs_dq, n_bytes, n_tus)
 
     def me_full_search_runs(self, cur, sc, ref, sr, cur_off, ref_off, sizes, search_range):
         return self.B.me_full_search_runs(cur, sc, ref, sr, cur_off, ref_off, self._cost_runs, search_range)

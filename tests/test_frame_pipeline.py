@@ -93,6 +93,12 @@ class OracleOps:
         return dst
 
 
+    def transform_quantize_reconstruct_runs(self, n_bytes, stride, cur, pred, off, tu_sizes, n_tus):
+        res = self.residual(cur, pred)
+        levels, cbf = self.quantize_runs(self.transform_runs(res, stride, off, tu_sizes, n_bytes), tu_sizes, n_tus)
+        return self.dequant_inverse_transform_add_runs(n_bytes, stride, pred, stride, off, tu_sizes, levels), levels, cbf
+
+
 def _with_half_pel_motion(frame):
     """The generator moves blocks by whole pixels; here the lower half of the current frame becomes the mean of itself and its right-hand neighbour,
     i.e. content half a pixel away from anything in the reference, so that the refinement has fractional winners."""
@@ -205,6 +211,8 @@ def test_partition_chain_with_a_tu_quad_tree_on_the_oracle(oracle_lib):
         assert np.array_equal(r["cbf"][f:f + n] != 0, (r["levels"][cf:cf + (n << (2 * l2))].reshape(n, -1) != 0).any(axis=1))
     assert int(r["pu_ssd"].astype(np.int64).sum()) == int(r["frame_sse"][0]) and pipeline.psnr(int(r["frame_sse"][0]), 192, 128) > 32.0
     assert r["cbf"].any() and not r["cbf"].all()
+    f = pipeline.stages_partition(frame, OracleOps(), pus, search_range=8, tus=tus, qp=22, fused=True)
+    assert np.array_equal(f["recon"], r["recon"]) and np.array_equal(f["levels"], r["levels"]) and f["coeffs"] is None
 
 
 @pytest.mark.gpu
@@ -221,6 +229,11 @@ def test_partition_chain_with_a_tu_quad_tree_hip_equals_oracle(w, h, rng, qp):
     graph, results = ops.capture(frame, pus=pus, search_range=rng, tus=tus, qp=qp)          # and as one HIP graph
     graph.replay()
     _same_partition_stages(pipeline.HipOps.to_numpy(results), want)
+    # the residual loop as ONE launch from the current and predicted planes: the same levels, flags, reconstruction and costs
+    fused = pipeline.HipOps.to_numpy(pipeline.stages_partition(frame, ops, pus, search_range=rng, tus=tus, qp=qp, fused=True))
+    assert fused["residual"] is None and fused["coeffs"] is None
+    for key in ("levels", "cbf", "recon", "pu_ssd", "frame_sse"):
+        assert np.array_equal(np.asarray(fused[key]), np.asarray(got[key])), "fused residual loop: %s differs" % key
 
 
 @pytest.mark.gpu
