@@ -606,8 +606,9 @@ static int inverse_runs_entry(uint8_t *dst, ptrdiff_t sd, const uint8_t *pred, p
 // makes it cheap to write: in the forward bodies a lane ends holding ROW t of its block's coefficients -- exactly what the inverse bodies start from (4x4: a
 // lane holds the whole block in both) -- so the fused body is the forward body fed from source - prediction, the quantiser and dequantiser on that row in
 // registers (levels stored, the flag OR-ed over the block's lanes), and the inverse body from behind its loads.  The bodies are the .inc files above through
-// their hooks; 8x8 takes the tile form of the inverse (the lane form wants a lane per block, the forward tile has a lane per row); 32x32 the VALU form of the
-// forward transform (the matrix-core form leaves a lane with a column).  One 20 KiB LDS buffer serves forward and inverse tiles of every size in turn.
+// their hooks; 8x8 takes the tile form of the inverse (the lane form wants a lane per block, the forward tile has a lane per row); 32x32 keeps the forward
+// transform on the matrix cores and turns its column-per-lane result into rows through LDS (fused_mfma32_workgroup).  One 20 KiB LDS buffer serves forward
+// and inverse tiles of every size in turn.
 constexpr int kFusedLdsDwords = 8 * InverseTiles<32>::DWORDS;      // the largest tenant: eight 32x32 blocks' inverse tiles
 static_assert(kFusedLdsDwords * 4 >= (kThreads / 32) * Tile<32>::HALFWORDS * 2 && kFusedLdsDwords * 4 >= (kThreads / 16) * Tile<16>::HALFWORDS * 2 &&
 		kFusedLdsDwords >= (kThreads / 16) * InverseTiles<16>::DWORDS && kFusedLdsDwords >= (kThreads / 8) * InverseTiles<8>::DWORDS, "fused LDS buffer too small");
@@ -694,6 +695,81 @@ __device__ __forceinline__ void fused_tile_workgroup(uint32_t *lds,
 #undef HEVC_WG
 }
 
+// 32x32: the forward transform on the matrix cores (forward32_mfma_kernel's body).  A wave owns two blocks in both halves: it transforms them one after the
+// other, a lane holding 16 rows of ONE column of the result -- where the coefficients are quantised (the body's own paired store then writes the LEVELS), the
+// flag is OR-ed over the wave, and the dequantised values go to an LDS tile [row][column]; from there lane t of each half-wave takes ROW t, which is what the
+// inverse body starts from.  (The vector-unit form of the forward pass in this place made the fused launch 1.45x SLOWER than the three launches at 32x32.)
+__device__ __forceinline__ void fused_mfma32_workgroup(uint32_t *lds,
+	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ cur_off, const uint32_t *__restrict__ pred_off,
+	int16_t *__restrict__ levels, int *__restrict__ cbf, int qscale, int qshift, int qoffset, int dscale, int dshift, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+	constexpr int N = 32, SS = Tile<32>::S, TILE = Tile<32>::HALFWORDS;
+	const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+	const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
+	int16_t *stage = reinterpret_cast<int16_t *>(lds);
+#define HEVC_WG wg_in_batch
+	[&]()      // (the body leaves by `return` when its wave has no block: every wave must still reach the barrier below)
+	{
+		int16_t *coeffs = levels;                                              // what the body stores are levels
+		const ptrdiff_t src_stride = stride_cur;                               // (only the hooks read memory)
+		int any = 0;
+#define HEVC_FWD32_LOAD(blk, x) \
+		{ \
+			(void)lane_off; \
+			Chunk<16> c_, p_; \
+			c_.load(cur + cur_off[blk] + (ptrdiff_t)r * stride_cur + 16 * h); \
+			p_.load(pred + pred_off[blk] + (ptrdiff_t)r * stride_pred + 16 * h); \
+			_Pragma("unroll") \
+			for (int k_ = 0; k_ < 8; ++k_) \
+			{ \
+				const int e_ = 2 * k_, o_ = 2 * k_ + 1; \
+				const int lo_ = (int)((c_.d[e_ / 4] >> (8 * (e_ % 4))) & 0xff) - (int)((p_.d[e_ / 4] >> (8 * (e_ % 4))) & 0xff); \
+				const int hi_ = (int)((c_.d[o_ / 4] >> (8 * (o_ % 4))) & 0xff) - (int)((p_.d[o_ / 4] >> (8 * (o_ % 4))) & 0xff); \
+				x[k_] = ((uint32_t)lo_ & 0xffffu) | ((uint32_t)hi_ << 16); \
+			} \
+		}
+#define HEVC_FWD32_VALUES(blk, i, v0, v1) \
+		{ \
+			int16_t *tile_ = stage + ((threadIdx.x >> 6) * BPW + (blk - first)) * TILE + r; \
+			v0 = fused_quantize((int)(int16_t)v0, scale24, qround, qshift); \
+			v1 = fused_quantize((int)(int16_t)v1, scale24, qround, qshift); \
+			any |= v0 | v1; \
+			tile_[((i & 3) + 8 * (i >> 2) + 4 * h) * SS] = (int16_t)fused_dequantize(v0, dscale24, dround, dshift); \
+			tile_[(((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * h) * SS] = (int16_t)fused_dequantize(v1, dscale24, dround, dshift); \
+		}
+#define HEVC_FWD32_BLOCK_DONE(blk) \
+		{ \
+			_Pragma("unroll") \
+			for (int d_ = 32; d_ >= 1; d_ >>= 1) any |= __shfl_xor(any, d_, kWave); \
+			if (l == 0) cbf[blk] = any; \
+			any = 0; \
+		}
+#include "transform_forward32_mfma.inc"
+#undef HEVC_FWD32_LOAD
+#undef HEVC_FWD32_VALUES
+#undef HEVC_FWD32_BLOCK_DONE
+	}();
+	__syncthreads();      // the dequantised blocks are in the tiles
+	int row[N];
+	row_to_regs<N>(stage + (threadIdx.x / N) * TILE + (threadIdx.x % N) * SS, row);
+	__syncthreads();      // ... and in registers: the storage becomes the inverse tiles
+	{
+		constexpr bool DST = false, DEQUANT = false;
+		const int scale = 0, shift = 1;
+#define HEVC_INV_TILES_DECL uint32_t *tiles = lds
+#define HEVC_INV_ROW_IN(blk, t, v, raw) \
+		{ \
+			_Pragma("unroll") \
+			for (int k = 0; k < N; ++k) v[k] = row[k]; \
+		}
+#include "transform_inverse_tile.inc"
+#undef HEVC_INV_TILES_DECL
+#undef HEVC_INV_ROW_IN
+	}
+#undef HEVC_WG
+}
+
 template <bool DST>
 __device__ __forceinline__ void fused_lane4_workgroup(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *cur, ptrdiff_t stride_cur, const uint8_t *pred, ptrdiff_t stride_pred,
@@ -764,6 +840,9 @@ struct FusedRunsArgs
 	TuRunTable table;
 };
 
+// CLASSES: bit 0 = the sizes below 32x32 (76 registers), bit 1 = 32x32 (the matrix-core path: + 64 accumulation registers, three waves per SIMD instead of
+// six).  A launch small enough to be latency takes both in one kernel; a large one is two launches, so that the small sizes keep their occupancy.
+template <int CLASSES>
 __global__ __launch_bounds__(kThreads) void fused_tu_runs_kernel(const FusedRunsArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t lds[kFusedLdsDwords];
@@ -773,14 +852,20 @@ __global__ __launch_bounds__(kThreads) void fused_tu_runs_kernel(const FusedRuns
 	int16_t *lv = a.levels + r.coeff_first;
 	int *cbf = a.cbf + r.first;
 #define HEVC_FUSED_ARGS a.dst, a.stride_dst, a.cur, a.stride_cur, a.pred, a.stride_pred, dof, cof, pof, lv, cbf, r.scale, r.shift, r.offset, r.dscale, r.dshift, r.count, wg
-	switch (r.variant)
+	if constexpr (CLASSES & 1)
 	{
-	case 0: fused_lane4_workgroup<true>(HEVC_FUSED_ARGS); break;
-	case 1: fused_lane4_workgroup<false>(HEVC_FUSED_ARGS); break;
-	case 2: fused_tile_workgroup<8>(lds, HEVC_FUSED_ARGS); break;
-	case 3: fused_tile_workgroup<16>(lds, HEVC_FUSED_ARGS); break;
-	case 4: fused_tile_workgroup<32>(lds, HEVC_FUSED_ARGS); break;
-	default: break;
+		switch (r.variant)
+		{
+		case 0: fused_lane4_workgroup<true>(HEVC_FUSED_ARGS); break;
+		case 1: fused_lane4_workgroup<false>(HEVC_FUSED_ARGS); break;
+		case 2: fused_tile_workgroup<8>(lds, HEVC_FUSED_ARGS); break;
+		case 3: fused_tile_workgroup<16>(lds, HEVC_FUSED_ARGS); break;
+		default: break;
+		}
+	}
+	if constexpr (CLASSES & 2)
+	{
+		if (r.variant == 4) fused_mfma32_workgroup(lds, HEVC_FUSED_ARGS);
 	}
 #undef HEVC_FUSED_ARGS
 }
@@ -798,11 +883,36 @@ extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
 	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
 	if (n_runs == 0) return 0;
 	if (!runs_quantize || !runs_dequantize || !rec || !src || !pred || !rec_off || !src_off || !pred_off || !levels || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	std::vector<TuRunTable> tables;
-	std::vector<uint32_t> grids;
-	if (int e = build_tu_tables(runs_quantize, n_runs, [=](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+	// validated first; then split by class when the call is large (see fused_tu_runs_kernel)
+	std::vector<hevcasm_hip_tu_run> q[2], dq[2];
+	uint64_t wgs_all = 0;
+	for (int i = 0; i < n_runs; ++i)
+	{
+		const int big = runs_quantize[i].log2TrafoSize == 5;
+		q[big].push_back(runs_quantize[i]);
+		dq[big].push_back(runs_dequantize[i]);
+		if (runs_quantize[i].log2TrafoSize >= 2 && runs_quantize[i].log2TrafoSize <= 5)
+			wgs_all += ceil_div(runs_quantize[i].count, kFusedRunBlocksPerWg[runs_quantize[i].log2TrafoSize == 2 ? 0 : runs_quantize[i].log2TrafoSize - 1]);
+	}
+	const bool split = !q[0].empty() && !q[1].empty() && wgs_all > (uint64_t)device_cus() * 8;
+	if (!split)
+	{
+		q[0].insert(q[0].end(), q[1].begin(), q[1].end());
+		dq[0].insert(dq[0].end(), dq[1].begin(), dq[1].end());
+		q[1].clear(); dq[1].clear();
+	}
+	for (int part = -1; part < 2; ++part)      // part -1: every run is checked before anything is launched
+	{
+		if (part >= 0 && q[part].empty()) continue;
+		const hevcasm_hip_tu_run *rq = part < 0 ? runs_quantize : q[part].data(), *rdq = part < 0 ? runs_dequantize : dq[part].data();
+		const int n_part = part < 0 ? n_runs : (int)q[part].size();
+		bool any_small = false, any_big = false;
+		for (int i = 0; i < n_part; ++i) { if (rq[i].count == 0) continue; (rq[i].log2TrafoSize == 5 ? any_big : any_small) = true; }
+		std::vector<TuRunTable> tables;
+		std::vector<uint32_t> grids;
+		if (int e = build_tu_tables(rq, n_part, [=](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
 			if (int e = tu_variant(r, variant)) return e;
-			const hevcasm_hip_tu_run &d = runs_dequantize[&r - runs_quantize];
+			const hevcasm_hip_tu_run &d = rdq[&r - rq];
 			if (d.first != r.first || d.count != r.count || d.coeff_first != r.coeff_first || d.log2TrafoSize != r.log2TrafoSize || d.trType != r.trType || d.reserved)
 				return set_error(HEVCASM_HIP_EINVAL, "run: the dequantiser's run must describe the same units as the quantiser's");
 			// the domains of hevcasm_hip_quantize_batch (quantize.c:162-168) and of hevcasm_hip_dequant_inverse_transform_add_batch
@@ -810,12 +920,16 @@ extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
 				return set_error(HEVCASM_HIP_EINVAL, "run: quantiser scale/offset/shift outside the reference's domain (0 <= scale, offset < 0x8000; 16 <= shift <= 27)");
 			if (d.shift < 1 || d.shift > 31 || d.scale < -32768 || d.scale > 32767) return set_error(HEVCASM_HIP_EINVAL, "run: dequantiser shift out of range or scale beyond int16");
 			bpwg = kFusedRunBlocksPerWg[variant];
-			return 0; }, tables, grids, runs_dequantize)) return e;
-	for (size_t i = 0; i < tables.size(); ++i)
-	{
-		FusedRunsArgs a = { rec, src, pred, stride_rec, stride_src, stride_pred, rec_off, src_off, pred_off, levels, cbf, tables[i] };
-		hipLaunchKernelGGL(fused_tu_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
-		if (int e = launch_status("fused_tu_runs_kernel")) return e;
+			return 0; }, tables, grids, rdq)) return e;
+		if (part < 0) continue;
+		for (size_t i = 0; i < tables.size(); ++i)
+		{
+			FusedRunsArgs a = { rec, src, pred, stride_rec, stride_src, stride_pred, rec_off, src_off, pred_off, levels, cbf, tables[i] };
+			if (any_small && any_big) hipLaunchKernelGGL(fused_tu_runs_kernel<3>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			else if (any_big) hipLaunchKernelGGL(fused_tu_runs_kernel<2>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			else hipLaunchKernelGGL(fused_tu_runs_kernel<1>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			if (int e = launch_status("fused_tu_runs_kernel")) return e;
+		}
 	}
 	return 0;
 }

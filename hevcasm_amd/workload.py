@@ -451,13 +451,15 @@ def tu_partition(w, h, seed, split=(0.8, 0.6, 0.45), dst_share=0.3):
     return tus
 
 
-def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0, src_kind=None):
+def tu_frame_case(w, h, seed, qp=27, kind="video", residual="residual9", pad=0, src_kind=None, raster=False):
     """One plane's TUs (tu_partition) as RUNS for the four transform-stage entry points: an int16 residual plane and 8-bit prediction / destination planes (stride
     w + pad; offsets in elements of each), the TUs sorted by (size, type) with z-scan order inside a run, coefficients of the runs laid end to end (w x h in all),
     every run with the (de)quantiser parameters HEVC uses for its size at `qp` (intra_qp).  Keys: residual, pred, src, stride, off (uint32, shared by all planes),
     runs_q / runs_dq (TU_RUN_DTYPE with the quantiser's / the dequantiser's parameters), sizes [(log2, tr_type, first, count, coeff_first)], n_tus, n_coeffs."""
     tus = np.array(tu_partition(w, h, seed), dtype=np.int64)
     order = np.lexsort((np.arange(len(tus)), -tus[:, 3], tus[:, 2]))      # 4x4 DST, 4x4 DCT, 8x8, 16x16, 32x32
+    if raster:      # inside a run by rows of the plane instead of z-scan: neighbouring lanes then read neighbouring pieces of a row wherever the units are neighbours
+        order = np.lexsort((tus[:, 0], tus[:, 1], -tus[:, 3], tus[:, 2]))
     tus = tus[order]
     stride = w + pad
     off = (tus[:, 1] * stride + tus[:, 0]).astype(np.uint32)

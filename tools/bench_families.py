@@ -378,8 +378,13 @@ def bench_tu_latency(reps=30):
                note="forward transform -> quantise -> dequantise + inverse + add of one 1080p frame's TUs")
     del frames3, srcs
     torch.cuda.empty_cache()
-    # throughput: the TUs of F frames in one call (a run per size over all frames), cold planes rotating
-    F, c = 32, c0
+    # throughput: the TUs of F frames in one call (a run per size over all frames), cold planes rotating; units inside a run in z-scan order and in raster order
+    for order_name, craster in (("z-scan", c0), ("raster", wl.tu_frame_case(1920, 1080, 970, pad=64, raster=True))):
+        _tu_throughput(craster, order_name, px)
+
+
+def _tu_throughput(c, order_name, px):
+    F = 32
     plane = c["stride"] * c["h"]
     off_parts, runs_q, runs_dq, first, coeff = [], [], [], 0, 0
     for (log2, tr, f0, count, cf), rq, rd in zip(c["sizes"], c["runs_q"], c["runs_dq"]):
@@ -422,8 +427,53 @@ def bench_tu_latency(reps=30):
             fn(i)
         torch.cuda.synchronize()
         ms = timed(fn, 9)
-        report("%d frames' TUs: %s" % (F, name), n_tus, bytes_all // n_tus, ms, size="%d sizes" % len(c["sizes"]), frames=F, launches=launches, mpixels_per_s=round(pxF / ms / 1e3, 1),
+        report("%d frames' TUs (%s inside a run): %s" % (F, order_name, name), n_tus, bytes_all // n_tus, ms, size="%d sizes" % len(c["sizes"]), frames=F, launches=launches, mpixels_per_s=round(pxF / ms / 1e3, 1),
                note="1080p residual quad-trees of %d frames in one call, cold planes; bytes = what that form moves through HBM" % F)
+    del sets
+    torch.cuda.empty_cache()
+
+
+def bench_tu_fused_sizes(frames=32):
+    """The fused residual loop on planes cut into ONE TU size (1920x1088 x `frames` per call), next to the three stage launches on the same units: which size
+    costs what.  Gpixel/s and the fraction of the HBM peak at 5 (fused) / 12 (three stages, residual given) bytes per pixel."""
+    w, h, stride = 1920, 1088, 1920
+    plane = stride * h
+    q = wl.intra_qp(27)
+    g = torch.Generator(device="cuda"); g.manual_seed(77)
+    sets = []
+    for k in range(3):
+        src = torch.randint(0, 256, (plane * frames,), generator=g, device="cuda", dtype=torch.uint8)
+        pred = (src.to(torch.int16) + torch.randint(-12, 13, (plane * frames,), generator=g, device="cuda", dtype=torch.int16)).clamp_(0, 255).to(torch.uint8)
+        sets.append(dict(src=src, pred=pred, res=src.to(torch.int16) - pred.to(torch.int16), dst=torch.zeros_like(src), coeffs=torch.zeros(plane * frames, dtype=torch.int16, device="cuda"),
+                         levels=torch.zeros(plane * frames, dtype=torch.int16, device="cuda")))
+    for (log2, tr) in ((2, 1), (2, 0), (3, 0), (4, 0), (5, 0)):
+        n = 1 << log2
+        by, bx = np.meshgrid(np.arange(h // n), np.arange(w // n), indexing="ij")
+        one = (by * n * stride + bx * n).reshape(-1).astype(np.int64)
+        off = B.off32((one[None, :] + (np.arange(frames, dtype=np.int64) * plane)[:, None]).reshape(-1).astype(np.uint32))
+        n_tus = one.size * frames
+        qs, qsh, qo, ds, dsh = (int(v) for v in q[log2 - 2])
+        rq = np.array([(0, n_tus, 0, log2, tr, 0, qs, qsh, qo)], dtype=wl.TU_RUN_DTYPE)
+        rdq = np.array([(0, n_tus, 0, log2, tr, 0, ds, dsh, 0)], dtype=wl.TU_RUN_DTYPE)
+        cbf = torch.zeros(n_tus, dtype=torch.int32, device="cuda")
+
+        def fused(i):
+            d = sets[i % 3]
+            B.transform_quantize_reconstruct_runs(d["dst"], stride, d["src"], stride, d["pred"], stride, off, off, off, rq, rdq, plane * frames, n_tus, levels=d["levels"], cbf=cbf)
+
+        def stages(i):
+            d = sets[i % 3]
+            B.transform_runs(d["res"], stride, off, rq, plane * frames, out=d["coeffs"])
+            B.quantize_runs(d["coeffs"], rq, n_tus, out=d["levels"], cbf=cbf)
+            B.inverse_transform_add_runs(d["dst"], stride, d["pred"], stride, off, off, d["levels"], rdq, dequant=True)
+
+        px = w * h * frames
+        for name, fn, bpp in (("fused", fused, 5), ("three stages", stages, 12)):
+            for i in range(3):
+                fn(i)
+            torch.cuda.synchronize()
+            ms = timed(fn, 9)
+            report("TU %dx%d%s %s" % (n, n, " DST" if tr else "", name), n_tus, bpp * n * n + 16, ms, size="%dx%d" % (n, n), frames=frames, gpixels_per_s=round(px / ms / 1e6, 1))
     del sets
     torch.cuda.empty_cache()
 
@@ -727,4 +777,4 @@ if __name__ == "__main__":
         if w.startswith("pred") and w[4:].isdigit():      # pred256: the prediction rows at 256 frames per launch
             bench_pred(frames=int(w[4:]))
             continue
-        dict(pred=bench_pred, predlat=bench_pred_latency, costlat=bench_cost_latency, tulat=bench_tu_latency, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
+        dict(pred=bench_pred, predlat=bench_pred_latency, costlat=bench_cost_latency, tulat=bench_tu_latency, tufusedsizes=bench_tu_fused_sizes, intraframes=bench_intra_frames, meframe=bench_me_frame, transform=bench_transform, quant=bench_quant, me=bench_me, subpel=bench_subpel, satd=bench_satd, intra=bench_intra, intramodes=bench_intra_modes, ssdlin=bench_ssd_linear)[w]()
