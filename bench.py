@@ -244,6 +244,14 @@ FAMILY_KEYS = {   # (family, kernel + size as bench_families reports them) -> ke
     ("block_cost_latency", "sad frame partition, a launch per size 24 sizes"): "sad_frame_24_launches",
     ("block_cost_latency", "sad_multiref_4 frame partition, a launch per size 24 sizes"): "sad4_frame_24_launches",
     ("intra_frames", "intra_frames 1080p x 1"): "intra_frame", ("intra_frames", "intra_frames 1080p x 64"): "intra_frames64",
+    # round 6: the transform stages of a frame's TUs (4x4 DST ... 32x32, each size with its quantiser parameters): the residual loop as ONE launch, as three, as fifteen
+    ("tu_latency", "transform_quantize_reconstruct frame TUs, ONE launch (fused: residual, coefficients, levels stay in the workgroup) 5 sizes"): "tu_fused_frame",
+    ("tu_latency", "residual (torch) + three stages, one launch each 5 sizes"): "tu_residual_3stages_frame",
+    ("tu_latency", "transform+quantize+dequant_inverse three stages, one launch each 5 sizes"): "tu_3stages_frame",
+    ("tu_latency", "transform+quantize+dequant_inverse three stages, a launch per size and stage 5 sizes"): "tu_15_launches_frame",
+    ("tu_latency", "32 frames' TUs (z-scan inside a run): transform_quantize_reconstruct, ONE launch (fused) 5 sizes"): "tu_fused_32frames",
+    ("tu_latency", "32 frames' TUs (z-scan inside a run): three stages, one launch each (residual plane given) 5 sizes"): "tu_3stages_32frames",
+    ("tu_latency", "32 frames' TUs (z-scan inside a run): residual (torch) + three stages 5 sizes"): "tu_residual_3stages_32frames",
 }
 for _n in (8, 16, 32):
     for _fam, _sfx in (("", ""), ("_large_launch", "_2p28")):
@@ -378,7 +386,7 @@ def cpu_family_legs(budget_s, max_procs=16, sample_pus=8100):
 
 HEADLINE_FAMILIES = ("sad16", "pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8", "idct16", "idct32", "fused_idct32", "fdct32")
 # families whose headline is a TIME, not a fraction of the HBM peak: a frame's partition in one launch; one intra frame alone (dependency-limited) and 64 per call
-HEADLINE_MS = ("sad_frame_runs", "sad4_frame_runs", "pred_uni_frame_runs", "pred_bi_frame_runs", "intra_frame", "intra_frames64")
+HEADLINE_MS = ("sad_frame_runs", "sad4_frame_runs", "pred_uni_frame_runs", "pred_bi_frame_runs", "intra_frame", "intra_frames64", "tu_fused_frame", "tu_fused_32frames", "tu_residual_3stages_32frames")
 PATTERN_HEADLINES = ("pred_uni_luma16", "pred_bi_luma16", "pred_uni_chroma8", "pred_bi_chroma8")
 LINE_LIMIT = 4096
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_stale", "algorithmic_bytes_per_launch", "avg_launch_ms", "bytes_per_block",
@@ -888,6 +896,8 @@ def measure_families():
     collect("#2's kernels, one 1080p frame's partition", lambda r: "block_cost_latency")
     fam.bench_intra_frames()                                  # whole intra frames in wavefront order, one alone and 64 per call
     collect("8f-3, 1080p intra frames", lambda r: "intra_frames")
+    fam.bench_tu_latency()                                    # the residual loop of a frame's TUs (every transform size): fused, one launch per stage, a launch per size and stage
+    collect("#4's kernels, a 1080p frame's TUs", lambda r: "tu_latency")
     fam.bench_transform(only=((0, 3), (0, 4), (0, 5)))      # inverse (+ fused dequantisation) and forward 8x8 / 16x16 / 32x32
     collect("#4, 2^26 coefficients per launch", lambda r: "idct" if "inverse" in r["kernel"] else "fdct")
     fam.bench_transform(1 << 28, only=((0, 4), (0, 5)))       # the same kernels nearer their steady state: a 60 us launch pays 10-13 us of ramp-up and tail

@@ -83,6 +83,13 @@ def _canned_family_rows():
         rows.append(dict(family="block_cost_latency", kernel=k, ms=0.02, mblocks_per_s=870.0, gbs=210.0, frac=0.03, bytes_per_block=243, note="y" * 200))
     for k, ms in (("intra_frames 1080p x 1", 9.4), ("intra_frames 1080p x 64", 10.7)):      # round 6: whole intra frames in wavefront order
         rows.append(dict(family="intra_frames", kernel=k, ms=ms, mblocks_per_s=2.9, gbs=0.9, frac=0.0001, bytes_per_block=320, frames=1, note="n" * 200))
+    for k in ("transform_quantize_reconstruct frame TUs, ONE launch (fused: residual, coefficients, levels stay in the workgroup) 5 sizes",      # round 6: a frame's TUs
+              "residual (torch) + three stages, one launch each 5 sizes", "transform+quantize+dequant_inverse three stages, one launch each 5 sizes",
+              "transform+quantize+dequant_inverse three stages, a launch per size and stage 5 sizes", "transform frame TUs, one launch 5 sizes",
+              "32 frames' TUs (z-scan inside a run): transform_quantize_reconstruct, ONE launch (fused) 5 sizes",
+              "32 frames' TUs (z-scan inside a run): three stages, one launch each (residual plane given) 5 sizes",
+              "32 frames' TUs (z-scan inside a run): residual (torch) + three stages 5 sizes", "32 frames' TUs (raster inside a run): residual (torch) + three stages 5 sizes"):
+        rows.append(dict(family="tu_latency", kernel=k, ms=0.018, mblocks_per_s=2200.0, gbs=600.0, frac=0.08, bytes_per_block=276, frames=1, launches=1, note="t" * 200))
     for fam, sfx in (("", ""), ("_large_launch", "")):
         for n in (8, 16, 32):
             rows.append(dict(family="idct" + fam, kernel="inverse_transform_add dct%d" % n, ms=0.06, mblocks_per_s=1000.0, gbs=4500.0, frac=0.57, bytes_per_block=4 * n * n + 8))
@@ -105,7 +112,8 @@ def test_the_record_keeps_every_family_as_scalars():
             "pred_bi_chroma8_256f", "pred_uni_luma16_256f", "idct8", "idct16", "idct32", "fused_idct8", "fused_idct16", "fused_idct32", "fdct8", "fdct16", "fdct32",
             "idct16_2p28", "idct32_2p28", "fused_idct32_2p28", "fdct32_2p28", "pred_uni_luma16_1frame", "pred_uni_frame_graph", "pred_bi_frame_graph",
             "pred_uni_frame_runs", "pred_bi_frame_runs", "pred_uni_frame_72_launches", "intra_frame", "intra_frames64", "sad_frame_runs", "sad4_frame_runs",
-            "sad_frame_24_launches"]
+            "sad_frame_24_launches", "tu_fused_frame", "tu_3stages_frame", "tu_15_launches_frame", "tu_residual_3stages_frame", "tu_fused_32frames", "tu_3stages_32frames",
+            "tu_residual_3stages_32frames"]
     for k in want:
         for sfx in ("_frac", "_gbs", "_ms", "_mblocks"):
             assert isinstance(kept[k + sfx], float), k + sfx

@@ -267,3 +267,28 @@ def test_cost_runs_random_partitions():
         c = wl.cost_frame_case(w, h, 9700 + i, kind=["noise", "video", "max"][int(rng.integers(0, 3))], search=int(rng.integers(0, 40)))
         for kind in test_cost_runs.KINDS:
             assert np.array_equal(test_cost_runs._hip(c, kind), test_cost_runs._oracle(pyoracle, c, kind)), "fuzz cost runs %dx%d %s" % (w, h, kind)
+
+
+def test_tu_runs_random_partitions_and_parameters():
+    """Round 6: a plane's transform units in one launch per stage and the whole residual loop in ONE launch -- random plane sizes (multiples of 4), QP, content,
+    row padding, unit order, against the oracle per run; the fused launch also against the three stage launches' results (the same numbers by another route)."""
+    import test_tu_runs
+    from oracle import pyoracle
+    rng = np.random.default_rng(20261013 + SEED)
+    kinds = ["noise", "video", "max", "zeros"]
+    for i in range(8 * NMUL):
+        w, h = 4 * int(rng.integers(1, 80)), 4 * int(rng.integers(1, 60))
+        c = wl.tu_frame_case(w, h, 9900 + i + SEED, qp=int(rng.integers(0, 52)), kind=kinds[int(rng.integers(0, 4))], src_kind=kinds[int(rng.integers(0, 4))],
+                             residual=["residual9", "full", "natural"][int(rng.integers(0, 3))], pad=4 * int(rng.integers(0, 5)), raster=bool(rng.integers(0, 2)))
+        (coeffs,), (want,) = test_tu_runs._hip(c, "forward"), test_tu_runs._oracle(pyoracle, c, "forward")
+        assert np.array_equal(coeffs, want), "fuzz tu runs %dx%d forward" % (w, h)
+        for g, x in zip(test_tu_runs._hip(c, "quantize", coeffs), test_tu_runs._oracle(pyoracle, c, "quantize", coeffs)):
+            assert np.array_equal(g, x), "fuzz tu runs %dx%d quantize" % (w, h)
+        full = wl.fill_i16(c["n_coeffs"], 77 + i, "full")
+        for stage in ("inverse", "dequant_inverse"):
+            assert np.array_equal(test_tu_runs._hip(c, stage, full)[0], test_tu_runs._oracle(pyoracle, c, stage, full)[0]), "fuzz tu runs %dx%d %s" % (w, h, stage)
+        m = test_tu_runs._mask(c)
+        for in_place in (False, True):
+            for g, x, what in zip(test_tu_runs._fused_hip(c, in_place=in_place), test_tu_runs._fused_oracle(pyoracle, c), ("levels", "cbf", "reconstruction")):
+                ok = np.array_equal(g[m], x[m]) if what == "reconstruction" else np.array_equal(g, x)
+                assert ok, "fuzz tu runs %dx%d fused %s in_place=%s" % (w, h, what, in_place)
