@@ -44,3 +44,16 @@ r = pipeline.HipOps.to_numpy(results)
 sizes = sorted({(p[2], p[3]) for p in pus})
 print("mixed partition: %d PUs of %d sizes, %dx%d transform units: PSNR %.2f dB; prediction cost == refinement cost on %d of %d PUs; %.3f ms per frame as one HIP graph"
       % (len(pus), len(sizes), size, size, pipeline.psnr(int(r["frame_sse"][0]), w, h), int((r["pu_sad"] == r["qmv"][:, 2]).sum()), len(pus), e0.elapsed_time(e1) / 20))
+
+# ... and with the residual on a quad-tree of transform units as well (4x4 DST ... 32x32, each size with the quantiser parameters HEVC gives it at this QP): first a
+# launch per transform stage (hevcasm_hip_*_runs), then the whole residual loop as ONE launch from the current and predicted planes
+tus = workload.tu_partition(w, h, 3)
+for fused in (False, True):
+    graph, results = ops.capture(frame, pus=pus, search_range=rng, tus=tus, qp=27, fused=fused)
+    e0.record()
+    for _ in range(20):
+        graph.replay()
+    e1.record()
+    r = pipeline.HipOps.to_numpy(results)
+    print("mixed partition, %d TUs of 5 kinds, %s: PSNR %.2f dB, %d TUs coded; %.3f ms per frame as one HIP graph"
+          % (len(tus), "the residual loop in ONE launch" if fused else "a launch per transform stage", pipeline.psnr(int(r["frame_sse"][0]), w, h), int((r["cbf"] != 0).sum()), e0.elapsed_time(e1) / 20))
