@@ -171,6 +171,31 @@ def test_hip_fused_residual_loop_equals_the_oracles_four_functions(w, h, qp, kin
 
 
 @pytest.mark.gpu
+def test_hip_fused_large_call_two_launches_and_many_runs(oracle_lib):
+    """A call large enough to be split by register class (sizes below 32x32 in one launch, 32x32 on the matrix cores in another: > 8 workgroups per CU), and a call
+    of more runs than one table holds with empty runs in between: the same levels, flags and reconstruction as the oracle."""
+    c = wl.tu_frame_case(3840, 2176, 17, qp=30, pad=0)
+    wgs = sum(-(-n // {2: 256, 3: 32, 4: 16, 5: 8}[log2]) for (log2, _, _, n, _) in c["sizes"])
+    assert wgs > 256 * 8 and {s[0] for s in c["sizes"]} == {2, 3, 4, 5}
+    want = _fused_oracle(oracle_lib, c)
+    for g, w, what in zip(_fused_hip(c), want, ("levels", "cbf", "reconstruction")):
+        assert np.array_equal(g, w), "split call: %s (%d differ)" % (what, int((g != w).sum()))
+    c = wl.tu_frame_case(256, 192, 77, qp=18)
+    def pieces(runs):
+        out = []
+        for r in runs:
+            n2 = 1 << (2 * int(r["log2"]))
+            for s in range(0, int(r["count"]), 3):
+                out.append((int(r["first"]) + s, min(3, int(r["count"]) - s), int(r["coeff_first"]) + s * n2, r["log2"], r["tr_type"], 0, r["scale"], r["shift"], r["offset"]))
+                out.append((7, 0, 64, r["log2"], r["tr_type"], 0, r["scale"], r["shift"], r["offset"]))
+        return np.array(out, dtype=wl.TU_RUN_DTYPE)
+    pq, pdq = pieces(c["runs_q"]), pieces(c["runs_dq"])
+    assert int((pq["count"] > 0).sum()) > 64
+    for g, w, what in zip(_fused_hip(c, runs_q=pq, runs_dq=pdq), _fused_oracle(oracle_lib, c), ("levels", "cbf", "reconstruction")):
+        assert np.array_equal(g, w), "many runs: " + what
+
+
+@pytest.mark.gpu
 def test_hip_fused_residual_loop_equals_the_three_launches_and_refuses_bad_runs():
     import torch
     from hevcasm_amd import batch as B
