@@ -562,11 +562,28 @@ def intra_frame_mixed_cases(seed=1800):
     return out
 
 
+def tu_chain_cases(seed=1900):
+    """PINNED: an encoder's residual loop over a plane's transform units of every size -- source - prediction -> hevcasm_transform -> hevcasm_quantize ->
+    hevcasm_quantize_inverse -> hevcasm_inverse_transform_add (residual_decode.h:82, quantize.h:78, :57, residual_decode.h:54), each TU size with the parameters
+    HEVC gives it at the case's QP.  Every step is one of the reference's own C functions, so refdrv composes them as the oracle does; the product runs the whole
+    loop in ONE launch (hevcasm_hip_transform_quantize_reconstruct_runs).  Ragged planes, row padding, flat / extreme / noise content, QP 0 ... 51."""
+    out = []
+    for (name, w, h, qp, kind, src_kind, pad) in (("tuchain_video_200x136_qp27", 200, 136, 27, "video", None, 0), ("tuchain_noise_96x160_qp12", 96, 160, 12, "noise", None, 8),
+                                                   ("tuchain_white_on_black_64x64_qp0", 64, 64, 0, "zeros", "max", 0), ("tuchain_black_on_white_132x76_qp51", 132, 76, 51, "max", "zeros", 4),
+                                                   ("tuchain_noise_on_video_160x96_qp33", 160, 96, 33, "video", "noise", 0), ("tuchain_video_4x4_qp20", 4, 4, 20, "video", None, 0),
+                                                   ("tuchain_video_256x192_qp4", 256, 192, 4, "video", None, 0)):
+        c = wl.tu_frame_case(w, h, seed + w + h, qp=qp, kind=kind, src_kind=src_kind, pad=pad)
+        out.append((name, "tu_chain", dict(w=w, h=h, stride=c["stride"], src=c["src"], pred=c["pred"], off=c["off"], sizes=np.array(c["sizes"], dtype=np.int64).reshape(-1, 5),
+                                           runs_q=c["runs_q"], runs_dq=c["runs_dq"])))
+    return out
+
+
 UNPINNED_CASE_LISTS = dict(intra_modes=intra_modes_cases, intra_filter=intra_filter_cases, intra_frame_mixed=intra_frame_mixed_cases)
 
 ALL_CASE_LISTS = dict(sad=sad_cases, ssd=ssd_cases, satd=satd_cases, pred_uni=pred_uni_cases, pred_bi=pred_bi_cases, inverse=inverse_cases,
                       dequant_inverse=dequant_inverse_cases, forward=forward_cases, quant=quant_cases, me=me_cases, subpel=subpel_cases,
-                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases, intra_frame=intra_frame_cases)
+                      intra=intra_cases, ssd_linear=ssd_linear_cases, frame_sse=frame_sse_cases, narrowing=narrowing_cases, intra_frame=intra_frame_cases,
+                      tu_chain=tu_chain_cases)
 
 
 # ------------------------------------------------------------------------------------- runners
@@ -624,6 +641,17 @@ def _run_cpu(api, family, c):
         rec, lev, cbf = api.intra_reconstruct_frame(c["src"] if enc else None, c["stride"], None if enc else c["levels"], c["tus"], c["qp"], c["w"], c["h"], c["stride"],
                                                     c["ctu"], c["cidx"], c["strong"])
         return _intra_frame_outputs(rec, lev, cbf, c, enc)
+    if family == "tu_chain":
+        # the codec's loop, run by run: its own subtraction, then four functions of the library per TU (batched per size here)
+        residual = c["src"].astype(np.int16) - c["pred"].astype(np.int16)
+        n_tus, n_bytes = len(c["off"]), c["stride"] * c["h"]
+        levels, cbf, rec = np.zeros(c["w"] * c["h"], dtype=np.int16), np.zeros(n_tus, dtype=np.int32), np.zeros(n_bytes, dtype=np.uint8)
+        for (log2, tr, first, count, cf), rq, rd in zip(c["sizes"], c["runs_q"], c["runs_dq"]):
+            o, e = c["off"][first:first + count], cf + (count << (2 * log2))
+            coeffs = api.transform_batch(int(tr), int(log2), residual, c["stride"], o)
+            levels[cf:e], cbf[first:first + count] = api.quantize_batch(coeffs, int(rq["scale"]), int(rq["shift"]), int(rq["offset"]), 1 << (2 * int(log2)))
+            rec |= api.dequant_inverse_transform_add_batch(int(tr), int(log2), n_bytes, c["stride"], c["pred"], c["stride"], o, o, levels[cf:e], int(rd["scale"]), int(rd["shift"]))
+        return (levels, (cbf != 0).astype(np.int32), rec.reshape(c["h"], c["stride"])[:, :c["w"]].copy())      # the flag's meaning is zero / non-zero (quantize.c:257)
     if family == "intra_filter":
         return (_filter_samples(api.intra_filter_neighbours_batch(c["neighbours"], c["neighbour_stride"], c["log2"], c["strong"], c["n"], out_stride=136), 136, c["log2"], c["n"]),)
     raise ValueError(family)
@@ -696,6 +724,13 @@ def run_hip(family, c):
         return (cpu(B.ssd_linear(u8(c["src0"]), u8(c["src1"]), off(c["off0"]), off(c["off1"]), c["size"])),)
     if family == "frame_sse":
         return (cpu(B.frame_sse(u8(c["a"]), c["stride_a"], u8(c["b"]), c["stride_b"], off(c["a_off"]), off(c["b_off"]), c["width"], c["height"])),)
+    if family == "tu_chain":
+        o, n_bytes = off(c["off"]), c["stride"] * c["h"]
+        rec, levels, cbf = B.transform_quantize_reconstruct_runs(plane(n_bytes), c["stride"], u8(c["src"]), c["stride"], u8(c["pred"]), c["stride"], o, o, o, c["runs_q"], c["runs_dq"],
+                                                                 c["w"] * c["h"], len(c["off"]))
+        rec = cpu(rec).reshape(c["h"], c["stride"])
+        assert not rec[:, c["w"]:].any(), "the fused residual loop wrote outside its TUs"
+        return (cpu(levels), (cpu(cbf) != 0).astype(np.int32), rec[:, :c["w"]].copy())
     if family == "intra_modes":
         size = 1 << ((c["packed"] >> 1) & 0x7f)
         return (cpu(B.pred_intra_modes(plane(c["modes"].size * size * size), u8(c["neighbours"]), c["neighbour_stride"], u8(c["modes"]), c["packed"])),)
