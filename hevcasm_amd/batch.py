@@ -210,6 +210,14 @@ def inverse_transform_add_runs(dst, stride_dst, pred, stride_pred, dst_off, pred
     return dst
 
 
+def quantize_reconstruct_runs(rec, stride_rec, pred, stride_pred, rec_off, pred_off, res, runs):
+    """hevcasm_hip_quantize_reconstruct_runs: rec = clip(pred + res) for units of every size in ONE launch."""
+    runs = _tu_runs(runs)
+    check(lib().hevcasm_hip_quantize_reconstruct_runs(rec.data_ptr(), stride_rec, pred.data_ptr(), stride_pred, rec_off.data_ptr(), pred_off.data_ptr(), res.data_ptr(),
+                                                      runs.ctypes.data, len(runs), _stream()), "quantize_reconstruct_runs")
+    return rec
+
+
 def transform_quantize_reconstruct_runs(rec, stride_rec, src, stride_src, pred, stride_pred, rec_off, src_off, pred_off, runs_q, runs_dq, n_coeffs, n_tus, levels=None, cbf=None):
     """hevcasm_hip_transform_quantize_reconstruct_runs: src - pred -> transform -> quantise -> dequantise -> inverse + add for a frame's TUs in ONE launch
     -> (rec, levels, cbf)."""

@@ -71,41 +71,9 @@ __global__ __launch_bounds__(kThreads) void reconstruct_kernel(
 	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ res, uint32_t n_blocks)
 {
-	constexpr int PX = N < 8 ? N : 8;
-	constexpr int LPR = N / PX;              // lanes per row
-	constexpr int LPB = LPR * N;             // lanes per block
-	constexpr int BPWG = kThreads / LPB;     // blocks per workgroup
-	// Lane order inside a workgroup: x-part fastest, then block, then row -- so consecutive lanes
-	// walk along ONE frame row across neighbouring blocks (contiguous for raster-ordered blocks).
-	const uint32_t tid = threadIdx.x;
-	const uint32_t xpart = tid % LPR, b = (tid / LPR) % BPWG, y = tid / (LPR * BPWG);
-	const uint32_t wg = xcd_contiguous(blockIdx.x, gridDim.x);
-	const size_t blk = (size_t)wg * BPWG + b;
-	if (blk >= n_blocks) return;
-	const uint32_t x = xpart * PX;
-	// (round 4: the workgroup's offsets by scalar loads, as in sad.hip: -3 ... +3 %, nothing: profiles/r04_scalar_offsets_elsewhere_ab.txt)
-	const uint32_t po = pred_off[blk], ro = rec_off[blk];
-
-	Chunk<PX> p;
-	Chunk<2 * PX> r;
-	p.load(pred + po + y * stride_pred + x);
-	// The residual of a 16x16 / 32x32 block is read once and a row is a whole number of 32-byte sectors per lane group:
-	// streaming loads leave the L1 to the prediction rows (16x16 0.066 -> 0.058 ms, 32x32 0.066 -> 0.057 per 2^26
-	// pixels; 8x8, whose 16-byte rows share lines across instructions, loses 7 % with them and keeps ordinary loads).
-	if (N >= 16) r.load_stream(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
-	else r.load(reinterpret_cast<const uint8_t *>(res + blk * (N * N) + y * N + x));
-	Chunk<PX> o;
-#pragma unroll
-	for (int k = 0; k < PX / 4; ++k)
-	{
-		const uint32_t pd = p.d[k];
-		const int v0 = clip3(0, 255, (int)(pd & 0xff) + sext_lo(r.d[2 * k]));
-		const int v1 = clip3(0, 255, (int)((pd >> 8) & 0xff) + sext_hi(r.d[2 * k]));
-		const int v2 = clip3(0, 255, (int)((pd >> 16) & 0xff) + sext_lo(r.d[2 * k + 1]));
-		const int v3 = clip3(0, 255, (int)(pd >> 24) + sext_hi(r.d[2 * k + 1]));
-		o.d[k] = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
-	}
-	o.store(rec + ro + y * stride_rec + x);
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "quant_reconstruct.inc"
+#undef HEVC_WG
 }
 
 // 4x4 blocks: one lane per block (32 bytes of residual in two 16-byte loads, four row dwords in and
@@ -115,27 +83,9 @@ __global__ __launch_bounds__(kThreads) void reconstruct4_lane_kernel(
 	const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ res, uint32_t n_blocks)
 {
-	const uint32_t blk = xcd_contiguous(blockIdx.x, gridDim.x) * kThreads + threadIdx.x;
-	if (blk >= n_blocks) return;
-	Chunk<16> r0, r1;
-	const uint8_t *rp = reinterpret_cast<const uint8_t *>(res + (size_t)blk * 16);
-	r0.load(rp);
-	r1.load(rp + 16);
-	const uint32_t r[8] = { r0.d[0], r0.d[1], r0.d[2], r0.d[3], r1.d[0], r1.d[1], r1.d[2], r1.d[3] };
-	const uint8_t *pp = pred + pred_off[blk];
-	uint8_t *out = rec + rec_off[blk];
-	uint32_t pd[4];
-#pragma unroll
-	for (int y = 0; y < 4; ++y) pd[y] = reinterpret_cast<const U1 *>(pp + y * stride_pred)->v;
-#pragma unroll
-	for (int y = 0; y < 4; ++y)
-	{
-		const int v0 = (int)(pd[y] & 0xff) + sext_lo(r[2 * y]), v1 = (int)((pd[y] >> 8) & 0xff) + sext_hi(r[2 * y]);
-		const int v2 = (int)((pd[y] >> 16) & 0xff) + sext_lo(r[2 * y + 1]), v3 = (int)(pd[y] >> 24) + sext_hi(r[2 * y + 1]);
-		const uint32_t lo = __builtin_amdgcn_ashr_pk_u8_i32(v0, v1, 0);   // saturates to [0, 255]: the clip of quantize.c:299
-		const uint32_t hi = __builtin_amdgcn_ashr_pk_u8_i32(v2, v3, 0);
-		reinterpret_cast<U1 *>(out + y * stride_rec)->v = __builtin_amdgcn_perm(hi, lo, 0x05040100);
-	}
+#define HEVC_WG xcd_contiguous(blockIdx.x, gridDim.x)
+#include "quant_reconstruct4_lane.inc"
+#undef HEVC_WG
 }
 
 // ---- one launch for the quantiser of a frame's transform units (round 6; tu_runs.hpp): the body above per run, with the run's parameters ----------------
@@ -176,9 +126,80 @@ __global__ __launch_bounds__(kThreads) void quantize_runs_kernel(const QuantizeR
 	}
 }
 
+// ---- hevcasm_quantize_reconstruct for a frame's units of every size in one launch (round 6): the bodies above per run -----------------------------------
+template <int N>
+__device__ __forceinline__ void reconstruct_workgroup(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ res, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "quant_reconstruct.inc"
+#undef HEVC_WG
+}
+__device__ __forceinline__ void reconstruct4_lane_workgroup(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ pred_off,
+	const int16_t *__restrict__ res, uint32_t n_blocks, const uint32_t wg_in_batch)
+{
+#define HEVC_WG wg_in_batch
+#include "quant_reconstruct4_lane.inc"
+#undef HEVC_WG
+}
+
+// blocks per workgroup by variant (= log2 size - 2): a lane per 4x4 block; above, a lane per 8 pixels of a row
+constexpr uint32_t kReconstructRunBlocksPerWg[4] = { kThreads, kThreads / 8, kThreads / 32, kThreads / 128 };
+
+struct ReconstructRunsArgs
+{
+	uint8_t *rec;
+	const uint8_t *pred;
+	ptrdiff_t stride_rec, stride_pred;
+	const uint32_t *rec_off, *pred_off;
+	const int16_t *res;
+	TuRunTable table;
+};
+
+__global__ __launch_bounds__(kThreads) void reconstruct_runs_kernel(const ReconstructRunsArgs a)
+{
+	uint32_t wg;
+	const TuRunDev r = find_tu_run(a.table, wg);
+	const uint32_t *ro = a.rec_off + r.first, *po = a.pred_off + r.first;
+	const int16_t *res = a.res + r.coeff_first;
+	switch (r.variant)
+	{
+	case 0: reconstruct4_lane_workgroup(a.rec, a.stride_rec, a.pred, a.stride_pred, ro, po, res, r.count, wg); break;
+	case 1: reconstruct_workgroup<8>(a.rec, a.stride_rec, a.pred, a.stride_pred, ro, po, res, r.count, wg); break;
+	case 2: reconstruct_workgroup<16>(a.rec, a.stride_rec, a.pred, a.stride_pred, ro, po, res, r.count, wg); break;
+	case 3: reconstruct_workgroup<32>(a.rec, a.stride_rec, a.pred, a.stride_pred, ro, po, res, r.count, wg); break;
+	default: break;
+	}
+}
+
 }  // namespace hevc
 
 using namespace hevc;
+
+extern "C" int hevcasm_hip_quantize_reconstruct_runs(uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+		const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res, const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
+{
+	if (int e = check_device()) return e;
+	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_runs == 0) return 0;
+	if (!runs || !rec || !pred || !rec_off || !pred_off || !res) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	std::vector<TuRunTable> tables;
+	std::vector<uint32_t> grids;
+	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.reserved) return set_error(HEVCASM_HIP_EINVAL, "run: nCbS must be 4, 8, 16 or 32 (log2TrafoSize 2..5), reserved 0");
+			variant = (uint32_t)r.log2TrafoSize - 2u;
+			bpwg = kReconstructRunBlocksPerWg[variant];
+			return 0; }, tables, grids)) return e;
+	for (size_t i = 0; i < tables.size(); ++i)
+	{
+		ReconstructRunsArgs a = { rec, pred, stride_rec, stride_pred, rec_off, pred_off, res, tables[i] };
+		hipLaunchKernelGGL(reconstruct_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+		if (int e = launch_status("reconstruct_runs_kernel")) return e;
+	}
+	return 0;
+}
 
 extern "C" int hevcasm_hip_quantize_runs(int16_t *dst, const int16_t *src, int *cbf, const hevcasm_hip_tu_run *runs, int n_runs, void *stream)
 {

@@ -466,12 +466,18 @@ static int launch_forward(int16_t *coeffs, const int16_t *src, ptrdiff_t ss, con
 // The workgroup bodies above once more, as functions of (batch, workgroup index inside the batch); the one-size kernels keep their own copies of the same text
 // (an inlined function is optimised before it meets its kernel's launch bounds and came out scheduled differently: the measured kernels stay as they were).
 template <int N, bool DST, bool DEQUANT>
-__device__ __forceinline__ void inverse_tile_workgroup(
+__device__ __forceinline__ void inverse_tile_workgroup(uint32_t *lds,
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred, const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ pred_off,
 	const int16_t *__restrict__ coeffs, int scale, int shift, uint32_t n_blocks, const uint32_t wg_in_batch)
 {
 #define HEVC_WG wg_in_batch
+#define HEVC_INV_TILES_DECL uint32_t *tiles = lds      // one buffer for the runs kernel's sizes in turn, not a static array per size
+#define HEVC_INV_ROW_IN(blk, t, v, raw) \
+	if (DEQ_OPSEL) global_row_load_raw<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, raw); \
+	else global_row_load<N, N == 16>(coeffs + (size_t)blk * (N * N) + t * N, v)
 #include "transform_inverse_tile.inc"
+#undef HEVC_INV_TILES_DECL
+#undef HEVC_INV_ROW_IN
 #undef HEVC_WG
 }
 template <int N, bool DST, bool DEQUANT>
@@ -484,11 +490,17 @@ __device__ __forceinline__ void inverse_lane_workgroup(
 #undef HEVC_WG
 }
 template <int N, bool DST>
-__device__ __forceinline__ void forward_tile_workgroup(
+__device__ __forceinline__ void forward_tile_workgroup(uint32_t *lds,
 	int16_t *__restrict__ coeffs, const int16_t *__restrict__ src, ptrdiff_t src_stride, const uint32_t *__restrict__ src_off, uint32_t n_blocks, const uint32_t wg_in_batch)
 {
 #define HEVC_WG wg_in_batch
+#define HEVC_FWD_TILES_DECL int16_t *tiles = reinterpret_cast<int16_t *>(lds)
+#define HEVC_FWD_ROW_IN(off1, t1, v) global_row_load<N>(src + off1 + (ptrdiff_t)t1 * src_stride, v)
+#define HEVC_FWD_ROW_OUT(blk, t, v, live) if (live) global_row_store<N, true>(coeffs + (size_t)blk * (N * N) + t * N, v)
 #include "transform_forward_tile.inc"
+#undef HEVC_FWD_TILES_DECL
+#undef HEVC_FWD_ROW_IN
+#undef HEVC_FWD_ROW_OUT
 #undef HEVC_WG
 }
 template <bool DST>
@@ -532,6 +544,8 @@ struct ForwardRunsArgs
 template <bool DEQUANT>
 __global__ __launch_bounds__(kThreads) void inverse_runs_kernel(const InverseRunsArgs a)
 {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[(kThreads / 32) * InverseTiles<32>::DWORDS];      // 20 KiB: the larger of the two tile sizes
+	static_assert((kThreads / 32) * InverseTiles<32>::DWORDS >= (kThreads / 16) * InverseTiles<16>::DWORDS, "inverse runs LDS");
 	uint32_t wg;
 	const TuRunDev r = find_tu_run(a.table, wg);
 	const uint32_t *dof = a.dst_off + r.first, *pof = a.pred_off + r.first;
@@ -541,26 +555,37 @@ __global__ __launch_bounds__(kThreads) void inverse_runs_kernel(const InverseRun
 	case 0: inverse_lane_workgroup<4, true, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
 	case 1: inverse_lane_workgroup<4, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
 	case 2: inverse_lane_workgroup<8, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
-	case 3: inverse_tile_workgroup<16, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
-	case 4: inverse_tile_workgroup<32, false, DEQUANT>(a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 3: inverse_tile_workgroup<16, false, DEQUANT>(lds, a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
+	case 4: inverse_tile_workgroup<32, false, DEQUANT>(lds, a.dst, a.stride_dst, a.pred, a.stride_pred, dof, pof, c, r.scale, r.shift, r.count, wg); break;
 	default: break;
 	}
 }
 
+// CLASSES as for fused_tu_runs_kernel below: bit 0 = the sizes below 32x32, bit 1 = 32x32 on the matrix cores (+ 64 accumulation registers); a large call is
+// two launches so that the small sizes keep their occupancy, a frame-sized one a single launch of the combined kernel.
+template <int CLASSES>
 __global__ __launch_bounds__(kThreads) void forward_runs_kernel(const ForwardRunsArgs a)
 {
+	__shared__ __attribute__((aligned(16))) uint32_t lds[(kThreads / 16) * Tile<16>::HALFWORDS / 2];      // 10 KiB: 16x16 tiles; the 8x8 tiles fit
+	static_assert((kThreads / 16) * Tile<16>::HALFWORDS >= (kThreads / 8) * Tile<8>::HALFWORDS, "forward runs LDS");
 	uint32_t wg;
 	const TuRunDev r = find_tu_run(a.table, wg);
 	int16_t *c = a.coeffs + r.coeff_first;
 	const uint32_t *sof = a.src_off + r.first;
-	switch (r.variant)
+	if constexpr (CLASSES & 1)
 	{
-	case 0: forward4_lane_workgroup<true>(c, a.src, a.src_stride, sof, r.count, wg); break;
-	case 1: forward4_lane_workgroup<false>(c, a.src, a.src_stride, sof, r.count, wg); break;
-	case 2: forward_tile_workgroup<8, false>(c, a.src, a.src_stride, sof, r.count, wg); break;
-	case 3: forward_tile_workgroup<16, false>(c, a.src, a.src_stride, sof, r.count, wg); break;
-	case 4: forward32_mfma_workgroup(c, a.src, a.src_stride, sof, r.count, wg); break;
-	default: break;
+		switch (r.variant)
+		{
+		case 0: forward4_lane_workgroup<true>(c, a.src, a.src_stride, sof, r.count, wg); break;
+		case 1: forward4_lane_workgroup<false>(c, a.src, a.src_stride, sof, r.count, wg); break;
+		case 2: forward_tile_workgroup<8, false>(lds, c, a.src, a.src_stride, sof, r.count, wg); break;
+		case 3: forward_tile_workgroup<16, false>(lds, c, a.src, a.src_stride, sof, r.count, wg); break;
+		default: break;
+		}
+	}
+	if constexpr (CLASSES & 2)
+	{
+		if (r.variant == 4) forward32_mfma_workgroup(c, a.src, a.src_stride, sof, r.count, wg);
 	}
 }
 
@@ -958,17 +983,37 @@ extern "C" int hevcasm_hip_transform_runs(
 	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
 	if (n_runs == 0) return 0;
 	if (!runs || !coeffs || !src || !src_off) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
-	std::vector<TuRunTable> tables;
-	std::vector<uint32_t> grids;
-	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
-			if (int e = tu_variant(r, variant)) return e;
-			bpwg = kForwardRunBlocksPerWg[variant];
-			return 0; }, tables, grids)) return e;
-	for (size_t i = 0; i < tables.size(); ++i)
+	std::vector<hevcasm_hip_tu_run> part[2];
+	uint64_t wgs_all = 0;
+	for (int i = 0; i < n_runs; ++i)
 	{
-		ForwardRunsArgs a = { coeffs, src, src_stride, src_off, tables[i] };
-		hipLaunchKernelGGL(forward_runs_kernel, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
-		if (int e = launch_status("forward_runs_kernel")) return e;
+		part[runs[i].log2TrafoSize == 5].push_back(runs[i]);
+		if (runs[i].log2TrafoSize >= 2 && runs[i].log2TrafoSize <= 5) wgs_all += ceil_div(runs[i].count, kForwardRunBlocksPerWg[runs[i].log2TrafoSize == 2 ? 0 : runs[i].log2TrafoSize - 1]);
+	}
+	const bool split = !part[0].empty() && !part[1].empty() && wgs_all > (uint64_t)device_cus() * 8;
+	if (!split) { part[0].insert(part[0].end(), part[1].begin(), part[1].end()); part[1].clear(); }
+	for (int p = -1; p < 2; ++p)      // p = -1: every run is checked before anything is launched
+	{
+		if (p >= 0 && part[p].empty()) continue;
+		const hevcasm_hip_tu_run *rp = p < 0 ? runs : part[p].data();
+		const int n_part = p < 0 ? n_runs : (int)part[p].size();
+		bool any_small = false, any_big = false;
+		for (int i = 0; i < n_part; ++i) { if (rp[i].count == 0) continue; (rp[i].log2TrafoSize == 5 ? any_big : any_small) = true; }
+		std::vector<TuRunTable> tables;
+		std::vector<uint32_t> grids;
+		if (int e = build_tu_tables(rp, n_part, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
+				if (int e = tu_variant(r, variant)) return e;
+				bpwg = kForwardRunBlocksPerWg[variant];
+				return 0; }, tables, grids)) return e;
+		if (p < 0) continue;
+		for (size_t i = 0; i < tables.size(); ++i)
+		{
+			ForwardRunsArgs a = { coeffs, src, src_stride, src_off, tables[i] };
+			if (any_small && any_big) hipLaunchKernelGGL(forward_runs_kernel<3>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			else if (any_big) hipLaunchKernelGGL(forward_runs_kernel<2>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			else hipLaunchKernelGGL(forward_runs_kernel<1>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
+			if (int e = launch_status("forward_runs_kernel")) return e;
+		}
 	}
 	return 0;
 }

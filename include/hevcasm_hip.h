@@ -387,7 +387,8 @@ int hevcasm_hip_quantize_reconstruct_batch(
  * coefficient array (for TUs that tile a frame, runs laid end to end: frame_w x frame_h elements in all).  scale / shift / offset are the run's (de)quantiser
  * parameters -- HEVC's shifts depend on the TU size -- read by hevcasm_hip_quantize_runs (all three) and hevcasm_hip_dequant_inverse_transform_add_runs (scale,
  * shift), ignored by the other two.  `runs` is a HOST array read during the call (32 runs per launch; more = more launches, made by the call).  Per TU exactly
- * the result of the one-size call (hevcasm_hip_transform_batch, _quantize_batch, _inverse_transform_add_batch, _dequant_inverse_transform_add_batch) with the
+ * the result of the one-size call (hevcasm_hip_transform_batch, _quantize_batch, _inverse_transform_add_batch, _dequant_inverse_transform_add_batch,
+ * _quantize_reconstruct_batch) with the
  * run's size and parameters, which also gives the domain of every field; a bad run refuses the whole call (HEVCASM_HIP_EINVAL) before anything is launched.
  * Offsets are relative to ONE base pointer and stride per call: planes that share a stride (Cb and Cr; or all three of a frame kept at the luma stride) go in one
  * call when they lie in one allocation. */
@@ -414,6 +415,12 @@ int hevcasm_hip_inverse_transform_add_runs(
 int hevcasm_hip_dequant_inverse_transform_add_runs(
 	uint8_t *dst, ptrdiff_t stride_dst, const uint8_t *pred, ptrdiff_t stride_pred,
 	const uint32_t *dst_off, const uint32_t *pred_off, const int16_t *levels,
+	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
+/* hevcasm_quantize_reconstruct (quantize.h:99) for units of every size in one launch: per unit exactly hevcasm_hip_quantize_reconstruct_batch with nCbS =
+ * 1 << log2TrafoSize; the run's residual blocks start at element coeff_first of `res`; trType and the quantiser fields are not read. */
+int hevcasm_hip_quantize_reconstruct_runs(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *pred_off, const int16_t *res,
 	const hevcasm_hip_tu_run *runs, int n_runs, void *stream);
 
 /* An encoder's residual loop for a frame's TUs in ONE launch (round 6): per TU  src - pred  ->  hevcasm_transform  ->  hevcasm_quantize  (levels and cbf out)

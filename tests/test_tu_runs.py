@@ -99,6 +99,7 @@ def test_tu_runs_entry_points_refuse_without_a_gpu():
         for f in (L.hevcasm_hip_inverse_transform_add_runs, L.hevcasm_hip_dequant_inverse_transform_add_runs):
             assert f(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
         assert L.hevcasm_hip_transform_quantize_reconstruct_runs(None, 0, None, 0, None, 0, None, None, None, None, None, None, None, 1, None) == capi.ENODEV
+        assert L.hevcasm_hip_quantize_reconstruct_runs(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
 
 
 @pytest.mark.gpu
@@ -128,6 +129,33 @@ def test_hip_tu_chain_small_frames_extremes_in_place(oracle_lib):
             (want,) = _oracle(oracle_lib, c, stage, levels)
             assert np.array_equal(_hip(c, stage, levels)[0], want), (w, h, stage)
             assert np.array_equal(_hip(c, stage, levels, in_place=True)[0], want), (w, h, stage, "in place")
+
+
+@pytest.mark.gpu
+def test_hip_quantize_reconstruct_runs_equals_the_oracle(oracle_lib):
+    """hevcasm_quantize_reconstruct (quantize.h:99) for a plane's units of every size in one launch: per run the oracle's one-size batch; full-range residuals
+    (both clips), in place, a bad run refused."""
+    import torch
+    from hevcasm_amd import batch as B
+    for (w, h, kind, pad) in ((1920, 1080, "video", 64), (200, 136, "noise", 0), (64, 64, "max", 4)):
+        c = wl.tu_frame_case(w, h, 90 + w, kind=kind, pad=pad)
+        res = wl.fill_i16(c["n_coeffs"], 5 + w, "full" if kind != "video" else "residual9")
+        want = np.zeros(c["stride"] * c["h"], dtype=np.uint8)
+        for (log2, tr, first, count, cf) in c["sizes"]:
+            o = c["off"][first:first + count]
+            want |= oracle_lib.quantize_reconstruct_batch(want.size, c["stride"], c["pred"], c["stride"], o, o, res[cf:cf + (count << (2 * log2))], 1 << log2)
+        off, m = B.off32(c["off"]), _mask(c)
+        for in_place in (False, True):
+            pred = B.u8(c["pred"])
+            rec = pred if in_place else torch.zeros(want.size, dtype=torch.uint8, device="cuda")
+            got = B.quantize_reconstruct_runs(rec, c["stride"], pred, c["stride"], off, off, torch.from_numpy(res).cuda(), c["runs_q"]).cpu().numpy()
+            assert np.array_equal(got[m], want[m]), (w, h, in_place)
+            assert np.array_equal(got[~m], c["pred"][~m] if in_place else np.zeros_like(got[~m]))
+    bad = c["runs_q"][:1].copy(); bad["log2"] = 6
+    z = torch.zeros(1 << 14, dtype=torch.int16, device="cuda")
+    L = capi.lib()
+    assert L.hevcasm_hip_quantize_reconstruct_runs(z.data_ptr(), 64, z.data_ptr(), 64, off.data_ptr(), off.data_ptr(), z.data_ptr(), bad.ctypes.data, 1, None) == capi.EINVAL
+    assert L.hevcasm_hip_quantize_reconstruct_runs(z.data_ptr(), 64, z.data_ptr(), 64, off.data_ptr(), off.data_ptr(), z.data_ptr(), bad.ctypes.data, 0, None) == 0
 
 
 def _fused_oracle(oracle_lib, c):
