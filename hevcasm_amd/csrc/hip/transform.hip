@@ -653,11 +653,14 @@ template <int N> __device__ __forceinline__ void residual_row(const uint8_t *c, 
 	}
 }
 
-// quantize.c:160-186 (abs() in int, so -32768 becomes 32768) and quantize.c:53-62, as quant.hip has them; scale24 / dscale24 carry 24 significant bits
-__device__ __forceinline__ int fused_quantize(int v, int scale24, int round, int shift)
+// quantize.c:160-186: level = sign(v) * ((|v| * scale + round) >> shift), clipped to int16.  This kernel is bound by its vector instructions, so the same number
+// in four of them instead of nine: with a = v * scale (exact in 32 bits), -floor((-a + round) / 2^shift) = ceil((a - round) / 2^shift) = floor((a + 2^shift - 1 - round)
+// / 2^shift), and an arithmetic shift is that floor -- so a negative v only takes another rounding constant (neg_round = 2^shift - 1 - round); -32768 needs no
+// special case (the reference's abs() is an int).  The clip cannot act: |v| <= 2^15, scale < 2^15, shift >= 16, round < 2^(shift - 1) (the entry point checks the
+// last three) => |level| <= 2^14.  quantize.c:53-62 below as quant.hip has it; scale24 / dscale24 carry 24 significant bits.
+__device__ __forceinline__ int fused_quantize(int v, int scale24, int round, int neg_round, int shift)
 {
-	const int mag = ((v < 0 ? -v : v) * scale24 + round) >> shift;
-	return clip3(-32768, 32767, v < 0 ? -mag : mag);
+	return (v * scale24 + (v < 0 ? neg_round : round)) >> shift;
 }
 __device__ __forceinline__ int fused_dequantize(int level, int dscale24, int dround, int dshift) { return clip3(-32768, 32767, (level * dscale24 + dround) >> dshift); }
 
@@ -688,13 +691,13 @@ __device__ __forceinline__ void fused_tile_workgroup(uint32_t *lds,
 #undef HEVC_FWD_ROW_OUT
 	}
 	{
-		const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+		const int qround = qoffset << (qshift - 16), qneg = (1 << qshift) - 1 - qround, dround = 1 << (dshift - 1);
 		const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
 		int lev[N], any = 0;
 #pragma unroll
 		for (int k = 0; k < N; ++k)
 		{
-			lev[k] = fused_quantize(row[k], scale24, qround, qshift);
+			lev[k] = fused_quantize(row[k], scale24, qround, qneg, qshift);
 			any |= lev[k];
 			row[k] = fused_dequantize(lev[k], dscale24, dround, dshift);
 		}
@@ -730,7 +733,7 @@ __device__ __forceinline__ void fused_mfma32_workgroup(uint32_t *lds,
 	int16_t *__restrict__ levels, int *__restrict__ cbf, int qscale, int qshift, int qoffset, int dscale, int dshift, uint32_t n_blocks, const uint32_t wg_in_batch)
 {
 	constexpr int N = 32, SS = Tile<32>::S, TILE = Tile<32>::HALFWORDS;
-	const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+	const int qround = qoffset << (qshift - 16), qneg = (1 << qshift) - 1 - qround, dround = 1 << (dshift - 1);
 	const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
 	int16_t *stage = reinterpret_cast<int16_t *>(lds);
 #define HEVC_WG wg_in_batch
@@ -757,8 +760,8 @@ __device__ __forceinline__ void fused_mfma32_workgroup(uint32_t *lds,
 #define HEVC_FWD32_VALUES(blk, i, v0, v1) \
 		{ \
 			int16_t *tile_ = stage + ((threadIdx.x >> 6) * BPW + (blk - first)) * TILE + r; \
-			v0 = fused_quantize((int)(int16_t)v0, scale24, qround, qshift); \
-			v1 = fused_quantize((int)(int16_t)v1, scale24, qround, qshift); \
+			v0 = fused_quantize((int)(int16_t)v0, scale24, qround, qneg, qshift); \
+			v1 = fused_quantize((int)(int16_t)v1, scale24, qround, qneg, qshift); \
 			any |= v0 | v1; \
 			tile_[((i & 3) + 8 * (i >> 2) + 4 * h) * SS] = (int16_t)fused_dequantize(v0, dscale24, dround, dshift); \
 			tile_[(((i + 1) & 3) + 8 * ((i + 1) >> 2) + 4 * h) * SS] = (int16_t)fused_dequantize(v1, dscale24, dround, dshift); \
@@ -801,7 +804,7 @@ __device__ __forceinline__ void fused_lane4_workgroup(
 	const uint32_t *__restrict__ dst_off, const uint32_t *__restrict__ cur_off, const uint32_t *__restrict__ pred_off,
 	int16_t *__restrict__ levels, int *__restrict__ cbf, int qscale, int qshift, int qoffset, int dscale, int dshift, uint32_t n_blocks, const uint32_t wg_in_batch)
 {
-	const int qround = qoffset << (qshift - 16), dround = 1 << (dshift - 1);
+	const int qround = qoffset << (qshift - 16), qneg = (1 << qshift) - 1 - qround, dround = 1 << (dshift - 1);
 	const int scale24 = (qscale << 8) >> 8, dscale24 = (dscale << 8) >> 8;
 	uint32_t lev_pairs[8], deq_pairs[8];      // row k, columns (2j, 2j + 1) in dword 2k + j, low half first: the coefficient block as it lies in memory
 	int any = 0;
@@ -816,7 +819,7 @@ __device__ __forceinline__ void fused_lane4_workgroup(
 			_Pragma("unroll") \
 			for (int x = 0; x < 4; ++x) \
 			{ \
-				l_[x] = fused_quantize(coef[x], scale24, qround, qshift); \
+				l_[x] = fused_quantize(coef[x], scale24, qround, qneg, qshift); \
 				any |= l_[x]; \
 				d_[x] = fused_dequantize(l_[x], dscale24, dround, dshift); \
 			} \
