@@ -69,6 +69,7 @@ def small_cases():
     out += [x for x in cases.intra_cases() if x[0].endswith("_s160")]
     out += [x for x in cases.ssd_linear_cases() if x[0] in ("ssdlin_17", "ssdlin_512", "ssdlin_1023", "ssdlin_4099")]
     out += [x for x in cases.frame_sse_cases() if x[0] in ("fsse_17x33", "fsse_257x5", "fsse_bottom_up")]
+    out += [x for x in cases.tu_chain_cases() if x[0] in ("tuchain_white_on_black_64x64_qp0", "tuchain_video_4x4_qp20", "tuchain_noise_96x160_qp12")]      # round 6: the residual loop
     return out
 
 
