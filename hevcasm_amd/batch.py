@@ -231,6 +231,20 @@ def transform_quantize_reconstruct_runs(rec, stride_rec, src, stride_src, pred, 
     return rec, levels, cbf
 
 
+def transform_quantize_reconstruct_planes(planes, rec_off, src_off, pred_off, runs_q, runs_dq, levels, cbf):
+    """hevcasm_hip_transform_quantize_reconstruct_planes: the residual loop over the planes of a frame (luma, Cb, Cr: own pointers and strides) in ONE launch.
+    planes: list of (rec tensor, stride_rec, src tensor, stride_src, pred tensor, stride_pred); a run's `plane` field picks its plane."""
+    import ctypes as C
+    runs_q, runs_dq = _tu_runs(runs_q), _tu_runs(runs_dq)
+    assert len(runs_q) == len(runs_dq)
+    table = (C.c_int64 * (6 * len(planes)))()      # hevcasm_hip_tu_plane = { rec, src, pred, stride_rec, stride_src, stride_pred }: six 8-byte members
+    for i, (rec, srec, src, ssrc, pred, spred) in enumerate(planes):
+        table[6 * i:6 * i + 6] = [rec.data_ptr(), src.data_ptr(), pred.data_ptr(), srec, ssrc, spred]
+    check(lib().hevcasm_hip_transform_quantize_reconstruct_planes(table, len(planes), rec_off.data_ptr(), src_off.data_ptr(), pred_off.data_ptr(), levels.data_ptr(), cbf.data_ptr(),
+                                                                  runs_q.ctypes.data, runs_dq.ctypes.data, len(runs_q), _stream()), "transform_quantize_reconstruct_planes")
+    return [p[0] for p in planes], levels, cbf
+
+
 def _result_rows(out, n, like):
     """The (dx, dy, cost) table of n answers: allocated, or the caller's, checked -- the entry points write 12 n bytes through a raw pointer
     (and, for small launches, memset them first), so a short, strided, int64 or other-device `out` would be overrun or silently misread."""

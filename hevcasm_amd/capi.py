@@ -54,6 +54,7 @@ HIP_API = {
     "hevcasm_hip_quantize_runs": (_i, [_vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_inverse_transform_add_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_dequant_inverse_transform_add_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
+    "hevcasm_hip_transform_quantize_reconstruct_planes": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_quantize_reconstruct_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_transform_quantize_reconstruct_runs": (_i, [_vp, _pd, _vp, _pd, _vp, _pd, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "hevcasm_hip_me_full_search_batch": (_i, [_vp, _pd, _vp, _pd, _vp, _vp, _vp, _u32, _i, _sz, _vp]),

@@ -188,7 +188,7 @@ extern "C" int hevcasm_hip_quantize_reconstruct_runs(uint8_t *rec, ptrdiff_t str
 	std::vector<TuRunTable> tables;
 	std::vector<uint32_t> grids;
 	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
-			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.reserved) return set_error(HEVCASM_HIP_EINVAL, "run: nCbS must be 4, 8, 16 or 32 (log2TrafoSize 2..5), reserved 0");
+			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.plane) return set_error(HEVCASM_HIP_EINVAL, "run: nCbS must be 4, 8, 16 or 32 (log2TrafoSize 2..5), plane 0");
 			variant = (uint32_t)r.log2TrafoSize - 2u;
 			bpwg = kReconstructRunBlocksPerWg[variant];
 			return 0; }, tables, grids)) return e;
@@ -210,7 +210,7 @@ extern "C" int hevcasm_hip_quantize_runs(int16_t *dst, const int16_t *src, int *
 	std::vector<TuRunTable> tables;
 	std::vector<uint32_t> grids;
 	if (int e = build_tu_tables(runs, n_runs, [](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
-			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.reserved) return set_error(HEVCASM_HIP_EINVAL, "run: log2TrafoSize must be 2..5 (16, 64, 256 or 1024 coefficients per block), reserved 0");
+			if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.plane) return set_error(HEVCASM_HIP_EINVAL, "run: log2TrafoSize must be 2..5 (16, 64, 256 or 1024 coefficients per block), plane 0");
 			// the domain of hevcasm_hip_quantize_batch (quantize.c:162-168)
 			if (r.scale < 0 || r.scale >= 0x8000 || r.offset < 0 || r.offset >= 0x8000 || r.shift < 16 || r.shift > 27)
 				return set_error(HEVCASM_HIP_EINVAL, "run: scale/offset/shift outside the reference's domain (0 <= scale, offset < 0x8000; 16 <= shift <= 27)");

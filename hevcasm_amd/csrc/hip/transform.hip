@@ -590,10 +590,10 @@ __global__ __launch_bounds__(kThreads) void forward_runs_kernel(const ForwardRun
 }
 
 // a run's size and type -> variant; the checks of the one-size entry points
-static int tu_variant(const hevcasm_hip_tu_run &r, uint32_t &variant)
+static int tu_variant(const hevcasm_hip_tu_run &r, uint32_t &variant, int n_planes = 1)
 {
-	if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.trType > 1 || (r.trType && r.log2TrafoSize != 2) || r.reserved)
-		return set_error(HEVCASM_HIP_EINVAL, "run: transform size/type not supported by the reference (log2TrafoSize 2..5, trType 1 only at 2, reserved 0)");
+	if (r.log2TrafoSize < 2 || r.log2TrafoSize > 5 || r.trType > 1 || (r.trType && r.log2TrafoSize != 2) || (int)r.plane >= n_planes)
+		return set_error(HEVCASM_HIP_EINVAL, "run: transform size/type not supported by the reference (log2TrafoSize 2..5, trType 1 only at 2), or plane beyond the call's planes");
 	variant = r.log2TrafoSize == 2 ? (r.trType ? 0u : 1u) : (uint32_t)r.log2TrafoSize - 1u;
 	return 0;
 }
@@ -857,11 +857,10 @@ __device__ __forceinline__ void fused_lane4_workgroup(
 
 constexpr uint32_t kFusedRunBlocksPerWg[5] = { kThreads, kThreads, kThreads / 8, kThreads / 16, kThreads / 32 };
 
+constexpr int kMaxTuPlanes = 4;
 struct FusedRunsArgs
 {
-	uint8_t *dst;
-	const uint8_t *cur, *pred;
-	ptrdiff_t stride_dst, stride_cur, stride_pred;
+	hevcasm_hip_tu_plane planes[kMaxTuPlanes];      // a run's plane: luma, Cb, Cr of a frame in one launch
 	const uint32_t *dst_off, *cur_off, *pred_off;
 	int16_t *levels;
 	int *cbf;
@@ -879,7 +878,8 @@ __global__ __launch_bounds__(kThreads) void fused_tu_runs_kernel(const FusedRuns
 	const uint32_t *dof = a.dst_off + r.first, *cof = a.cur_off + r.first, *pof = a.pred_off + r.first;
 	int16_t *lv = a.levels + r.coeff_first;
 	int *cbf = a.cbf + r.first;
-#define HEVC_FUSED_ARGS a.dst, a.stride_dst, a.cur, a.stride_cur, a.pred, a.stride_pred, dof, cof, pof, lv, cbf, r.scale, r.shift, r.offset, r.dscale, r.dshift, r.count, wg
+	const hevcasm_hip_tu_plane P = a.planes[r.plane];
+#define HEVC_FUSED_ARGS P.rec, P.stride_rec, P.src, P.stride_src, P.pred, P.stride_pred, dof, cof, pof, lv, cbf, r.scale, r.shift, r.offset, r.dscale, r.dshift, r.count, wg
 	if constexpr (CLASSES & 1)
 	{
 		switch (r.variant)
@@ -902,15 +902,18 @@ __global__ __launch_bounds__(kThreads) void fused_tu_runs_kernel(const FusedRuns
 
 using namespace hevc;
 
-extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
-	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *pred, ptrdiff_t stride_pred,
+extern "C" int hevcasm_hip_transform_quantize_reconstruct_planes(
+	const hevcasm_hip_tu_plane *planes, int n_planes,
 	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
 	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream)
 {
 	if (int e = check_device()) return e;
 	if (n_runs < 0) return set_error(HEVCASM_HIP_EINVAL, "negative run count");
+	if (n_planes < 1 || n_planes > kMaxTuPlanes) return set_error(HEVCASM_HIP_EINVAL, "1 to 4 planes per call");
 	if (n_runs == 0) return 0;
-	if (!runs_quantize || !runs_dequantize || !rec || !src || !pred || !rec_off || !src_off || !pred_off || !levels || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	if (!planes || !runs_quantize || !runs_dequantize || !rec_off || !src_off || !pred_off || !levels || !cbf) return set_error(HEVCASM_HIP_EINVAL, "null pointer");
+	for (int i = 0; i < n_planes; ++i)
+		if (!planes[i].rec || !planes[i].src || !planes[i].pred) return set_error(HEVCASM_HIP_EINVAL, "null plane pointer");
 	// validated first; then split by class when the call is large (see fused_tu_runs_kernel)
 	std::vector<hevcasm_hip_tu_run> q[2], dq[2];
 	uint64_t wgs_all = 0;
@@ -939,9 +942,9 @@ extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
 		std::vector<TuRunTable> tables;
 		std::vector<uint32_t> grids;
 		if (int e = build_tu_tables(rq, n_part, [=](const hevcasm_hip_tu_run &r, uint32_t &variant, uint32_t &bpwg) {
-			if (int e = tu_variant(r, variant)) return e;
+			if (int e = tu_variant(r, variant, n_planes)) return e;
 			const hevcasm_hip_tu_run &d = rdq[&r - rq];
-			if (d.first != r.first || d.count != r.count || d.coeff_first != r.coeff_first || d.log2TrafoSize != r.log2TrafoSize || d.trType != r.trType || d.reserved)
+			if (d.first != r.first || d.count != r.count || d.coeff_first != r.coeff_first || d.log2TrafoSize != r.log2TrafoSize || d.trType != r.trType || d.plane != r.plane)
 				return set_error(HEVCASM_HIP_EINVAL, "run: the dequantiser's run must describe the same units as the quantiser's");
 			// the domains of hevcasm_hip_quantize_batch (quantize.c:162-168) and of hevcasm_hip_dequant_inverse_transform_add_batch
 			if (r.scale < 0 || r.scale >= 0x8000 || r.offset < 0 || r.offset >= 0x8000 || r.shift < 16 || r.shift > 27)
@@ -952,7 +955,9 @@ extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
 		if (part < 0) continue;
 		for (size_t i = 0; i < tables.size(); ++i)
 		{
-			FusedRunsArgs a = { rec, src, pred, stride_rec, stride_src, stride_pred, rec_off, src_off, pred_off, levels, cbf, tables[i] };
+			FusedRunsArgs a = {};
+			for (int k = 0; k < n_planes; ++k) a.planes[k] = planes[k];
+			a.dst_off = rec_off; a.cur_off = src_off; a.pred_off = pred_off; a.levels = levels; a.cbf = cbf; a.table = tables[i];
 			if (any_small && any_big) hipLaunchKernelGGL(fused_tu_runs_kernel<3>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
 			else if (any_big) hipLaunchKernelGGL(fused_tu_runs_kernel<2>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
 			else hipLaunchKernelGGL(fused_tu_runs_kernel<1>, dim3(grids[i]), dim3(kThreads), 0, as_stream(stream), a);
@@ -960,6 +965,16 @@ extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
 		}
 	}
 	return 0;
+}
+
+extern "C" int hevcasm_hip_transform_quantize_reconstruct_runs(
+	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
+	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream)
+{
+	if (n_runs > 0 && (!rec || !src || !pred)) { if (int e = check_device()) return e; return set_error(HEVCASM_HIP_EINVAL, "null pointer"); }
+	const hevcasm_hip_tu_plane plane = { rec, src, pred, stride_rec, stride_src, stride_pred };
+	return hevcasm_hip_transform_quantize_reconstruct_planes(&plane, 1, rec_off, src_off, pred_off, levels, cbf, runs_quantize, runs_dequantize, n_runs, stream);
 }
 
 extern "C" int hevcasm_hip_inverse_transform_add_runs(

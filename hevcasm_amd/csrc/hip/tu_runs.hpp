@@ -23,6 +23,7 @@ struct TuRunDev
 	int scale, shift, offset;      // the run's (de)quantiser parameters
 	int dscale, dshift;            // the dequantiser's beside the quantiser's (the fused transform + quantise + reconstruct kernel only)
 	uint32_t variant;              // which workgroup body
+	uint32_t plane;                // which plane of the call (the fused residual loop over a frame's planes; 0 elsewhere)
 };
 
 struct TuRunTable
@@ -69,6 +70,7 @@ static int build_tu_tables(const hevcasm_hip_tu_run *runs, int n_runs, VariantOf
 		d.scale = runs[i].scale; d.shift = runs[i].shift; d.offset = runs[i].offset;
 		d.dscale = dequant_runs ? dequant_runs[i].scale : 0; d.dshift = dequant_runs ? dequant_runs[i].shift : 0;
 		d.variant = variant;
+		d.plane = runs[i].plane;
 		all.push_back(d);
 	}
 	std::stable_sort(all.begin(), all.end(), [](const TuRunDev &a, const TuRunDev &b) { return a.variant > b.variant; });   // variants ascend with the unit's size

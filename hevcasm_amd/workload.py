@@ -424,7 +424,7 @@ def cost_frame_case(w, h, seed, border=80, kind="noise", search=7):
 # a frame's transform units: the four sizes of the reference's transform tables (residual_decode.h:54, :82), one launch per stage (hevcasm_hip_*_runs over
 # hevcasm_hip_tu_run: transform, quantize, inverse_transform_add, dequant_inverse_transform_add)
 
-TU_RUN_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("coeff_first", "<u4"), ("log2", "u1"), ("tr_type", "u1"), ("reserved", "<u2"),
+TU_RUN_DTYPE = np.dtype([("first", "<u4"), ("count", "<u4"), ("coeff_first", "<u4"), ("log2", "u1"), ("tr_type", "u1"), ("plane", "<u2"),
                          ("scale", "<i4"), ("shift", "<i4"), ("offset", "<i4")])      # = hevcasm_hip_tu_run, 28 bytes
 
 

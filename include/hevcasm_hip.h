@@ -389,7 +389,7 @@ int hevcasm_hip_quantize_reconstruct_batch(
  * shift), ignored by the other two.  `runs` is a HOST array read during the call (32 runs per launch; more = more launches, made by the call).  Per TU exactly
  * the result of the one-size call (hevcasm_hip_transform_batch, _quantize_batch, _inverse_transform_add_batch, _dequant_inverse_transform_add_batch,
  * _quantize_reconstruct_batch) with the
- * run's size and parameters, which also gives the domain of every field; a bad run refuses the whole call (HEVCASM_HIP_EINVAL) before anything is launched.
+ * run's size and parameters, which also gives the domain of every field (`plane` must be 0); a bad run refuses the whole call (HEVCASM_HIP_EINVAL) before anything is launched.
  * Offsets are relative to ONE base pointer and stride per call: planes that share a stride (Cb and Cr; or all three of a frame kept at the luma stride) go in one
  * call when they lie in one allocation. */
 typedef struct
@@ -398,7 +398,7 @@ typedef struct
 	uint32_t coeff_first;        /* first int16 element of the run's coefficient / level blocks */
 	uint8_t log2TrafoSize;       /* 2..5 */
 	uint8_t trType;              /* 1 = the 4x4 DST (log2TrafoSize 2 only) */
-	uint16_t reserved;           /* 0 */
+	uint16_t plane;              /* hevcasm_hip_transform_quantize_reconstruct_planes: index into planes[]; every other entry point: 0 */
 	int32_t scale, shift, offset;
 } hevcasm_hip_tu_run;
 
@@ -432,6 +432,20 @@ int hevcasm_hip_quantize_reconstruct_runs(
  * and stride (in-place reconstruction); offsets are in bytes of their planes. */
 int hevcasm_hip_transform_quantize_reconstruct_runs(
 	uint8_t *rec, ptrdiff_t stride_rec, const uint8_t *src, ptrdiff_t stride_src, const uint8_t *pred, ptrdiff_t stride_pred,
+	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
+	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream);
+
+/* The same for the planes of a frame in ONE launch -- luma, Cb and Cr have their own pointers and strides: run i works on planes[runs_quantize[i].plane]; the
+ * offset arrays, levels and cbf are shared (a run's `first` / `coeff_first` say where its entries lie), n_planes <= 4.  Per unit exactly the single-plane call. */
+typedef struct
+{
+	uint8_t *rec;
+	const uint8_t *src, *pred;
+	ptrdiff_t stride_rec, stride_src, stride_pred;
+} hevcasm_hip_tu_plane;
+
+int hevcasm_hip_transform_quantize_reconstruct_planes(
+	const hevcasm_hip_tu_plane *planes, int n_planes,
 	const uint32_t *rec_off, const uint32_t *src_off, const uint32_t *pred_off, int16_t *levels, int *cbf,
 	const hevcasm_hip_tu_run *runs_quantize, const hevcasm_hip_tu_run *runs_dequantize, int n_runs, void *stream);
 

@@ -100,6 +100,7 @@ def test_tu_runs_entry_points_refuse_without_a_gpu():
             assert f(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
         assert L.hevcasm_hip_transform_quantize_reconstruct_runs(None, 0, None, 0, None, 0, None, None, None, None, None, None, None, 1, None) == capi.ENODEV
         assert L.hevcasm_hip_quantize_reconstruct_runs(None, 0, None, 0, None, None, None, None, 1, None) == capi.ENODEV
+        assert L.hevcasm_hip_transform_quantize_reconstruct_planes(None, 1, None, None, None, None, None, None, None, 1, None) == capi.ENODEV
 
 
 @pytest.mark.gpu
@@ -224,6 +225,43 @@ def test_hip_fused_large_call_two_launches_and_many_runs(oracle_lib):
 
 
 @pytest.mark.gpu
+def test_hip_fused_residual_loop_over_the_three_planes_of_a_frame_in_one_launch(oracle_lib):
+    """hevcasm_hip_transform_quantize_reconstruct_planes: luma, Cb and Cr of a 4:2:0 frame -- each with its own partition, stride and QP -- in ONE launch: per plane
+    the oracle's composition (== the single-plane call); a plane index beyond the call's planes is refused."""
+    import torch
+    from hevcasm_amd import batch as B
+    cs = [wl.tu_frame_case(416, 240, 5, qp=27, pad=32), wl.tu_frame_case(208, 120, 6, qp=30, pad=0, kind="noise"), wl.tu_frame_case(208, 120, 7, qp=33, pad=8, src_kind="max")]
+    off, rq, rdq, first, coeff = [], [], [], 0, 0
+    for plane, c in enumerate(cs):
+        off.append(c["off"])
+        for src_runs, out in ((c["runs_q"], rq), (c["runs_dq"], rdq)):
+            r = src_runs.copy()
+            r["first"] += first; r["coeff_first"] += coeff; r["plane"] = plane
+            out.append(r)
+        first += c["n_tus"]; coeff += c["n_coeffs"]
+    # interleave the planes' runs: the order of the runs must not matter
+    order = np.argsort(np.concatenate([np.arange(len(r)) * 3 + i for i, r in enumerate(rq)]), kind="stable")
+    rq, rdq = np.concatenate(rq)[order], np.concatenate(rdq)[order]
+    o = B.off32(np.concatenate(off))
+    planes = [(torch.zeros(c["stride"] * c["h"], dtype=torch.uint8, device="cuda"), c["stride"], B.u8(c["src"]), c["stride"], B.u8(c["pred"]), c["stride"]) for c in cs]
+    levels, cbf = torch.zeros(coeff, dtype=torch.int16, device="cuda"), torch.zeros(first, dtype=torch.int32, device="cuda")
+    B.transform_quantize_reconstruct_planes(planes, o, o, o, rq, rdq, levels, cbf)
+    torch.cuda.synchronize()
+    levels, cbf, first, coeff = levels.cpu().numpy(), cbf.cpu().numpy(), 0, 0
+    for plane, c in enumerate(cs):
+        want_levels, want_cbf, want_rec = _fused_oracle(oracle_lib, c)
+        m = _mask(c)
+        assert np.array_equal(levels[coeff:coeff + c["n_coeffs"]], want_levels) and np.array_equal(cbf[first:first + c["n_tus"]], want_cbf), "plane %d levels / flags" % plane
+        got = planes[plane][0].cpu().numpy()
+        assert np.array_equal(got[m], want_rec[m]) and not got[~m].any(), "plane %d reconstruction" % plane
+        first += c["n_tus"]; coeff += c["n_coeffs"]
+    bad = rq.copy(); bad["plane"][0] = 3
+    bad_dq = rdq.copy(); bad_dq["plane"][0] = 3
+    with pytest.raises(Exception):
+        B.transform_quantize_reconstruct_planes(planes, o, o, o, bad, bad_dq, torch.zeros(coeff, dtype=torch.int16, device="cuda"), torch.zeros(first, dtype=torch.int32, device="cuda"))
+
+
+@pytest.mark.gpu
 def test_hip_fused_residual_loop_equals_the_three_launches_and_refuses_bad_runs():
     import torch
     from hevcasm_amd import batch as B
@@ -245,7 +283,7 @@ def test_hip_fused_residual_loop_equals_the_three_launches_and_refuses_bad_runs(
     rq, rdq = c["runs_q"][:1].copy(), c["runs_dq"][:1].copy()
     rq["count"] = rdq["count"] = 1
     assert call(rq, rdq) == 0 and call(rq, rdq, 0) == 0
-    for field, value in (("count", 2), ("first", 1), ("coeff_first", 16), ("log2", 3), ("tr_type", 0), ("reserved", 1)):
+    for field, value in (("count", 2), ("first", 1), ("coeff_first", 16), ("log2", 3), ("tr_type", 0), ("plane", 1)):
         bad = rdq.copy(); bad[field] = value
         assert call(rq, bad) == capi.EINVAL, field
     for field, value in (("shift", 15), ("shift", 28), ("scale", 0x8000), ("offset", -1)):
@@ -300,12 +338,12 @@ def test_hip_tu_runs_many_runs_one_size_calls_and_bad_arguments(oracle_lib):
     deq = lambda r: inv(r, L.hevcasm_hip_dequant_inverse_transform_add_runs)
     assert fwd(run()) == 0 and qnt(run()) == 0 and inv(run()) == 0 and deq(run(shift=5)) == 0
     assert fwd(run(), 0) == 0 and fwd(run(count=0)) == 0
-    for bad in (run(log2=1), run(log2=6), run(tr_type=1), run(tr_type=2, log2=2), run(reserved=1)):
+    for bad in (run(log2=1), run(log2=6), run(tr_type=1), run(tr_type=2, log2=2), run(plane=1)):
         assert fwd(bad) == capi.EINVAL and inv(bad) == capi.EINVAL and deq(bad) == capi.EINVAL
     assert fwd(run(), -1) == capi.EINVAL
     assert L.hevcasm_hip_transform_runs(dev.data_ptr(), None, 64, off.data_ptr(), run().ctypes.data, 1, None) == capi.EINVAL
     assert L.hevcasm_hip_transform_runs(dev.data_ptr(), dev.data_ptr(), 64, off.data_ptr(), None, 1, None) == capi.EINVAL
-    for bad in (run(shift=15), run(shift=28), run(scale=0x8000), run(scale=-1), run(offset=0x8000), run(offset=-1), run(log2=6), run(reserved=2)):
+    for bad in (run(shift=15), run(shift=28), run(scale=0x8000), run(scale=-1), run(offset=0x8000), run(offset=-1), run(log2=6), run(plane=2)):
         assert qnt(bad) == capi.EINVAL
     for bad in (run(shift=0), run(shift=32), run(scale=40000), run(scale=-40000)):
         assert deq(bad) == capi.EINVAL
